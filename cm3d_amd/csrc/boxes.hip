@@ -1,0 +1,265 @@
+// a10-a15: nearest lane point, box assembly, class-aware circle NMS.
+//   reference: lane_yaws_distances_and_coords src/nuscenes/2d_to_3d.py:277-302,
+//   stage 2 :745-817 with push_centroid :164-198, circle_nms :309-332, thresholds :850-861.
+// All float64 like the reference (scipy cdist / numpy scalars).  FP64-VALU-bound (lane NN) and
+// latency-bound (NMS); no HBM roofline applies.
+#include "common.h"
+
+#define LN_THREADS 256
+#define LN_SLICES 32
+#define LN_TILE 512
+
+// Candidate update shared by both paths.  Reference: d = sqrt(dx*dx+dy*dy), first minimum of d.
+// sqrt is monotone, so a candidate with d2 >= d2cut (the d2 of the current best) cannot have a
+// strictly smaller sqrt and is skipped without evaluating it.
+static __device__ __forceinline__ void ln_update(double d2, int j, double &d2cut, double &sbest, int &jbest)
+{
+    if (d2 < d2cut) {
+        const double s = sqrt(d2);
+        if (s < sbest) { sbest = s; jbest = j; d2cut = d2; }
+    }
+}
+
+// grid (ceil(n_masks/256), LN_SLICES): thread = one centroid, block.y = one slice of its lane table
+__global__ __launch_bounds__(LN_THREADS) void k_lane_nn(const float *__restrict__ centroid,
+                                                         const int32_t *__restrict__ medoid_pos,
+                                                         const int32_t *__restrict__ mask_frame, int n_masks,
+                                                         const float *__restrict__ lane, const int32_t *__restrict__ lane_off,
+                                                         const int32_t *__restrict__ frame_lane,
+                                                         double *__restrict__ part_s, int32_t *__restrict__ part_j)
+{
+    __shared__ double2 s_lane[LN_TILE];
+    __shared__ int s_tb, s_uni;
+    const int k = blockIdx.x * LN_THREADS + threadIdx.x;
+    const int slice = blockIdx.y;
+    const bool act = k < n_masks && medoid_pos[k] >= 0;
+    const int tb = act ? frame_lane[mask_frame[k]] : -1;
+    if (threadIdx.x == 0) { s_tb = -2; s_uni = 1; }
+    __syncthreads();
+    if (act) {
+        const int old = atomicCAS(&s_tb, -2, tb);
+        if (old != -2 && old != tb) s_uni = 0;
+    }
+    __syncthreads();
+    if (s_tb == -2) return;                      // no centroid in this block
+    double cx = 0.0, cy = 0.0;
+    if (act) { cx = (double)centroid[3 * k]; cy = (double)centroid[3 * k + 1]; }
+    double d2cut = INFINITY, sbest = INFINITY;
+    int jbest = 0;
+    if (s_uni) {
+        // every centroid of the block uses the same table: stage it through LDS
+        const int tbu = s_tb;
+        const int lo = lane_off[tbu], L = lane_off[tbu + 1] - lo;
+        const int chunk = (L + LN_SLICES - 1) / LN_SLICES;
+        const int j0 = slice * chunk, j1 = min(L, j0 + chunk);
+        for (int t0 = j0; t0 < j1; t0 += LN_TILE) {
+            __syncthreads();
+            for (int q = threadIdx.x; q < LN_TILE && t0 + q < j1; q += LN_THREADS) {
+                const float *lp = lane + (size_t)(lo + t0 + q) * 3;
+                s_lane[q] = make_double2((double)lp[0], (double)lp[1]);
+            }
+            __syncthreads();
+            const int cnt = min(LN_TILE, j1 - t0);
+            if (act) {
+#pragma unroll 4
+                for (int q = 0; q < cnt; ++q) {
+                    const double2 lp = s_lane[q];
+                    const double dx = cx - lp.x, dy = cy - lp.y;
+                    ln_update(dx * dx + dy * dy, t0 + q, d2cut, sbest, jbest);
+                }
+            }
+        }
+    } else if (act) {
+        const int lo = lane_off[tb], L = lane_off[tb + 1] - lo;
+        const int chunk = (L + LN_SLICES - 1) / LN_SLICES;
+        const int j0 = slice * chunk, j1 = min(L, j0 + chunk);
+        for (int j = j0; j < j1; ++j) {
+            const float *lp = lane + (size_t)(lo + j) * 3;
+            const double dx = cx - (double)lp[0], dy = cy - (double)lp[1];
+            ln_update(dx * dx + dy * dy, j, d2cut, sbest, jbest);
+        }
+    }
+    if (k < n_masks) {
+        part_s[(size_t)slice * n_masks + k] = sbest;
+        part_j[(size_t)slice * n_masks + k] = jbest;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lane_nn_reduce(const int32_t *__restrict__ medoid_pos, int n_masks,
+                                                        const double *__restrict__ part_s, const int32_t *__restrict__ part_j,
+                                                        int32_t *__restrict__ lane_idx, double *__restrict__ lane_dist)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_masks) return;
+    if (medoid_pos[k] < 0) { lane_idx[k] = -1; lane_dist[k] = INFINITY; return; }
+    double sb = INFINITY; int jb = 0;
+    bool have = false;
+    for (int s = 0; s < LN_SLICES; ++s) {
+        const double v = part_s[(size_t)s * n_masks + k];
+        const int j = part_j[(size_t)s * n_masks + k];
+        // slices cover ascending j ranges, so a strict < keeps the first minimum
+        if (v < sb) { sb = v; jb = j; have = true; }
+    }
+    (void)have;
+    lane_idx[k] = jb;
+    lane_dist[k] = sb;
+}
+
+extern "C" int64_t cm3d_lane_nn_workspace_bytes(int32_t n_masks)
+{
+    return n_masks > 0 ? (int64_t)n_masks * LN_SLICES * (int64_t)(sizeof(double) + sizeof(int32_t)) : 0;
+}
+
+extern "C" int cm3d_lane_nn(const float *centroid, const int32_t *medoid_pos, const int32_t *mask_frame, int32_t n_masks,
+                            const float *lane, const int32_t *lane_off, const int32_t *frame_lane, int32_t *lane_idx,
+                            double *lane_dist, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream)
+{
+    if (!centroid || !medoid_pos || !mask_frame || !lane || !lane_off || !frame_lane || !lane_idx || !lane_dist || !workspace)
+        return CM3D_ERR_ARG;
+    if (n_masks <= 0) return CM3D_ERR_ARG;
+    if (workspace_bytes < cm3d_lane_nn_workspace_bytes(n_masks)) return CM3D_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    double *part_s = (double *)workspace;
+    int32_t *part_j = (int32_t *)(part_s + (size_t)n_masks * LN_SLICES);
+    dim3 grid((n_masks + LN_THREADS - 1) / LN_THREADS, LN_SLICES);
+    hipLaunchKernelGGL(k_lane_nn, grid, dim3(LN_THREADS), 0, st, centroid, medoid_pos, mask_frame, n_masks, lane, lane_off,
+                       frame_lane, part_s, part_j);
+    CM3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_lane_nn_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, medoid_pos, n_masks, part_s, part_j,
+                       lane_idx, lane_dist);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
+}
+
+// ---------------------------------------------------------------------------
+// One wave per frame: box assembly for every mask with a centroid, then greedy circle NMS.
+#define BN_MAX CM3D_MAX_MASKS_PER_FRAME
+
+__global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centroid, const int32_t *__restrict__ medoid_pos,
+                                                const int32_t *__restrict__ mask_off, const int32_t *__restrict__ class_id,
+                                                const double *__restrict__ score, const float *__restrict__ lane,
+                                                const int32_t *__restrict__ lane_off, const int32_t *__restrict__ frame_lane,
+                                                const int32_t *__restrict__ lane_idx, const double *__restrict__ lane_dist,
+                                                const double *__restrict__ prior_wlh, const int32_t *__restrict__ is_vehicle,
+                                                const double *__restrict__ nms_thr, int n_classes,
+                                                const double *__restrict__ ego_xyz, double *__restrict__ box,
+                                                int32_t *__restrict__ flags)
+{
+    __shared__ double s_x[BN_MAX], s_y[BN_MAX], s_s[BN_MAX];
+    __shared__ int s_lab[BN_MAX], s_order[BN_MAX];
+    __shared__ unsigned char s_valid[BN_MAX], s_sup[BN_MAX], s_keep[BN_MAX];
+    const int f = blockIdx.x;
+    const int m0 = mask_off[f];
+    const int nm = min(mask_off[f + 1] - m0, BN_MAX);
+    const int lane_id = threadIdx.x;
+    const double ex0 = ego_xyz[3 * f], ey0 = ego_xyz[3 * f + 1];
+    const int ltab = lane_off[frame_lane[f]];
+
+    for (int k = lane_id; k < nm; k += 64) {
+        const int m = m0 + k;
+        const bool valid = medoid_pos[m] >= 0;
+        int cls = class_id[m];
+        if (cls < 0 || cls >= n_classes) cls = 0;
+        double tx = 0.0, ty = 0.0, tz = 0.0, qw = 1.0, qz = 0.0, yaw_out = 0.0, ld = 0.0;
+        if (valid) {
+            const double cx = (double)centroid[3 * m], cy = (double)centroid[3 * m + 1], cz = (double)centroid[3 * m + 2];
+            const float yaw = lane[(size_t)(ltab + lane_idx[m]) * 3 + 2];      // :295, an f32 value
+            yaw_out = (double)yaw; ld = lane_dist[m];
+            tx = cx; ty = cy; tz = cz;
+            if (is_vehicle[cls]) {
+                // :788-789 np.cos/np.sin of a float32 give float32
+                const double cs = (double)cosf(yaw), sn = (double)sinf(yaw);
+                // pyquaternion Quaternion(matrix=Rz): trace method on M^T
+                if (cs < -cs) { const double t = 1.0 - cs - cs + 1.0; const double fct = 0.5 / sqrt(t); qw = (sn + sn) * fct; qz = t * fct; }
+                else          { const double t = 1.0 + cs + cs + 1.0; const double fct = 0.5 / sqrt(t); qw = t * fct; qz = (sn + sn) * fct; }
+                // push_centroid :164-198
+                const double PI = 3.14159265358979323846;
+                double phi = 2.0 * atan2(qw, qz);
+                if (phi > PI) phi -= 2.0 * PI;
+                if (phi <= -PI) phi += 2.0 * PI;
+                double theta = -phi;
+                if (theta != theta) theta = 0.5 * PI;
+                const double ex = cx - ex0, ey = cy - ey0;
+                double alpha = atan(fabs(ey) / fabs(ex));
+                if (ex < 0) { if (ey < 0) alpha = -PI + alpha; else alpha = PI - alpha; }
+                else        { if (ey < 0) alpha = -alpha; }
+                const double l = prior_wlh[3 * cls + 0], w = prior_wlh[3 * cls + 1];
+                const double o1 = fabs(w / (2.0 * sin(theta - alpha)));
+                const double o2 = fabs(l / (2.0 * cos(theta - alpha)));
+                double off = o1 < o2 ? o1 : o2;
+                if (o1 != o1 || o2 != o2) off = NAN;
+                tx = cx + off * cos(alpha);
+                ty = cy + off * sin(alpha);
+            }
+        }
+        double *b = box + (size_t)m * CM3D_BOX_STRIDE;
+        b[0] = tx; b[1] = ty; b[2] = tz; b[3] = qw; b[4] = qz; b[5] = yaw_out; b[6] = ld; b[7] = 0.0;
+        s_x[k] = tx; s_y[k] = ty; s_s[k] = score[m]; s_lab[k] = cls;
+        s_valid[k] = valid; s_sup[k] = 0; s_keep[k] = 0;
+    }
+    __syncthreads();
+    // order: descending score, ties by descending index (pinned tie-break, SURVEY hard part 4)
+    int nv = 0;
+    for (int k = 0; k < nm; ++k) nv += s_valid[k];
+    for (int k = lane_id; k < nm; k += 64) {
+        if (!s_valid[k]) continue;
+        int rank = 0;
+        const double sk = s_s[k];
+        for (int j = 0; j < nm; ++j) {
+            if (!s_valid[j]) continue;
+            const double sj = s_s[j];
+            rank += (sj > sk || (sj == sk && j > k)) ? 1 : 0;
+        }
+        s_order[rank] = k;
+    }
+    __syncthreads();
+    for (int r = 0; r < nv; ++r) {
+        const int i = s_order[r];
+        if (!s_sup[i]) {            // uniform: every lane reads the same LDS word
+            if (lane_id == 0) s_keep[i] = 1;
+            const double xi = s_x[i], yi = s_y[i];
+            const int li = s_lab[i];
+            for (int r2 = r + 1 + lane_id; r2 < nv; r2 += 64) {
+                const int j = s_order[r2];
+                if (s_sup[j]) continue;
+                const double dx = xi - s_x[j], dy = yi - s_y[j];
+                const double dist = dx * dx + dy * dy;
+                if (dist <= nms_thr[s_lab[j]] && s_lab[j] == li) s_sup[j] = 1;
+            }
+        }
+        __syncthreads();
+    }
+    for (int k = lane_id; k < nm; k += 64) flags[m0 + k] = (s_valid[k] ? 1 : 0) | (s_keep[k] ? 2 : 0);
+}
+
+extern "C" int cm3d_box_nms(const float *centroid, const int32_t *medoid_pos, const int32_t *mask_off, int32_t n_frames,
+                            int32_t n_masks, const int32_t *class_id, const double *score, const float *lane,
+                            const int32_t *lane_off, const int32_t *frame_lane, const int32_t *lane_idx,
+                            const double *lane_dist, const double *prior_wlh, const int32_t *is_vehicle,
+                            const double *nms_thr, int32_t n_classes, const double *ego_xyz, double *box, int32_t *flags,
+                            cm3d_stream_t stream)
+{
+    if (!centroid || !medoid_pos || !mask_off || !class_id || !score || !lane || !lane_off || !frame_lane || !lane_idx ||
+        !lane_dist || !prior_wlh || !is_vehicle || !nms_thr || !ego_xyz || !box || !flags)
+        return CM3D_ERR_ARG;
+    if (n_frames <= 0 || n_masks <= 0 || n_classes <= 0) return CM3D_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_box_nms, dim3(n_frames), dim3(64), 0, st, centroid, medoid_pos, mask_off, class_id, score, lane,
+                       lane_off, frame_lane, lane_idx, lane_dist, prior_wlh, is_vehicle, nms_thr, n_classes, ego_xyz, box, flags);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int cm3d_abi_version(void) { return CM3D_ABI_VERSION; }
+
+extern "C" const char *cm3d_error_string(int code)
+{
+    switch (code) {
+    case CM3D_OK: return "ok";
+    case CM3D_ERR_ARG: return "invalid argument (null pointer, non-positive size or unsupported shape)";
+    case CM3D_ERR_LAUNCH: return "kernel launch failed";
+    case CM3D_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown error";
+    }
+}

@@ -1,0 +1,170 @@
+// a9: medoid of the in-mask points -- reference src/nuscenes/2d_to_3d.py:116-119 (get_medoid),
+// gather at :620, use at :645-647.
+// argmin_j sum_i D[i][j], D = torch.cdist(P, P) in float32:
+//   M <= 25 : direct form   agg = fma(d,d,agg) over |a_k-b_k|, sqrt
+//   M  > 25 : expansion     [-2x_i,-2y_i,-2z_i,n_i,1].[x_j,y_j,z_j,1,n_j] as a k-sequential fma
+//             chain, clamp at 0, sqrt   (n = (x*x + y*y) + z*z)
+// (the expansion's cancellation error at global-frame magnitudes is part
+// of the reference's behaviour and is reproduced, not fixed.)
+// Column j lives in one thread and is summed over rows i in ascending order, so the float32
+// column sums do not depend on the launch geometry.  A tile = 256 columns of one mask; rows are
+// staged through LDS 256 at a time and read back as wave-wide broadcasts.  VALU-bound
+// (about 20 ops per pair incl. the IEEE sqrt); nothing M x M ever touches HBM.
+#include "common.h"
+
+#define MD_THREADS CM3D_MEDOID_TILE
+
+struct TileBest { float s; int j; };
+
+__global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__restrict__ points,
+                                                              const int32_t *__restrict__ pt_off,
+                                                              const int32_t *__restrict__ mask_frame, int n_masks,
+                                                              const int32_t *__restrict__ hit_off,
+                                                              const int32_t *__restrict__ tile_off,
+                                                              const int32_t *__restrict__ hit_idx, int idx_cap,
+                                                              TileBest *__restrict__ tile_best, int tile_cap,
+                                                              float *__restrict__ colsum_opt)
+{
+    __shared__ float4 s_row[MD_THREADS];
+    __shared__ float s_ws[MD_THREADS / 64];
+    __shared__ int s_wj[MD_THREADS / 64];
+    const int ntiles = min(tile_off[n_masks], tile_cap);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // mask of this tile: largest m with tile_off[m] <= t (uniform binary search)
+        int lo = 0, hi = n_masks;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (tile_off[mid] <= t) lo = mid; else hi = mid;
+        }
+        const int m = lo;
+        const int off = hit_off[m];
+        int M = hit_off[m + 1] - off;
+        if (off + M > idx_cap) M = max(0, idx_cap - off);     // index capacity overflow: stay in bounds
+        const int jt = t - tile_off[m];
+        const float4 *P = points + pt_off[mask_frame[m]];
+        const int j = jt * MD_THREADS + threadIdx.x;
+        const bool act = j < M;
+        float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
+        if (act) {
+            const float4 q = P[hit_idx[off + j]];
+            qx = q.x; qy = q.y; qz = q.z;
+            qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
+        }
+        float s = 0.f;
+        const bool direct = M <= 25;
+        for (int i0 = 0; i0 < M; i0 += MD_THREADS) {
+            __syncthreads();
+            const int i = i0 + threadIdx.x;
+            if (i < M) {
+                float4 r = P[hit_idx[off + i]];
+                r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
+                s_row[threadIdx.x] = r;
+            }
+            __syncthreads();
+            const int cnt = min(MD_THREADS, M - i0);
+            if (direct) {
+                for (int ii = 0; ii < cnt; ++ii) {
+                    const float4 r = s_row[ii];
+                    float d = fabsf(r.x - qx);
+                    float agg = fmaf(d, d, 0.0f);
+                    d = fabsf(r.y - qy); agg = fmaf(d, d, agg);
+                    d = fabsf(r.z - qz); agg = fmaf(d, d, agg);
+                    s = s + sqrtf(agg);
+                }
+            } else {
+#pragma unroll 4
+                for (int ii = 0; ii < cnt; ++ii) {
+                    const float4 r = s_row[ii];
+                    float acc = (-2.0f * r.x) * qx;
+                    acc = fmaf(-2.0f * r.y, qy, acc);
+                    acc = fmaf(-2.0f * r.z, qz, acc);
+                    acc = fmaf(r.w, 1.0f, acc);
+                    acc = fmaf(1.0f, qn, acc);
+                    acc = acc > 0.0f ? acc : (acc != acc ? acc : 0.0f);   // clamp_min_(0)
+                    s = s + sqrtf(acc);
+                }
+            }
+        }
+        if (act && colsum_opt) colsum_opt[off + j] = s;
+        // first minimum over the tile's columns (torch.argmin: NaN counts as minimal, first wins)
+        float bs = act ? s : INFINITY;
+        int bj = act ? j : 0x7FFFFFFF;
+        auto better = [](float s1, int j1, float s2, int j2) {   // is (s1,j1) ahead of (s2,j2)?
+            const bool n1 = s1 != s1, n2 = s2 != s2;
+            if (n1 != n2) return n1;
+            if (!n1 && s1 != s2) return s1 < s2;
+            return j1 < j2;
+        };
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o, 64);
+            const int oj = __shfl_xor(bj, o, 64);
+            if (better(os, oj, bs, bj)) { bs = os; bj = oj; }
+        }
+        if (cm3d_lane() == 0) { s_ws[threadIdx.x >> 6] = bs; s_wj[threadIdx.x >> 6] = bj; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < MD_THREADS / 64; ++w)
+                if (better(s_ws[w], s_wj[w], bs, bj)) { bs = s_ws[w]; bj = s_wj[w]; }
+            tile_best[t].s = bs;
+            tile_best[t].j = bj;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict__ points, const int32_t *__restrict__ pt_off,
+                                                       const int32_t *__restrict__ mask_frame, int n_masks,
+                                                       const int32_t *__restrict__ hit_off,
+                                                       const int32_t *__restrict__ tile_off,
+                                                       const int32_t *__restrict__ hit_idx, int idx_cap,
+                                                       const TileBest *__restrict__ tile_best, int tile_cap,
+                                                       int32_t *__restrict__ medoid_pos, float *__restrict__ centroid)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_masks) return;
+    const int t0 = tile_off[m], t1 = min(tile_off[m + 1], tile_cap);
+    int bj = -1;
+    float bs = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const TileBest b = tile_best[t];
+        if (b.j == 0x7FFFFFFF) continue;
+        const bool bn = b.s != b.s, cn = bs != bs;
+        if (bj < 0 || (bn && !cn) || (!bn && !cn && b.s < bs)) { bs = b.s; bj = b.j; }
+    }
+    medoid_pos[m] = bj;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (bj >= 0 && hit_off[m] + bj < idx_cap) {
+        const float4 p = points[pt_off[mask_frame[m]] + hit_idx[hit_off[m] + bj]];
+        cx = p.x; cy = p.y; cz = p.z;
+    }
+    centroid[3 * m + 0] = cx; centroid[3 * m + 1] = cy; centroid[3 * m + 2] = cz;
+}
+
+extern "C" int64_t cm3d_medoid_workspace_bytes(int32_t n_masks, int32_t idx_cap)
+{
+    if (n_masks <= 0 || idx_cap <= 0) return 0;
+    int64_t tiles = (int64_t)n_masks + (int64_t)idx_cap / CM3D_MEDOID_TILE + 1;
+    return tiles * (int64_t)sizeof(TileBest);
+}
+
+extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_frame, int32_t n_masks,
+                           const int32_t *hit_off, const int32_t *tile_off, const int32_t *hit_idx, int32_t idx_cap,
+                           int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
+                           int64_t workspace_bytes, cm3d_stream_t stream)
+{
+    if (!points || !pt_off || !mask_frame || !hit_off || !tile_off || !hit_idx || !medoid_pos || !centroid || !workspace)
+        return CM3D_ERR_ARG;
+    if (n_masks <= 0 || idx_cap <= 0) return CM3D_ERR_ARG;
+    if (workspace_bytes < cm3d_medoid_workspace_bytes(n_masks, idx_cap)) return CM3D_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t tile_cap64 = (int64_t)n_masks + (int64_t)idx_cap / CM3D_MEDOID_TILE + 1;
+    const int tile_cap = (int)(tile_cap64 > 0x7FFFFFFF ? 0x7FFFFFFF : tile_cap64);
+    int grid = tile_cap < 8192 ? tile_cap : 8192;
+    hipLaunchKernelGGL(k_medoid_tiles, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
+                       hit_off, tile_off, hit_idx, idx_cap, (TileBest *)workspace, tile_cap, colsum_opt);
+    CM3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_medoid_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, (const float4 *)points, pt_off, mask_frame,
+                       n_masks, hit_off, tile_off, hit_idx, idx_cap, (const TileBest *)workspace, tile_cap, medoid_pos, centroid);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
+}

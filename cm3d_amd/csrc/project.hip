@@ -1,0 +1,235 @@
+// a4-a8: projection, in-image test, in-mask test, ordered compaction.
+//   reference: src/nuscenes/2d_to_3d.py:553-620 (per mask: clone the cloud, 2x translate/rotate,
+//   view_points utils/pcd.py:262-284, 5-way in-image test, floor, mask gather with the
+//   floor(u)!=0 && floor(v)!=0 quirk, torch.where, two .cpu() index-tracking steps).
+// Here every point is read ONCE (float4, coalesced), projected into every camera of its frame,
+// and tested against the bit-packed eroded masks of that camera (bounding-box test first, so
+// only points that can hit a mask touch mask memory).  Results leave as one hit word per point
+// per 32 masks; k_compact_hits turns them into ascending index lists (wave ballot + mbcnt
+// prefix, two passes, no atomics on the output order).
+// HBM-bound: algorithmic bytes = 16 N + n*ceil(W*H/8) + 4*sum(M) + 4(n+1) per frame.
+#include "common.h"
+
+#define PH_THREADS 256
+#define PH_CHUNK 128          // mask descriptors staged per pass (4 hit planes)
+
+__global__ __launch_bounds__(PH_THREADS) void k_project_hits(
+    const float4 *__restrict__ points, const int32_t *__restrict__ pt_off, int n_points_total,
+    const float *__restrict__ cams, int n_cams, const int32_t *__restrict__ mask_off,
+    const int32_t *__restrict__ mask_cam, const int4 *__restrict__ bbox, const uint32_t *__restrict__ packed,
+    int W, int H, int Wp, float min_dist, uint32_t *__restrict__ hit_words, int32_t *__restrict__ hit_count,
+    int32_t *__restrict__ status)
+{
+    const int f = blockIdx.y;
+    const int p0 = pt_off[f], n = pt_off[f + 1] - p0;
+    const int base = blockIdx.x * PH_THREADS;
+    if (base >= n) return;
+    const int m0 = mask_off[f];
+    int nm = mask_off[f + 1] - m0;
+    if (nm > CM3D_MAX_MASKS_PER_FRAME) {
+        if (threadIdx.x == 0) atomicOr(&status[0], 4);
+        nm = CM3D_MAX_MASKS_PER_FRAME;
+    }
+
+    __shared__ float s_cam[CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
+    __shared__ int s_pix[CM3D_MAX_CAMS][PH_THREADS];
+    __shared__ int s_mcam[PH_CHUNK];
+    __shared__ int4 s_bbox[PH_CHUNK];
+
+    for (int i = threadIdx.x; i < n_cams * CM3D_CAM_STRIDE; i += PH_THREADS)
+        s_cam[i] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + i];
+    __syncthreads();
+
+    const int i = base + threadIdx.x;
+    const bool in_range = i < n;
+    float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in_range) pt = points[p0 + i];
+
+    const float wlim = (float)(W - 1), hlim = (float)(H - 1);
+    uint32_t cam_any = 0;     // wave-uniform: cameras that see at least one point of this wave
+    for (int c = 0; c < n_cams; ++c) {
+        const float *cm = s_cam + c * CM3D_CAM_STRIDE;
+        // global -> ego(cam time) -> camera: p += t1; p = R1 p; p += t2; p = R2 p   (2d_to_3d.py:569-577)
+        float x = pt.x + cm[0], y = pt.y + cm[1], z = pt.z + cm[2];
+        float ax, ay, az;
+        cm3d_rot3(cm + 3, x, y, z, ax, ay, az);
+        if (cm[33] > 1.5f) {
+            x = ax + cm[12]; y = ay + cm[13]; z = az + cm[14];
+            cm3d_rot3(cm + 15, x, y, z, ax, ay, az);
+        }
+        const float depth = az;                                   // :581
+        // view_points: viewpad(4x4) @ [p;1], rows 0..2, k-sequential fma chain (pcd.py:269-282)
+        const float *K = cm + 24;
+        float uh = K[0] * ax; uh = fmaf(K[1], ay, uh); uh = fmaf(K[2], az, uh); uh = fmaf(0.0f, 1.0f, uh);
+        float vh = K[3] * ax; vh = fmaf(K[4], ay, vh); vh = fmaf(K[5], az, vh); vh = fmaf(0.0f, 1.0f, vh);
+        float zh = K[6] * ax; zh = fmaf(K[7], ay, zh); zh = fmaf(K[8], az, zh); zh = fmaf(0.0f, 1.0f, zh);
+        const float u = uh / zh, v = vh / zh, w = zh / zh;
+        // :597-603 in-image test, :605 floor, :608-613 truthiness quirk (floor(.) != 0 on all three rows)
+        bool ok = in_range && depth > min_dist && u > 0.0f && u < wlim && v > 0.0f && v < hlim;
+        int iu = 0, iv = 0;
+        if (ok) {
+            iu = (int)floorf(u); iv = (int)floorf(v);
+            ok = iu != 0 && iv != 0 && (int)floorf(w) != 0;
+        }
+        s_pix[c][threadIdx.x] = ok ? ((iv << 16) | iu) : -1;
+        if (__ballot(ok)) cam_any |= 1u << c;
+    }
+
+    const size_t mask_words = (size_t)H * Wp;
+    for (int cbase = 0; cbase < nm; cbase += PH_CHUNK) {
+        const int cn = min(PH_CHUNK, nm - cbase);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cn; k += PH_THREADS) {
+            int c = mask_cam[m0 + cbase + k];
+            if (c < 0 || c >= n_cams) { atomicOr(&status[0], 4); c = 0; s_bbox[k] = make_int4(1, 1, 0, 0); }
+            else s_bbox[k] = bbox[m0 + cbase + k];
+            s_mcam[k] = c;
+        }
+        __syncthreads();
+        uint32_t bits = 0;
+        for (int k = 0; k < cn; ++k) {
+            const int c = s_mcam[k];
+            bool hit = false;
+            if ((cam_any >> c) & 1u) {
+                const int pix = s_pix[c][threadIdx.x];
+                if (pix >= 0) {
+                    const int iu = pix & 0xFFFF, iv = pix >> 16;
+                    const int4 bb = s_bbox[k];
+                    if (iu >= bb.x && iu <= bb.z && iv >= bb.y && iv <= bb.w) {
+                        const uint32_t word = packed[(size_t)(m0 + cbase + k) * mask_words + (size_t)iv * Wp + (iu >> 5)];
+                        hit = (word >> (iu & 31)) & 1u;
+                    }
+                }
+                const uint64_t bal = __ballot(hit);
+                if (bal && cm3d_lane() == 0) atomicAdd(&hit_count[m0 + cbase + k], __popcll(bal));
+            }
+            bits |= (hit ? 1u : 0u) << (k & 31);
+            if ((k & 31) == 31 || k == cn - 1) {
+                if (in_range) hit_words[(size_t)((cbase + k) >> 5) * n_points_total + p0 + i] = bits;
+                bits = 0;
+            }
+        }
+    }
+}
+
+// exclusive scans of hit_count and of the medoid tile counts; status bookkeeping.
+__global__ __launch_bounds__(1024) void k_scan_hits(const int32_t *__restrict__ hit_count, int n_masks,
+                                                    int32_t *__restrict__ hit_off, int32_t *__restrict__ tile_off,
+                                                    int idx_cap, int32_t *__restrict__ status)
+{
+    __shared__ int s_part[16];
+    int carry = 0, tcarry = 0;
+    for (int base = 0; base < n_masks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_masks ? hit_count[i] : 0;
+        const int t = (v + CM3D_MEDOID_TILE - 1) / CM3D_MEDOID_TILE;
+        int tot, ttot;
+        const int ex = cm3d_block1024_excl_scan(v, s_part, tot);
+        const int tex = cm3d_block1024_excl_scan(t, s_part, ttot);
+        if (i < n_masks) { hit_off[i] = carry + ex; tile_off[i] = tcarry + tex; }
+        carry += tot; tcarry += ttot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        hit_off[n_masks] = carry;
+        tile_off[n_masks] = tcarry;
+        status[2] = carry;
+        status[3] = tcarry;
+        if (carry > idx_cap) atomicOr(&status[0], 2);
+    }
+}
+
+// grid (planes, F), 16 waves: wave w owns a contiguous run of 64-point groups.
+// pass 1 counts per (wave, mask), LDS prefix over waves, pass 2 writes in order.
+__global__ __launch_bounds__(1024) void k_compact_hits(const uint32_t *__restrict__ hit_words, int n_points_total,
+                                                       const int32_t *__restrict__ pt_off,
+                                                       const int32_t *__restrict__ mask_off,
+                                                       const int32_t *__restrict__ hit_off,
+                                                       int32_t *__restrict__ hit_idx, int idx_cap)
+{
+    const int plane = blockIdx.x, f = blockIdx.y;
+    const int m0 = mask_off[f];
+    const int nm = min(mask_off[f + 1] - m0, CM3D_MAX_MASKS_PER_FRAME);
+    if (plane * 32 >= nm) return;
+    const int p0 = pt_off[f], n = pt_off[f + 1] - p0;
+    const uint32_t *hw = hit_words + (size_t)plane * n_points_total + p0;
+    const int wave = threadIdx.x >> 6, lane = cm3d_lane();
+    const int G = (n + 63) >> 6, gpw = (G + 15) >> 4;
+    const int g0 = wave * gpw, g1 = min(g0 + gpw, G);
+
+    __shared__ int s_cnt[16][32];
+    int mycnt = 0;                         // lane b < 32 counts the hits of mask bit b
+    for (int g = g0; g < g1; ++g) {
+        const int idx = g * 64 + lane;
+        const uint32_t w = idx < n ? hw[idx] : 0u;
+        uint32_t orw = cm3d_wave_or(w);
+        while (orw) {
+            const int b = __builtin_ctz(orw);
+            orw &= orw - 1;
+            const uint64_t mk = __ballot((w >> b) & 1u);
+            if (lane == b) mycnt += __popcll(mk);
+        }
+    }
+    if (lane < 32) s_cnt[wave][lane] = mycnt;
+    __syncthreads();
+    int run = 0;
+    if (lane < 32) {
+        for (int k = 0; k < wave; ++k) run += s_cnt[k][lane];
+        if (plane * 32 + lane < nm) run += hit_off[m0 + plane * 32 + lane];
+    }
+    for (int g = g0; g < g1; ++g) {
+        const int idx = g * 64 + lane;
+        const uint32_t w = idx < n ? hw[idx] : 0u;
+        uint32_t orw = cm3d_wave_or(w);
+        while (orw) {
+            const int b = __builtin_ctz(orw);
+            orw &= orw - 1;
+            const bool mine = (w >> b) & 1u;
+            const uint64_t mk = __ballot(mine);
+            const int basepos = __builtin_amdgcn_readlane(run, b);
+            if (mine) {
+                const int pos = basepos + cm3d_mbcnt(mk);
+                if (pos < idx_cap) hit_idx[pos] = idx;
+            }
+            if (lane == b) run += __popcll(mk);
+        }
+    }
+}
+
+extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
+                                 int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off,
+                                 const int32_t *mask_cam, const int32_t *bbox, const uint32_t *packed, int32_t n_masks,
+                                 int32_t W, int32_t H, float min_dist, int32_t planes, uint32_t *hit_words,
+                                 int32_t *hit_count, int32_t *status, cm3d_stream_t stream)
+{
+    if (!points || !pt_off || !cams || !mask_off || !mask_cam || !bbox || !packed || !hit_words || !hit_count || !status)
+        return CM3D_ERR_ARG;
+    if (n_frames <= 0 || max_pts_per_frame <= 0 || n_points_total <= 0 || n_cams <= 0 || n_cams > CM3D_MAX_CAMS ||
+        n_masks <= 0 || W <= 1 || H <= 1 || W > 32767 || H > 32767 || planes <= 0)
+        return CM3D_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(hit_count, 0, (size_t)n_masks * sizeof(int32_t), st) != hipSuccess) return CM3D_ERR_LAUNCH;
+    const int Wp = (W + 31) / 32;
+    dim3 grid((max_pts_per_frame + PH_THREADS - 1) / PH_THREADS, n_frames);
+    hipLaunchKernelGGL(k_project_hits, grid, dim3(PH_THREADS), 0, st, (const float4 *)points, pt_off, n_points_total, cams,
+                       n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, hit_words, hit_count,
+                       status);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
+}
+
+extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, const int32_t *pt_off, int32_t n_frames,
+                                 int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
+                                 const int32_t *hit_count, int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx,
+                                 int32_t idx_cap, int32_t *status, cm3d_stream_t stream)
+{
+    if (!hit_words || !pt_off || !mask_off || !hit_count || !hit_off || !tile_off || !hit_idx || !status) return CM3D_ERR_ARG;
+    if (planes <= 0 || n_frames <= 0 || n_points_total <= 0 || n_masks <= 0 || idx_cap <= 0) return CM3D_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_scan_hits, dim3(1), dim3(1024), 0, st, hit_count, n_masks, hit_off, tile_off, idx_cap, status);
+    CM3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_compact_hits, dim3(planes, n_frames), dim3(1024), 0, st, hit_words, n_points_total, pt_off, mask_off,
+                       hit_off, hit_idx, idx_cap);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
+}

@@ -1,0 +1,175 @@
+/*
+ * cm3d_hip.h -- C-ABI of libcm3d_hip.so: the MI355X (gfx950) kernels of CM3D's
+ * 2D->3D pseudo-label lifting path.
+ *
+ * The reference has no FFI: its hot path is inline torch/numpy/OpenCV code in
+ * src/{nuscenes,waymo,kitti}/2d_to_3d.py.  Each entry point below replaces the
+ * block of reference code it cites (paths relative to the reference checkout,
+ * src/nuscenes/ unless noted); INTEGRATION.md shows the ctypes stub a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _host;
+ *  - the caller owns every buffer; nothing is allocated or freed inside;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *    never synchronises, and is safe to capture into a hipGraph;
+ *  - return value: CM3D_OK or a negative CM3D_ERR_*; nothing throws;
+ *  - thread-safe for distinct streams and distinct workspaces; no global state;
+ *  - index arithmetic is int32: a batch holds < 2^31 points / mask words.
+ *
+ * Batch data model ("lift batch"): F frames; frame f owns sweeps
+ * [frame_sweep_off[f], frame_sweep_off[f+1]), points [pt_off[f], pt_off[f+1])
+ * and masks [mask_off[f], mask_off[f+1]).
+ */
+#ifndef CM3D_HIP_H
+#define CM3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CM3D_ABI_VERSION 1
+
+#define CM3D_OK 0
+#define CM3D_ERR_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
+#define CM3D_ERR_LAUNCH (-2)   /* hipGetLastError() != hipSuccess after a launch      */
+#define CM3D_ERR_WORKSPACE (-3)/* workspace smaller than cm3d_*_workspace_bytes says  */
+
+#define CM3D_CAM_STRIDE 40       /* floats per camera record, see cm3d_project_hits   */
+#define CM3D_SWEEP_XF_STRIDE 24  /* floats per sweep transform, see cm3d_sweep_prep   */
+#define CM3D_MAX_CAMS 8          /* cameras per frame                                  */
+#define CM3D_MAX_MASKS_PER_FRAME 1024
+#define CM3D_BOX_STRIDE 8        /* doubles per box record, see cm3d_box_nms           */
+#define CM3D_MEDOID_TILE 256     /* columns per medoid tile                            */
+
+/* status word written by kernels (int32[4] in device memory, zero it per batch):
+ *  [0] bit0: point capacity overflow (cm3d_sweep_prep), bit1: hit-index capacity
+ *      overflow (cm3d_compact_hits), bit2: too many masks in a frame / cams out of range
+ *  [1] total points produced by cm3d_sweep_prep
+ *  [2] total hit indices required by cm3d_compact_hits
+ *  [3] total medoid tiles */
+#define CM3D_STATUS_WORDS 4
+
+typedef void *cm3d_stream_t;
+
+int cm3d_abi_version(void);
+const char *cm3d_error_string(int code);
+
+/* ---- a2: sweep preparation -------------------------------------------------
+ * Replaces 2d_to_3d.py:437-465 + utils/pcd.py:159-172,246-257: strip a raw sweep to
+ * 4 columns, drop |x|<halfw && |y|<halfw (halfw = f32(sqrt(2.3))), sensor->ego->global
+ * (rotate then translate, twice), concatenate sweeps in order.
+ *  raw          float[rows][raw_stride]   all sweeps of the batch, back to back
+ *  sweep_row_off int32[S+1]               row offsets of the sweeps into raw
+ *  sweep_xf     float[S][24]              [0..8] R_cs, [9..11] t_cs, [12..20] R_ego, [21..23] t_ego (float32,
+ *                                         exactly the tensors the reference passes to rotate/translate)
+ *  frame_sweep_off int32[F+1]
+ *  points       float[pt_cap][4]  OUT     x,y,z,intensity in the global frame, input order preserved
+ *  pt_off       int32[F+1]        OUT
+ *  workspace: cm3d_sweep_prep_workspace_bytes(S, max_rows_per_sweep) */
+int64_t cm3d_sweep_prep_workspace_bytes(int32_t n_sweeps, int32_t max_rows_per_sweep);
+int cm3d_sweep_prep(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
+                    int32_t max_rows_per_sweep, const float *sweep_xf, const int32_t *frame_sweep_off,
+                    int32_t n_frames, float halfw, float *points, int32_t pt_cap, int32_t *pt_off,
+                    int32_t *status, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream);
+
+/* ---- a1: COCO-RLE expansion ------------------------------------------------
+ * Replaces pycocotools.mask.decode at 2d_to_3d.py:425 (+ the transpose at :428): run
+ * lengths -> dense uint8 [n][H][W] image-layout masks of 0/1.
+ *  rle_counts uint32[]  run lengths of all masks back to back (alternating 0-run,1-run,...)
+ *  rle_off    int32[n+1]
+ *  workspace: cm3d_rle_workspace_bytes(total_runs) */
+int64_t cm3d_rle_workspace_bytes(int32_t total_runs);
+int cm3d_rle_to_dense(const uint32_t *rle_counts, const int32_t *rle_off, int32_t n_masks, int32_t total_runs,
+                      int32_t W, int32_t H, uint8_t *dense, void *workspace, int64_t workspace_bytes,
+                      cm3d_stream_t stream);
+
+/* ---- a3: 3x3 erosion + bit-packing ------------------------------------------
+ * Replaces cv2.erode(mask, ones((3,3))) + astype(bool) + transpose + H2D at
+ * 2d_to_3d.py:526-527,542-544.  Out-of-image neighbours are ignored.
+ *  dense   uint8[n][H][W]   non-zero = set
+ *  packed  uint32[n][H][Wp] OUT, Wp = (W+31)/32, bit (x&31) of word [y][x>>5] = eroded pixel (x,y)
+ *  bbox    int32[n][4]      OUT x0,y0,x1,y1 inclusive bounds of the eroded mask (x0>x1 when empty) */
+int cm3d_erode_pack(const uint8_t *dense, int32_t n_masks, int32_t W, int32_t H, uint32_t *packed,
+                    int32_t *bbox, cm3d_stream_t stream);
+
+/* f1: same result straight from run lengths, no dense intermediate
+ * (fuses 2d_to_3d.py:425 with :526-527,542-544). */
+int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int32_t n_masks, int32_t total_runs,
+                        int32_t W, int32_t H, uint32_t *packed, int32_t *bbox, void *workspace,
+                        int64_t workspace_bytes, cm3d_stream_t stream);
+
+/* ---- a4-a7: projection + in-image + in-mask test ----------------------------
+ * Replaces the per-mask block 2d_to_3d.py:553-613 (clone, 2x translate/rotate,
+ * view_points, in-image test, floor, mask gather incl. the floor(u)!=0 && floor(v)!=0
+ * quirk) for ALL masks of ALL frames in one pass over the points.
+ *  cams  float[F][n_cams][CM3D_CAM_STRIDE]:
+ *        [0..2] t1 (added), [3..11] R1 row-major, [12..14] t2 (added), [15..23] R2, [24..32] K' (3x3),
+ *        [33] number of rigid stages (2 nuScenes, 1 Waymo); all float32 exactly as the reference
+ *        hands them to translate/rotate/view_points.
+ *  hit_words uint32[planes][n_points_total] OUT, planes = (max masks per frame + 31)/32;
+ *        bit (k&31) of hit_words[k>>5][p] = point p lies in mask mask_off[f]+k
+ *  hit_count int32[n_masks] OUT (zeroed inside) */
+int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
+                      int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off,
+                      const int32_t *mask_cam, const int32_t *bbox, const uint32_t *packed, int32_t n_masks,
+                      int32_t W, int32_t H, float min_dist, int32_t planes, uint32_t *hit_words,
+                      int32_t *hit_count, int32_t *status, cm3d_stream_t stream);
+
+/* ---- a7-a8: ordered compaction of the hits ----------------------------------
+ * Replaces torch.where + the two .cpu() index-tracking steps at 2d_to_3d.py:606,613-617.
+ *  hit_off  int32[n_masks+1] OUT exclusive scan of hit_count
+ *  tile_off int32[n_masks+1] OUT exclusive scan of ceil(hit_count/CM3D_MEDOID_TILE)
+ *  hit_idx  int32[idx_cap]   OUT ascending frame-local point indices of mask m at [hit_off[m], hit_off[m+1]) */
+int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, const int32_t *pt_off, int32_t n_frames,
+                      int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
+                      const int32_t *hit_count, int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx,
+                      int32_t idx_cap, int32_t *status, cm3d_stream_t stream);
+
+/* ---- a9: medoid --------------------------------------------------------------
+ * Replaces get_medoid (2d_to_3d.py:116-119) + the gather at :620,645-647:
+ * argmin_j sum_i cdist(P,P)[i][j] with torch.cdist's float32 arithmetic (direct form
+ * for <=25 points, matmul expansion otherwise), rows summed in ascending i, first minimum.
+ *  medoid_pos int32[n_masks]    OUT position in the mask's index list (-1 if the list is empty)
+ *  centroid   float[n_masks][3] OUT global-frame xyz of the medoid point
+ *  workspace: cm3d_medoid_workspace_bytes(n_masks, idx_cap) */
+int64_t cm3d_medoid_workspace_bytes(int32_t n_masks, int32_t idx_cap);
+int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_frame, int32_t n_masks,
+                const int32_t *hit_off, const int32_t *tile_off, const int32_t *hit_idx, int32_t idx_cap,
+                int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
+                int64_t workspace_bytes, cm3d_stream_t stream);
+
+/* ---- a10: nearest lane point --------------------------------------------------
+ * Replaces lane_yaws_distances_and_coords (2d_to_3d.py:277-302): float64 Euclidean
+ * distance on (x,y) between float32-rounded centroids and lane points, first minimum.
+ *  lane      float[L_total][3]  x,y,yaw (float32-rounded, as torch.Tensor(...) does at :278)
+ *  lane_off  int32[T+1]         lane tables back to back
+ *  frame_lane int32[F]          table of each frame
+ *  lane_idx  int32[n_masks] OUT index into the frame's table (-1 for masks without centroid)
+ *  lane_dist double[n_masks] OUT */
+int64_t cm3d_lane_nn_workspace_bytes(int32_t n_masks);
+int cm3d_lane_nn(const float *centroid, const int32_t *medoid_pos, const int32_t *mask_frame, int32_t n_masks,
+                 const float *lane, const int32_t *lane_off, const int32_t *frame_lane, int32_t *lane_idx,
+                 double *lane_dist, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream);
+
+/* ---- a11-a15: box assembly + class-aware circle NMS ----------------------------
+ * Replaces stage 2 (2d_to_3d.py:745-817: shape prior, lane-yaw rotation, push_centroid
+ * :164-198) and circle_nms (:309-332 with the thresholds of :850-861).
+ *  class_id int32[n_masks] index into the class tables; score double[n_masks]
+ *  prior_wlh double[n_classes][3]; is_vehicle int32[n_classes]; nms_thr double[n_classes]
+ *  ego_xyz double[F][3]   LIDAR_TOP ego_pose translation of each frame (:793-795)
+ *  box   double[n_masks][CM3D_BOX_STRIDE] OUT: tx,ty,tz, qw,qz (rotation = [qw,0,0,qz]), lane yaw, lane dist, 0
+ *  flags int32[n_masks] OUT: bit0 box exists (mask had points), bit1 box survives NMS */
+int cm3d_box_nms(const float *centroid, const int32_t *medoid_pos, const int32_t *mask_off, int32_t n_frames,
+                 int32_t n_masks, const int32_t *class_id, const double *score, const float *lane,
+                 const int32_t *lane_off, const int32_t *frame_lane, const int32_t *lane_idx,
+                 const double *lane_dist, const double *prior_wlh, const int32_t *is_vehicle,
+                 const double *nms_thr, int32_t n_classes, const double *ego_xyz, double *box, int32_t *flags,
+                 cm3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CM3D_HIP_H */

@@ -1,0 +1,382 @@
+/*
+ * cm3d_oracle.c -- CPU restatement of CM3D's 2D->3D pseudo-label lifting path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle and the CPU
+ * baseline.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it.  The product path (cm3d_amd/) never calls into it.
+ *
+ * It restates, in plain C, what the reference executes (file:line cites are
+ * relative to the reference checkout, src/nuscenes/ unless noted), in the
+ * order the reference executes it (per mask: clone the whole cloud, re-project
+ * it, full-frame 3x3 erode, O(M^2) medoid ...).  float32 arithmetic follows
+ * the op order that torch-CPU produces for the reference's tensor ops
+ * (SURVEY.md appendix B): small matmuls are k-sequential fmaf chains, cdist
+ * has a direct (<=25 rows) and an expansion (>25 rows) branch.
+ *
+ * Parity pinning: the reference ships no tests/golden vectors.  This oracle
+ * is pinned against (a) the reference's own importable helpers (get_medoid,
+ * view_points, LidarPointCloud.translate/rotate, push_centroid, circle_nms,
+ * lane_yaws_distances_and_coords) executed in the build container and frozen
+ * under tests/golden/ by tests/golden/gen_golden.py, and (b) torch-CPU ops.
+ * Third-party semantics that are absent from the reference checkout
+ * (cv2.erode 4.8.1, pycocotools 2.0.7 RLE, pyquaternion 0.9.9) are restated
+ * from their published behaviour: those pieces are "parity unpinned".
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
+ * -ffp-contract=off matters: every fused multiply-add below is explicit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* camera record layout shared with include/cm3d_hip.h (CM3D_CAM_STRIDE floats)
+ *  [0..2]   t1   vector ADDED to the global-frame point (= f32(-ego_pose.translation), 2d_to_3d.py:570)
+ *  [3..11]  R1   row-major 3x3 (= f32(R_ego^T), :571)
+ *  [12..14] t2   (= f32(-calibrated_sensor.translation), :576)
+ *  [15..23] R2   (= f32(R_cs^T), :577)
+ *  [24..32] K    row-major 3x3 scaled intrinsics, K[2][2]=1 (:585-587)
+ *  [33]     number of rigid stages: 2 (nuScenes) or 1 (Waymo: src/waymo/2d_to_3d.py:575-576)
+ */
+#define CAM_STRIDE 40
+
+/* ------------------------------------------------------------------ */
+/* a2: sweep preparation  (2d_to_3d.py:437-465, utils/pcd.py:159-172,246-257) */
+/* raw: (n_raw, stride) float32 rows of a .bin sweep, first 4 columns used.
+ * Drops |x|<halfw && |y|<halfw (halfw = f32(sqrt(2.3)), :442-445), then
+ * p = R_cs p; p += t_cs; p = R_ego p; p += t_ego, each matmul row a
+ * k-sequential fma chain.  Output rows (x,y,z,intensity), order preserved. */
+ORC_API int64_t orc_sweep_prep(const float *raw, int64_t n_raw, int stride,
+                               const float *R_cs, const float *t_cs,
+                               const float *R_ego, const float *t_ego,
+                               float halfw, float *out)
+{
+    int64_t n = 0;
+    for (int64_t i = 0; i < n_raw; ++i) {
+        const float *p = raw + i * stride;
+        float x = p[0], y = p[1], z = p[2];
+        if (fabsf(x) < halfw && fabsf(y) < halfw) continue;
+        float a[3];
+        for (int r = 0; r < 3; ++r) {
+            float acc = R_cs[3 * r] * x;
+            acc = fmaf(R_cs[3 * r + 1], y, acc);
+            acc = fmaf(R_cs[3 * r + 2], z, acc);
+            a[r] = acc;
+        }
+        for (int r = 0; r < 3; ++r) a[r] = a[r] + t_cs[r];
+        float b[3];
+        for (int r = 0; r < 3; ++r) {
+            float acc = R_ego[3 * r] * a[0];
+            acc = fmaf(R_ego[3 * r + 1], a[1], acc);
+            acc = fmaf(R_ego[3 * r + 2], a[2], acc);
+            b[r] = acc;
+        }
+        for (int r = 0; r < 3; ++r) b[r] = b[r] + t_ego[r];
+        float *o = out + 4 * n;
+        o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = p[3];
+        ++n;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* a1: COCO RLE (pycocotools 2.0.7 maskApi.c rleFrString / rleDecode; the
+ * reference calls pycocotools.mask.decode at 2d_to_3d.py:425). parity unpinned:
+ * restated from the published format. */
+ORC_API int64_t orc_rle_string_to_counts(const char *s, int64_t len, uint32_t *cnts, int64_t cap)
+{
+    int64_t m = 0, p = 0;
+    while (p < len) {
+        long x = 0; int k = 0, more = 1;
+        while (more) {
+            if (p >= len) return -1;
+            char c = s[p] - 48;
+            x |= (long)(c & 0x1f) << (5 * k);
+            more = c & 0x20; p++; k++;
+            if (!more && (c & 0x10)) x |= (long)(~0UL << (5 * k));
+        }
+        if (m > 2) x += (long)cnts[m - 2];
+        if (m >= cap) return -2;
+        cnts[m++] = (uint32_t)x;
+    }
+    return m;
+}
+
+ORC_API int64_t orc_rle_counts_to_string(const uint32_t *cnts, int64_t m, char *s, int64_t cap)
+{
+    int64_t p = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        long x = (long)cnts[i];
+        if (i > 2) x -= (long)cnts[i - 2];
+        int more = 1;
+        while (more) {
+            char c = x & 0x1f; x >>= 5;
+            more = (c & 0x10) ? x != -1 : x != 0;
+            if (more) c |= 0x20;
+            c += 48;
+            if (p >= cap) return -2;
+            s[p++] = c;
+        }
+    }
+    return p;
+}
+
+/* runs alternate 0,1,0,... over the column-major (h=W_img, w=H_img) array,
+ * i.e. over the row-major (H_img, W_img) image.  out: total bytes of 0/1. */
+ORC_API int orc_rle_to_dense(const uint32_t *cnts, int64_t m, int64_t total, uint8_t *out)
+{
+    int64_t p = 0; uint8_t v = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        int64_t c = cnts[i];
+        if (p + c > total) return -1;
+        memset(out + p, v, (size_t)c);
+        p += c; v = !v;
+    }
+    if (p != total) return -1;
+    return 0;
+}
+
+ORC_API int64_t orc_dense_to_rle(const uint8_t *img, int64_t total, uint32_t *cnts, int64_t cap)
+{
+    int64_t m = 0; uint8_t v = 0; uint32_t c = 0;
+    for (int64_t i = 0; i < total; ++i) {
+        uint8_t b = img[i] != 0;
+        if (b != v) { if (m >= cap) return -2; cnts[m++] = c; c = 0; v = b; }
+        c++;
+    }
+    if (m >= cap) return -2;
+    cnts[m++] = c;
+    return m;
+}
+
+/* ------------------------------------------------------------------ */
+/* a3: cv2.erode(mask, ones(3,3)) (2d_to_3d.py:526-527): anchor centre,
+ * BORDER_CONSTANT with the morphology default border value, so out-of-image
+ * neighbours never lower the minimum.  parity unpinned (opencv not in the
+ * reference checkout).  in/out: (H, W) uint8 image layout. */
+ORC_API void orc_erode3x3(const uint8_t *in, int H, int W, uint8_t *out)
+{
+    for (int y = 0; y < H; ++y) {
+        int y0 = y > 0 ? y - 1 : 0, y1 = y < H - 1 ? y + 1 : H - 1;
+        for (int x = 0; x < W; ++x) {
+            int x0 = x > 0 ? x - 1 : 0, x1 = x < W - 1 ? x + 1 : W - 1;
+            uint8_t m = 255;
+            for (int yy = y0; yy <= y1; ++yy)
+                for (int xx = x0; xx <= x1; ++xx) {
+                    uint8_t v = in[(int64_t)yy * W + xx];
+                    if (v < m) m = v;
+                }
+            out[(int64_t)y * W + x] = m;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* a4-a8: per-mask projection + in-mask test, executed the way the reference
+ * does: the whole cloud, once per mask (2d_to_3d.py:553-620).
+ * pts: (N,4) rows x,y,z,i (global frame).  eroded: (H,W) uint8 image, the
+ * reference indexes its (W,H) transpose as [floor(u), floor(v)] (:544,610).
+ * out_idx: ascending point indices (track_points, :606,617).  Returns M. */
+ORC_API int64_t orc_points_in_mask(const float *pts, int64_t N, const float *cam,
+                                   const uint8_t *eroded, int W, int H,
+                                   float min_dist, int32_t *out_idx, float *scratch)
+{
+    /* scratch: 3*N floats, plays the role of torch.clone (:553) */
+    float *X = scratch, *Y = scratch + N, *Z = scratch + 2 * N;
+    for (int64_t i = 0; i < N; ++i) { X[i] = pts[4 * i]; Y[i] = pts[4 * i + 1]; Z[i] = pts[4 * i + 2]; }
+    int stages = (int)cam[33];
+    for (int s = 0; s < stages; ++s) {
+        const float *t = cam + 12 * s, *R = cam + 12 * s + 3;
+        /* translate (pcd.py:159-165): row-wise add */
+        for (int64_t i = 0; i < N; ++i) X[i] = X[i] + t[0];
+        for (int64_t i = 0; i < N; ++i) Y[i] = Y[i] + t[1];
+        for (int64_t i = 0; i < N; ++i) Z[i] = Z[i] + t[2];
+        /* rotate (pcd.py:167-172): torch.matmul(3x3, 3xN) */
+        for (int64_t i = 0; i < N; ++i) {
+            float x = X[i], y = Y[i], z = Z[i], o[3];
+            for (int r = 0; r < 3; ++r) {
+                float acc = R[3 * r] * x;
+                acc = fmaf(R[3 * r + 1], y, acc);
+                acc = fmaf(R[3 * r + 2], z, acc);
+                o[r] = acc;
+            }
+            X[i] = o[0]; Y[i] = o[1]; Z[i] = o[2];
+        }
+    }
+    const float *K = cam + 24;
+    int64_t M = 0;
+    const float wlim = (float)(W - 1), hlim = (float)(H - 1);
+    for (int64_t i = 0; i < N; ++i) {
+        float x = X[i], y = Y[i], z = Z[i];
+        /* view_points (pcd.py:262-284): viewpad(4x4) @ [p;1], rows 0..2 */
+        float h[3];
+        for (int r = 0; r < 3; ++r) {
+            float acc = K[3 * r] * x;
+            acc = fmaf(K[3 * r + 1], y, acc);
+            acc = fmaf(K[3 * r + 2], z, acc);
+            acc = fmaf(0.0f, 1.0f, acc);
+            h[r] = acc;
+        }
+        float u = h[0] / h[2], v = h[1] / h[2];
+        /* :597-603 */
+        if (!(z > min_dist && u > 0.0f && u < wlim && v > 0.0f && v < hlim)) continue;
+        /* :605-613 incl. the truthiness quirk (floor(u)!=0 && floor(v)!=0) */
+        int64_t iu = (int64_t)floorf(u), iv = (int64_t)floorf(v);
+        float w = h[2] / h[2];
+        int64_t iw = (int64_t)floorf(w);
+        if (iu != 0 && iv != 0 && iw != 0 && eroded[iv * W + iu]) out_idx[M++] = (int32_t)i;
+    }
+    return M;
+}
+
+/* ------------------------------------------------------------------ */
+/* a9: get_medoid (2d_to_3d.py:116-119): argmin(cdist(P,P).sum(0)).
+ * pts (N,4); idx: M indices into pts.  colsum (optional, M floats) receives
+ * the per-column sums in this oracle's fixed order (sequential over rows i).
+ * torch.cdist: both sides <=25 rows -> direct; otherwise matmul expansion. */
+ORC_API int64_t orc_medoid(const float *pts, const int32_t *idx, int64_t M, float *colsum)
+{
+    if (M <= 0) return -1;
+    float *s = (float *)calloc((size_t)M, sizeof(float));
+    float *q = (float *)malloc((size_t)M * 4 * sizeof(float));
+    for (int64_t j = 0; j < M; ++j) {
+        const float *p = pts + 4 * (int64_t)idx[j];
+        q[4 * j] = p[0]; q[4 * j + 1] = p[1]; q[4 * j + 2] = p[2];
+        q[4 * j + 3] = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
+    }
+    if (M <= 25) {
+        for (int64_t i = 0; i < M; ++i)
+            for (int64_t j = 0; j < M; ++j) {
+                float agg = 0.0f;
+                for (int k = 0; k < 3; ++k) {
+                    float d = fabsf(q[4 * i + k] - q[4 * j + k]);
+                    agg = fmaf(d, d, agg);
+                }
+                s[j] = s[j] + sqrtf(agg);
+            }
+    } else {
+        for (int64_t i = 0; i < M; ++i) {
+            float ax = -2.0f * q[4 * i], ay = -2.0f * q[4 * i + 1], az = -2.0f * q[4 * i + 2], an = q[4 * i + 3];
+            for (int64_t j = 0; j < M; ++j) {
+                float acc = ax * q[4 * j];
+                acc = fmaf(ay, q[4 * j + 1], acc);
+                acc = fmaf(az, q[4 * j + 2], acc);
+                acc = fmaf(an, 1.0f, acc);
+                acc = fmaf(1.0f, q[4 * j + 3], acc);
+                acc = acc > 0.0f ? acc : (acc != acc ? acc : 0.0f);
+                s[j] = s[j] + sqrtf(acc);
+            }
+        }
+    }
+    int64_t best = 0;
+    for (int64_t j = 1; j < M; ++j) {
+        /* torch.argmin: first minimum; NaN counts as minimal */
+        if (s[best] != s[best]) break;
+        if (s[j] < s[best] || s[j] != s[j]) best = j;
+    }
+    if (colsum) memcpy(colsum, s, (size_t)M * sizeof(float));
+    free(s); free(q);
+    return best;
+}
+
+/* ------------------------------------------------------------------ */
+/* a10: lane_yaws_distances_and_coords (2d_to_3d.py:277-302): inputs rounded
+ * to float32 (torch.Tensor), scipy cdist in float64 on (x,y), argmin (first
+ * minimum) and min per centroid.  cent: (K,3) f32, lane: (L,3) f32 x,y,yaw. */
+ORC_API void orc_lane_nn(const float *cent, int64_t K, const float *lane, int64_t L,
+                         int32_t *out_j, double *out_dist)
+{
+    for (int64_t k = 0; k < K; ++k) {
+        double cx = (double)cent[3 * k], cy = (double)cent[3 * k + 1];
+        double best = INFINITY; int64_t bj = 0;
+        for (int64_t j = 0; j < L; ++j) {
+            double dx = cx - (double)lane[3 * j], dy = cy - (double)lane[3 * j + 1];
+            double d = sqrt(dx * dx + dy * dy);
+            if (d < best) { best = d; bj = j; }
+        }
+        out_j[k] = (int32_t)bj; out_dist[k] = best;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* a13: orientation + push_centroid (2d_to_3d.py:164-198, 788-806).
+ * centroid: medoid xyz (f32); prior: [w,l,h] from the table (:760);
+ * yaw: lane yaw (an f32 value, :295); ego: LIDAR_TOP ego_pose translation
+ * (:793-795); is_vehicle: name in {car,truck,bus,construction_vehicle,
+ * trailer,barrier} (:763).  out_t[3] translation, out_q[4] wxyz rotation. */
+ORC_API void orc_box_assemble(const float *centroid, const double *prior, float yaw,
+                              const double *ego, int is_vehicle, double *out_t, double *out_q)
+{
+    double c[3] = { (double)centroid[0], (double)centroid[1], (double)centroid[2] };
+    if (!is_vehicle) {            /* :802-806: identity rotation, raw medoid */
+        out_t[0] = c[0]; out_t[1] = c[1]; out_t[2] = c[2];
+        out_q[0] = 1.0; out_q[1] = 0.0; out_q[2] = 0.0; out_q[3] = 0.0;
+        return;
+    }
+    /* :788-789: np.cos/np.sin of an np.float32 -> float32 results */
+    double cs = (double)cosf(yaw), sn = (double)sinf(yaw);
+    /* pyquaternion 0.9.9 Quaternion(matrix=Rz): trace method on M^T */
+    double qw, qz;
+    if (cs < -cs) { double t = 1.0 - cs - cs + 1.0; double f = 0.5 / sqrt(t); qw = (sn + sn) * f; qz = t * f; }
+    else          { double t = 1.0 + cs + cs + 1.0; double f = 0.5 / sqrt(t); qw = t * f; qz = (sn + sn) * f; }
+    out_q[0] = qw; out_q[1] = 0.0; out_q[2] = 0.0; out_q[3] = qz;
+    /* :173-175: scipy from_quat([w,x,y,z]) reads it as [x,y,z,w] => a rotation
+     * about x by phi = 2*atan2(qw, qz); theta = -phi (wrapped to (-pi,pi]). */
+    double phi = 2.0 * atan2(qw, qz);
+    if (phi > M_PI) phi -= 2.0 * M_PI;
+    if (phi <= -M_PI) phi += 2.0 * M_PI;
+    double theta = -phi;
+    if (theta != theta) theta = 0.5 * M_PI;
+    double ex = c[0] - ego[0], ey = c[1] - ego[1];
+    double alpha = atan(fabs(ey) / fabs(ex));
+    if (ex < 0) { if (ey < 0) alpha = -M_PI + alpha; else alpha = M_PI - alpha; }
+    else        { if (ey < 0) alpha = -alpha; }
+    double l = prior[0], w = prior[1];   /* names as in :169-170 */
+    double o1 = fabs(w / (2.0 * sin(theta - alpha)));
+    double o2 = fabs(l / (2.0 * cos(theta - alpha)));
+    double off = o1 < o2 ? o1 : o2;
+    if (o1 != o1 || o2 != o2) off = NAN;  /* np.min propagates NaN */
+    out_t[0] = c[0] + off * cos(alpha);
+    out_t[1] = c[1] + off * sin(alpha);
+    out_t[2] = c[2];
+}
+
+/* ------------------------------------------------------------------ */
+/* a15: circle_nms (2d_to_3d.py:309-332) with the driver's per-label squared
+ * thresholds (:850-861).  Order = descending score; ties broken by DESCENDING
+ * original index (a reversed stable ascending sort) -- a deliberate pin, the
+ * reference's reversed unstable argsort leaves tie order undefined.
+ * keep[n] gets 0/1; returns number kept. */
+ORC_API int orc_circle_nms(const double *x, const double *y, const double *score,
+                           const int32_t *label, int n, const double *thr_by_label, uint8_t *keep)
+{
+    int *order = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    uint8_t *sup = (uint8_t *)calloc((size_t)(n > 0 ? n : 1), 1);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    /* insertion sort: descending score, then descending index */
+    for (int a = 1; a < n; ++a) {
+        int v = order[a], b = a - 1;
+        while (b >= 0 && (score[order[b]] < score[v] || (score[order[b]] == score[v] && order[b] < v))) {
+            order[b + 1] = order[b]; --b;
+        }
+        order[b + 1] = v;
+    }
+    int kept = 0;
+    memset(keep, 0, (size_t)n);
+    for (int _i = 0; _i < n; ++_i) {
+        int i = order[_i];
+        if (sup[i]) continue;
+        keep[i] = 1; kept++;
+        for (int _j = _i + 1; _j < n; ++_j) {
+            int j = order[_j];
+            if (sup[j]) continue;
+            double dx = x[i] - x[j], dy = y[i] - y[j];
+            double dist = dx * dx + dy * dy;
+            if (dist <= thr_by_label[label[j]] && label[j] == label[i]) sup[j] = 1;
+        }
+    }
+    free(order); free(sup);
+    return kept;
+}

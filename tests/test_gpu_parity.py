@@ -1,0 +1,79 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded
+frames.  Bit-exact for indices / integer outputs and for float32 centroids; 1e-4 (north_star)
+on the float64 box parameters, in practice ~1e-12."""
+import numpy as np
+import pytest
+
+from cm3d_amd import synthetic as syn
+from tests.helpers import oracle_batch
+
+pytestmark = pytest.mark.gpu
+
+BOX_TOL = 1e-4    # BASELINE.json north_star tolerance on (x,y,z,l,w,h,theta)
+
+
+def _run(cfg_name, n_frames, masks, oracle, **over):
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config(cfg_name, **over)
+    frames = [syn.make_frame(cfg, i) for i in range(n_frames)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 4000, seed=1), syn.make_lane_table(frames[-1].ego_xyz[:2], 3000, seed=2)]
+    frame_lane = [i % 2 for i in range(n_frames)]
+    hb = lifting.pack_frames(frames, lanes, frame_lane)
+    eng = lifting.LiftEngine(keep_colsum=True)
+    eng.upload(hb)
+    if masks == "dense":
+        eng.decode_masks_dense()
+    eng.run(masks=masks)
+    torch.cuda.synchronize()
+    got = eng.download()
+    exp = oracle_batch(oracle, frames, lanes, frame_lane, hb)
+    return hb, got, exp
+
+
+def _compare(hb, got, exp):
+    assert np.array_equal(got["pt_off"], exp["pt_off"])
+    assert np.array_equal(got["points"].view(np.uint32), exp["points"].view(np.uint32)), "sweep prep not bit-exact"
+    assert np.array_equal(got["bbox"], exp["bbox"])
+    assert np.array_equal(got["hit_off"], exp["hit_off"])
+    assert np.array_equal(got["hit_idx"], exp["hit_idx"]), "point-to-mask index lists differ"
+    assert np.array_equal(got["medoid_pos"], exp["medoid_pos"])
+    assert np.array_equal(got["centroid"].view(np.uint32), exp["centroid"].view(np.uint32))
+    assert np.array_equal(got["lane_idx"], exp["lane_idx"])
+    valid = exp["medoid_pos"] >= 0
+    assert np.array_equal(got["lane_dist"][valid], exp["lane_dist"][valid])
+    assert np.array_equal(got["flags"], exp["flags"])
+    assert np.allclose(got["box"], exp["box"], rtol=0, atol=BOX_TOL)
+    assert np.abs(got["box"] - exp["box"]).max() < 1e-9     # what we actually see
+
+
+@pytest.mark.parametrize("masks", ["dense", "rle"])
+def test_tiny_frames(oracle, masks):
+    hb, got, exp = _run("tiny", 5, masks, oracle)
+    assert exp["hit_idx"].size > 50
+    _compare(hb, got, exp)
+
+
+@pytest.mark.parametrize("masks", ["dense", "rle"])
+def test_reference_resolution_frame(oracle, masks):
+    # C1: 3 sweeps x 34.7k points, 6 x 1024x576 masks, ratio 0.64 -- the reference's own configuration
+    hb, got, exp = _run("c1", 2, masks, oracle)
+    assert exp["hit_idx"].size > 1000
+    _compare(hb, got, exp)
+
+
+def test_headline_resolution_frame(oracle):
+    # C2 shape: 35k points, 6 x 1600x900 masks, ratio 1.0
+    hb, got, exp = _run("c2", 2, "dense", oracle)
+    _compare(hb, got, exp)
+
+
+def test_colsum_bit_exact(oracle):
+    hb, got, exp = _run("c1", 1, "rle", oracle)
+    pts = exp["points"]
+    for m in range(hb.n_masks):
+        o, e = exp["hit_off"][m], exp["hit_off"][m + 1]
+        if e - o == 0:
+            continue
+        _, cs = oracle.medoid(pts, exp["hit_idx"][o:e], want_colsum=True)
+        assert np.array_equal(cs.view(np.uint32), got["colsum"][o:e].view(np.uint32)), f"mask {m} column sums differ"
