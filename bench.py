@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the lifting hot path (BASELINE.json: pseudo-label frames/sec on
+nuScenes-shaped sweeps).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the whole path (a2 sweep prep, a1+a3 mask expansion/erosion, a4-a8
+projection + in-mask gather + ordered compaction, a9 medoid, a10 lane NN, a11-a15 boxes + NMS)
+over one batch of synthetic frames resident in HBM.  Default workload = BASELINE config C2:
+256 frames x (35k points, 6 cameras, 20 masks of 1600x900).  Every rank owns its own batch
+(weak scaling); after the K steps one RCCL gather ships the fixed-size box records to rank 0.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from cm3d_amd import dist as cdist, lifting, synthetic as syn  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def algorithmic_bytes(hb, sum_hits, mode):
+    """SURVEY.md 8(d).  Returns per-kernel algorithmic bytes of ONE pass over the batch."""
+    F, M = hb.n_frames, hb.n_masks
+    W, H = hb.width, hb.height
+    packed = M * ((W + 31) // 32) * 4 * H
+    n_raw = hb.n_raw_rows
+    n_pts = n_raw      # upper bound; the ego-box filter removes ~0.2 %
+    alg = {
+        # ALG_PG = 16 N + n*ceil(W*H/8) + 4*sum(M_i) + 4*(n+1), summed over the frames of the batch
+        "project_gather": 16 * n_pts + packed + 4 * sum_hits + 4 * (M + F),
+        "k_project_hits": 16 * n_pts + packed + 4 * n_pts,
+        "k_erode_pack": M * W * H + packed,
+        "k_rle_erode_pack": 4 * int(hb.rle_counts.size) + packed,
+        "k_sweep": 2 * 4 * hb.raw_stride * n_raw + 16 * n_pts,
+    }
+    masks_in = M * W * H if mode == "dense" else 4 * int(hb.rle_counts.size)
+    alg["frame_total"] = alg["project_gather"] + masks_in + packed + 16 * sum_hits + 64 * M
+    return alg
+
+
+def cpu_baseline(frames, lanes, frame_lane, hb, n_sample):
+    """The CPU oracle (oracle/, a plain-C port of the reference algorithm in the reference's
+    execution order: per-mask clone + re-projection, per-mask full-frame erode, O(M^2) medoid,
+    f64 lane NN, circle NMS) timed on this box's host cores, single thread."""
+    from oracle import oracle as orc
+    from tests.helpers import oracle_batch
+    orc.lib()
+    n_sample = max(1, min(n_sample, len(frames)))
+    sub = frames[:n_sample]
+    sub_hb = lifting.pack_frames(sub, lanes, frame_lane[:n_sample])
+    t0 = time.perf_counter()
+    oracle_batch(orc, sub, lanes, frame_lane[:n_sample], sub_hb)
+    dt = time.perf_counter() - t0
+    cpu_model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": n_sample / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_sample} frames of the same synthetic batch, {dt:.1f} s, host has {os.cpu_count()} cores ({cpu_model})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--config", default="c2", help="synthetic config (c1,c2,c4,c5,tiny)")
+    ap.add_argument("--masks", default="rle", choices=["rle", "dense"],
+                    help="mask input resident in HBM: COCO-RLE run lengths (the on-disk contract) or dense uint8")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--lane-points", type=int, default=50000)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second mask mode")
+    args = ap.parse_args()
+
+    rank, world, local_rank = cdist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    cfg = syn.config(args.config)
+    t_gen = time.perf_counter()
+    frames = [syn.make_frame(cfg, rank * args.frames + i) for i in range(args.frames)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], args.lane_points, seed=7 + rank)]
+    frame_lane = [0] * len(frames)
+    hb = lifting.pack_frames(frames, lanes, frame_lane)
+    t_gen = time.perf_counter() - t_gen
+
+    eng = lifting.LiftEngine(dev)
+    eng.upload(hb)
+    modes = [args.masks] + ([] if args.no_secondary else [m for m in ("rle", "dense") if m != args.masks])
+    if "dense" in modes:
+        eng.decode_masks_dense()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    results = {}
+    for mode in modes:
+        stages = list(eng.STAGES)
+        ev = {s: [] for s in stages}
+        st = torch.cuda.current_stream(dev).cuda_stream
+        calls = {"sweeps": eng.stage_sweeps, "masks": lambda s: eng.stage_masks(s, mode), "project": eng.stage_project,
+                 "compact": eng.stage_compact, "medoid": eng.stage_medoid, "lanes": eng.stage_lanes, "boxes": eng.stage_boxes}
+        for _ in range(args.warmup):
+            eng.run(masks=mode)
+        torch.cuda.synchronize()
+        eng.check_status()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.stage_begin(st)
+            for s in stages:
+                if s == "project":      # HIP events around the roofline kernel only, on the launch stream
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    calls[s](st)
+                    b.record()
+                    ev[s].append((a, b))
+                else:
+                    calls[s](st)
+        gathered = None
+        if mode == modes[0]:
+            # the single end-of-job exchange: fixed-size box records -> rank 0 (RCCL gather)
+            gathered = cdist.gather_records(eng.b.box, dst=0)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tmax.item())
+        # per-stage breakdown: a separate, untimed pass with events around every stage
+        for _ in range(max(3, min(args.steps, 10))):
+            eng.stage_begin(st)
+            for s in stages:
+                if s == "project":
+                    calls[s](st)
+                    continue
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                calls[s](st)
+                b.record()
+                ev[s].append((a, b))
+        torch.cuda.synchronize()
+        stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) for s in stages}
+        status = eng.check_status()
+        results[mode] = dict(dt=dt, stage_ms=stage_ms, sum_hits=int(status[2]), n_points=int(status[1]),
+                             n_boxes=int((eng.b.flags == 3).sum().item()),
+                             n_gathered=None if gathered is None else int(sum(g.shape[0] for g in gathered)))
+
+    if rank != 0:
+        return
+    main_mode = modes[0]
+    r = results[main_mode]
+    frames_total = args.frames * world * args.steps
+    value = frames_total / r["dt"]
+    alg = algorithmic_bytes(hb, r["sum_hits"], main_mode)
+
+    def roof(kernel_key, stage_key, res, kernel_name, note):
+        ms = res["stage_ms"][stage_key]
+        ach = alg[kernel_key] / (ms * 1e-3) / 1e9
+        return {"kernel": kernel_name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": int(alg[kernel_key]),
+                "avg_launch_ms": round(ms, 4), "note": note}
+
+    # north_star's kernel: projection + in-mask gather (k_project_hits, one launch per pass)
+    roofline = roof("k_project_hits", "project", r, "k_project_hits",
+                    "algorithmic bytes = 16 B/point + every bit-packed mask once + 4 B/point hit word; the kernel's "
+                    "bounding-box test lets it skip most mask bytes, so achieved can exceed what HBM would allow for a full read")
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            roofline["traffic"] = tr.get(f"{args.config}_{main_mode}", {}).get("k_project_hits")
+        except (OSError, ValueError):
+            pass
+    mask_kernel = "k_erode_pack" if main_mode == "dense" else "k_rle_erode_pack"
+    kernels = {
+        "masks": roof(mask_kernel, "masks", r, mask_kernel, "HBM streaming"),
+        "sweeps": roof("k_sweep", "sweeps", r, "k_sweep_count+k_scan_i32+k_sweep_scatter", "HBM streaming, 4 launches"),
+        "stage_ms": {k: round(v, 4) for k, v in r["stage_ms"].items()},
+    }
+    out = {
+        "metric": "pseudo-label frames/sec on nuScenes-shaped sweeps", "value": round(value, 1), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(r["dt"] / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {args.frames} frames/GPU x ({cfg.n_points}x{cfg.n_sweeps} pts, {cfg.n_cams} cams, "
+                               f"{cfg.n_masks} masks {cfg.width}x{cfg.height}), masks resident as {main_mode}",
+                   "frames_per_gpu": args.frames, "points_per_frame": cfg.n_points * cfg.n_sweeps, "masks_per_frame": cfg.n_masks,
+                   "mask_size": [cfg.width, cfg.height], "lane_points": args.lane_points, "mask_input": main_mode,
+                   "parallelism": f"frame-sharded x{world}, one RCCL gather of box records"},
+        "roofline": roofline,
+        "kernels": kernels,
+        "frame_alg_bytes": int(alg["frame_total"] // hb.n_frames),
+        "boxes_per_step": r["n_boxes"], "in_mask_points_per_step": r["sum_hits"],
+        "gen_seconds": round(t_gen, 1),
+    }
+    for mode in modes[1:]:
+        o = results[mode]
+        out[f"value_{mode}_masks"] = round(frames_total / o["dt"], 1)
+        out[f"stage_ms_{mode}_masks"] = {k: round(v, 4) for k, v in o["stage_ms"].items()}
+    if world == 1 and args.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(frames, lanes, frame_lane, hb, args.cpu_sample)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -14,7 +14,7 @@ CAM_STRIDE = 40
 SWEEP_XF_STRIDE = 24
 MAX_CAMS = 8
 MAX_MASKS_PER_FRAME = 1024
-BOX_STRIDE = 8
+BOX_STRIDE = 10
 MEDOID_TILE = 256
 STATUS_WORDS = 4
 
@@ -24,6 +24,7 @@ _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "cm3d_abi_version": (_i32, []),
     "cm3d_error_string": (C.c_char_p, [_i32]),
+    "cm3d_batch_begin": (_i32, [_p, _p, _i32, _p]),
     "cm3d_sweep_prep_workspace_bytes": (_i64, [_i32, _i32]),
     "cm3d_sweep_prep": (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _f32, _p, _i32, _p, _p, _p, _i64, _p]),
     "cm3d_rle_workspace_bytes": (_i64, [_i32]),

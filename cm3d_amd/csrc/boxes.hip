@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
             }
         }
         double *b = box + (size_t)m * CM3D_BOX_STRIDE;
-        b[0] = tx; b[1] = ty; b[2] = tz; b[3] = qw; b[4] = qz; b[5] = yaw_out; b[6] = ld; b[7] = 0.0;
+        b[0] = tx; b[1] = ty; b[2] = tz; b[3] = qw; b[4] = qz; b[5] = yaw_out; b[6] = ld; b[7] = score[m]; b[8] = (double)cls;
         s_x[k] = tx; s_y[k] = ty; s_s[k] = score[m]; s_lab[k] = cls;
         s_valid[k] = valid; s_sup[k] = 0; s_keep[k] = 0;
     }
@@ -229,7 +229,11 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
         }
         __syncthreads();
     }
-    for (int k = lane_id; k < nm; k += 64) flags[m0 + k] = (s_valid[k] ? 1 : 0) | (s_keep[k] ? 2 : 0);
+    for (int k = lane_id; k < nm; k += 64) {
+        const int fl = (s_valid[k] ? 1 : 0) | (s_keep[k] ? 2 : 0);
+        flags[m0 + k] = fl;
+        box[(size_t)(m0 + k) * CM3D_BOX_STRIDE + 9] = (double)fl;
+    }
 }
 
 extern "C" int cm3d_box_nms(const float *centroid, const int32_t *medoid_pos, const int32_t *mask_off, int32_t n_frames,

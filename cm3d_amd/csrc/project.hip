@@ -196,6 +196,21 @@ __global__ __launch_bounds__(1024) void k_compact_hits(const uint32_t *__restric
     }
 }
 
+__global__ void k_batch_begin(int32_t *__restrict__ status, int32_t *__restrict__ hit_count, int n_masks)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < CM3D_STATUS_WORDS) status[i] = 0;
+    if (i < n_masks) hit_count[i] = 0;
+}
+
+extern "C" int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, cm3d_stream_t stream)
+{
+    if (!status || !hit_count || n_masks <= 0) return CM3D_ERR_ARG;
+    hipLaunchKernelGGL(k_batch_begin, dim3((n_masks + 255) / 256), dim3(256), 0, (hipStream_t)stream, status, hit_count, n_masks);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
+}
+
 extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
                                  int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off,
                                  const int32_t *mask_cam, const int32_t *bbox, const uint32_t *packed, int32_t n_masks,
@@ -208,7 +223,6 @@ extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int
         n_masks <= 0 || W <= 1 || H <= 1 || W > 32767 || H > 32767 || planes <= 0)
         return CM3D_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(hit_count, 0, (size_t)n_masks * sizeof(int32_t), st) != hipSuccess) return CM3D_ERR_LAUNCH;
     const int Wp = (W + 31) / 32;
     dim3 grid((max_pts_per_frame + PH_THREADS - 1) / PH_THREADS, n_frames);
     hipLaunchKernelGGL(k_project_hits, grid, dim3(PH_THREADS), 0, st, (const float4 *)points, pt_off, n_points_total, cams,

@@ -254,6 +254,10 @@ class LiftEngine:
         return b.dense
 
     # -- the stages, in reference order
+    def stage_begin(self, st):
+        b = self.b
+        check(self.lib.cm3d_batch_begin(_ptr(b.status), _ptr(b.hit_count), b.M, st), "cm3d_batch_begin")
+
     def stage_sweeps(self, st):
         b = self.b
         check(self.lib.cm3d_sweep_prep(_ptr(b.raw), b.hb.raw_stride, _ptr(b.sweep_row_off), b.S, b.hb.max_rows_per_sweep,
@@ -310,7 +314,7 @@ class LiftEngine:
     def run(self, masks="dense"):
         """One pass of the hot path over the resident batch (asynchronous)."""
         st = torch.cuda.current_stream(self.dev).cuda_stream
-        self.b.status.zero_()
+        self.stage_begin(st)
         self.stage_sweeps(st)
         self.stage_masks(st, masks)
         self.stage_project(st)

@@ -41,7 +41,7 @@ extern "C" {
 #define CM3D_SWEEP_XF_STRIDE 24  /* floats per sweep transform, see cm3d_sweep_prep   */
 #define CM3D_MAX_CAMS 8          /* cameras per frame                                  */
 #define CM3D_MAX_MASKS_PER_FRAME 1024
-#define CM3D_BOX_STRIDE 8        /* doubles per box record, see cm3d_box_nms           */
+#define CM3D_BOX_STRIDE 10       /* doubles per box record, see cm3d_box_nms           */
 #define CM3D_MEDOID_TILE 256     /* columns per medoid tile                            */
 
 /* status word written by kernels (int32[4] in device memory, zero it per batch):
@@ -56,6 +56,10 @@ typedef void *cm3d_stream_t;
 
 int cm3d_abi_version(void);
 const char *cm3d_error_string(int code);
+
+/* Resets the per-pass device state: the status word and hit_count[n_masks].  First call of
+ * every pass over a batch. */
+int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, cm3d_stream_t stream);
 
 /* ---- a2: sweep preparation -------------------------------------------------
  * Replaces 2d_to_3d.py:437-465 + utils/pcd.py:159-172,246-257: strip a raw sweep to
@@ -111,7 +115,7 @@ int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int3
  *        hands them to translate/rotate/view_points.
  *  hit_words uint32[planes][n_points_total] OUT, planes = (max masks per frame + 31)/32;
  *        bit (k&31) of hit_words[k>>5][p] = point p lies in mask mask_off[f]+k
- *  hit_count int32[n_masks] OUT (zeroed inside) */
+ *  hit_count int32[n_masks] IN/OUT accumulated with atomics; zeroed by cm3d_batch_begin */
 int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
                       int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off,
                       const int32_t *mask_cam, const int32_t *bbox, const uint32_t *packed, int32_t n_masks,
@@ -160,7 +164,8 @@ int cm3d_lane_nn(const float *centroid, const int32_t *medoid_pos, const int32_t
  *  class_id int32[n_masks] index into the class tables; score double[n_masks]
  *  prior_wlh double[n_classes][3]; is_vehicle int32[n_classes]; nms_thr double[n_classes]
  *  ego_xyz double[F][3]   LIDAR_TOP ego_pose translation of each frame (:793-795)
- *  box   double[n_masks][CM3D_BOX_STRIDE] OUT: tx,ty,tz, qw,qz (rotation = [qw,0,0,qz]), lane yaw, lane dist, 0
+ *  box   double[n_masks][CM3D_BOX_STRIDE] OUT: tx,ty,tz, qw,qz (rotation = [qw,0,0,qz]), lane yaw, lane dist,
+ *        score, class id, flags -- the fixed-size record that the multi-GPU gather ships
  *  flags int32[n_masks] OUT: bit0 box exists (mask had points), bit1 box survives NMS */
 int cm3d_box_nms(const float *centroid, const int32_t *medoid_pos, const int32_t *mask_off, int32_t n_frames,
                  int32_t n_masks, const int32_t *class_id, const double *score, const float *lane,

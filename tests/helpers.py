@@ -27,12 +27,15 @@ def oracle_batch(orc, frames, lane_tables, frame_lane, hb):
         m0, m1 = hb.mask_off[fi], hb.mask_off[fi + 1]
         s2 = orc.stage2_frame(cent, med, hb.class_id[m0:m1], hb.score[m0:m1], lane_tables[frame_lane[fi]], fr.ego_xyz)
         lane_idx.append(s2["lane_idx"]); lane_dist.append(s2["lane_dist"])
-        b = np.zeros((m1 - m0, 8))
+        b = np.zeros((m1 - m0, 10))
         b[:, 0:3] = np.where(s2["valid"][:, None], s2["translation"], 0.0)
         b[:, 3] = np.where(s2["valid"], s2["rotation"][:, 0], 1.0)
         b[:, 4] = np.where(s2["valid"], s2["rotation"][:, 3], 0.0)
         b[:, 5] = s2["yaw"]
         b[:, 6] = np.where(s2["valid"], s2["lane_dist"], 0.0)
+        b[:, 7] = hb.score[m0:m1]
+        b[:, 8] = hb.class_id[m0:m1]
+        b[:, 9] = s2["valid"].astype(np.int32) | (s2["keep"].astype(np.int32) << 1)
         box.append(b)
         flags.append(s2["valid"].astype(np.int32) | (s2["keep"].astype(np.int32) << 1))
     return dict(points=np.concatenate(pts_all, 0), pt_off=np.array(pt_off, np.int32),
