@@ -135,6 +135,46 @@ extern "C" int cm3d_lane_nn(const float *centroid, const int32_t *medoid_pos, co
 // One wave per frame: box assembly for every mask with a centroid, then greedy circle NMS.
 #define BN_MAX CM3D_MAX_MASKS_PER_FRAME
 
+// Greedy class-aware circle NMS over the LDS arrays of one frame (one wave).
+// reference circle_nms src/nuscenes/2d_to_3d.py:309-332.
+static __device__ __forceinline__ void nms_phase(int nm, int lane_id, const double *__restrict__ nms_thr, const double *s_x,
+                                                 const double *s_y, const double *s_s, const int *s_lab, int *s_order,
+                                                 const unsigned char *s_valid, unsigned char *s_sup, unsigned char *s_keep)
+{
+    __syncthreads();
+    // order: descending score, ties by descending index (pinned tie-break, SURVEY hard part 4)
+    int nv = 0;
+    for (int k = 0; k < nm; ++k) nv += s_valid[k];
+    for (int k = lane_id; k < nm; k += 64) {
+        if (!s_valid[k]) continue;
+        int rank = 0;
+        const double sk = s_s[k];
+        for (int j = 0; j < nm; ++j) {
+            if (!s_valid[j]) continue;
+            const double sj = s_s[j];
+            rank += (sj > sk || (sj == sk && j > k)) ? 1 : 0;
+        }
+        s_order[rank] = k;
+    }
+    __syncthreads();
+    for (int r = 0; r < nv; ++r) {
+        const int i = s_order[r];
+        if (!s_sup[i]) {            // uniform: every lane reads the same LDS word
+            if (lane_id == 0) s_keep[i] = 1;
+            const double xi = s_x[i], yi = s_y[i];
+            const int li = s_lab[i];
+            for (int r2 = r + 1 + lane_id; r2 < nv; r2 += 64) {
+                const int j = s_order[r2];
+                if (s_sup[j]) continue;
+                const double dx = xi - s_x[j], dy = yi - s_y[j];
+                const double dist = dx * dx + dy * dy;
+                if (dist <= nms_thr[s_lab[j]] && s_lab[j] == li) s_sup[j] = 1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centroid, const int32_t *__restrict__ medoid_pos,
                                                 const int32_t *__restrict__ mask_off, const int32_t *__restrict__ class_id,
                                                 const double *__restrict__ score, const float *__restrict__ lane,
@@ -197,38 +237,7 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
         s_x[k] = tx; s_y[k] = ty; s_s[k] = score[m]; s_lab[k] = cls;
         s_valid[k] = valid; s_sup[k] = 0; s_keep[k] = 0;
     }
-    __syncthreads();
-    // order: descending score, ties by descending index (pinned tie-break, SURVEY hard part 4)
-    int nv = 0;
-    for (int k = 0; k < nm; ++k) nv += s_valid[k];
-    for (int k = lane_id; k < nm; k += 64) {
-        if (!s_valid[k]) continue;
-        int rank = 0;
-        const double sk = s_s[k];
-        for (int j = 0; j < nm; ++j) {
-            if (!s_valid[j]) continue;
-            const double sj = s_s[j];
-            rank += (sj > sk || (sj == sk && j > k)) ? 1 : 0;
-        }
-        s_order[rank] = k;
-    }
-    __syncthreads();
-    for (int r = 0; r < nv; ++r) {
-        const int i = s_order[r];
-        if (!s_sup[i]) {            // uniform: every lane reads the same LDS word
-            if (lane_id == 0) s_keep[i] = 1;
-            const double xi = s_x[i], yi = s_y[i];
-            const int li = s_lab[i];
-            for (int r2 = r + 1 + lane_id; r2 < nv; r2 += 64) {
-                const int j = s_order[r2];
-                if (s_sup[j]) continue;
-                const double dx = xi - s_x[j], dy = yi - s_y[j];
-                const double dist = dx * dx + dy * dy;
-                if (dist <= nms_thr[s_lab[j]] && s_lab[j] == li) s_sup[j] = 1;
-            }
-        }
-        __syncthreads();
-    }
+    nms_phase(nm, lane_id, nms_thr, s_x, s_y, s_s, s_lab, s_order, s_valid, s_sup, s_keep);
     for (int k = lane_id; k < nm; k += 64) {
         const int fl = (s_valid[k] ? 1 : 0) | (s_keep[k] ? 2 : 0);
         flags[m0 + k] = fl;
@@ -250,6 +259,42 @@ extern "C" int cm3d_box_nms(const float *centroid, const int32_t *medoid_pos, co
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_box_nms, dim3(n_frames), dim3(64), 0, st, centroid, medoid_pos, mask_off, class_id, score, lane,
                        lane_off, frame_lane, lane_idx, lane_dist, prior_wlh, is_vehicle, nms_thr, n_classes, ego_xyz, box, flags);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
+}
+
+
+// standalone NMS on float64 centres (frames given by frame_off), same device function as k_box_nms
+__global__ __launch_bounds__(64) void k_circle_nms(const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ score, const int32_t *__restrict__ label,
+                                                   const int32_t *__restrict__ frame_off, const double *__restrict__ nms_thr,
+                                                   int n_classes, int32_t *__restrict__ keep)
+{
+    __shared__ double s_x[BN_MAX], s_y[BN_MAX], s_s[BN_MAX];
+    __shared__ int s_lab[BN_MAX], s_order[BN_MAX];
+    __shared__ unsigned char s_valid[BN_MAX], s_sup[BN_MAX], s_keep[BN_MAX];
+    const int f = blockIdx.x;
+    const int m0 = frame_off[f];
+    const int nm = min(frame_off[f + 1] - m0, BN_MAX);
+    const int lane_id = threadIdx.x;
+    for (int k = lane_id; k < nm; k += 64) {
+        int cls = label[m0 + k];
+        if (cls < 0 || cls >= n_classes) cls = 0;
+        s_x[k] = x[m0 + k]; s_y[k] = y[m0 + k]; s_s[k] = score[m0 + k]; s_lab[k] = cls;
+        s_valid[k] = 1; s_sup[k] = 0; s_keep[k] = 0;
+    }
+    nms_phase(nm, lane_id, nms_thr, s_x, s_y, s_s, s_lab, s_order, s_valid, s_sup, s_keep);
+    for (int k = lane_id; k < nm; k += 64) keep[m0 + k] = s_keep[k];
+}
+
+extern "C" int cm3d_circle_nms(const double *x, const double *y, const double *score, const int32_t *label,
+                               const int32_t *frame_off, int32_t n_frames, const double *nms_thr, int32_t n_classes,
+                               int32_t *keep, cm3d_stream_t stream)
+{
+    if (!x || !y || !score || !label || !frame_off || !nms_thr || !keep) return CM3D_ERR_ARG;
+    if (n_frames <= 0 || n_classes <= 0) return CM3D_ERR_ARG;
+    hipLaunchKernelGGL(k_circle_nms, dim3(n_frames), dim3(64), 0, (hipStream_t)stream, x, y, score, label, frame_off, nms_thr,
+                       n_classes, keep);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

@@ -174,6 +174,12 @@ int cm3d_box_nms(const float *centroid, const int32_t *medoid_pos, const int32_t
                  const double *nms_thr, int32_t n_classes, const double *ego_xyz, double *box, int32_t *flags,
                  cm3d_stream_t stream);
 
+/* circle_nms alone (2d_to_3d.py:309-332) on float64 centres: boxes [frame_off[f], frame_off[f+1]) form
+ * one sample; keep[i] = 1 for the survivors.  Order: descending score, ties by descending index. */
+int cm3d_circle_nms(const double *x, const double *y, const double *score, const int32_t *label,
+                    const int32_t *frame_off, int32_t n_frames, const double *nms_thr, int32_t n_classes,
+                    int32_t *keep, cm3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

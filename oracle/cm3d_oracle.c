@@ -231,6 +231,40 @@ ORC_API int64_t orc_points_in_mask(const float *pts, int64_t N, const float *cam
     return M;
 }
 
+
+/* a4-a5 only: camera-frame depth and pixel coordinates of every point (used to pin the
+ * transform chain against the reference's translate/rotate/view_points, golden G1).
+ * out: (N,3) rows u, v, depth. */
+ORC_API void orc_project_points(const float *pts, int64_t N, const float *cam, float *out)
+{
+    int stages = (int)cam[33];
+    const float *K = cam + 24;
+    for (int64_t i = 0; i < N; ++i) {
+        float x = pts[4 * i], y = pts[4 * i + 1], z = pts[4 * i + 2];
+        for (int s = 0; s < stages; ++s) {
+            const float *t = cam + 12 * s, *R = cam + 12 * s + 3;
+            x = x + t[0]; y = y + t[1]; z = z + t[2];
+            float o[3];
+            for (int r = 0; r < 3; ++r) {
+                float acc = R[3 * r] * x;
+                acc = fmaf(R[3 * r + 1], y, acc);
+                acc = fmaf(R[3 * r + 2], z, acc);
+                o[r] = acc;
+            }
+            x = o[0]; y = o[1]; z = o[2];
+        }
+        float h[3];
+        for (int r = 0; r < 3; ++r) {
+            float acc = K[3 * r] * x;
+            acc = fmaf(K[3 * r + 1], y, acc);
+            acc = fmaf(K[3 * r + 2], z, acc);
+            acc = fmaf(0.0f, 1.0f, acc);
+            h[r] = acc;
+        }
+        out[3 * i] = h[0] / h[2]; out[3 * i + 1] = h[1] / h[2]; out[3 * i + 2] = z;
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* a9: get_medoid (2d_to_3d.py:116-119): argmin(cdist(P,P).sum(0)).
  * pts (N,4); idx: M indices into pts.  colsum (optional, M floats) receives

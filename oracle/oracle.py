@@ -44,6 +44,8 @@ def _load():
     lib.orc_erode3x3.argtypes = [p, i32, i32, p]
     lib.orc_points_in_mask.restype = i64
     lib.orc_points_in_mask.argtypes = [p, i64, p, p, i32, i32, f32, p, p]
+    lib.orc_project_points.restype = None
+    lib.orc_project_points.argtypes = [p, i64, p, p]
     lib.orc_medoid.restype = i64
     lib.orc_medoid.argtypes = [p, p, i64, p]
     lib.orc_lane_nn.restype = None
@@ -153,6 +155,14 @@ def points_in_mask(pts, cam, eroded_hw, min_dist=MIN_DIST_F32):
     scratch = np.empty(3 * max(N, 1), np.float32)
     m = lib().orc_points_in_mask(_ptr(pts), N, _ptr(_f32(cam)), _ptr(er), W, H, float(min_dist), _ptr(out), _ptr(scratch))
     return out[:m].copy()
+
+
+def project_points(pts, cam):
+    """(N,3) float32 rows (u, v, camera-frame depth)."""
+    pts = _f32(pts)
+    out = np.empty((pts.shape[0], 3), np.float32)
+    lib().orc_project_points(_ptr(pts), pts.shape[0], _ptr(_f32(cam)), _ptr(out))
+    return out
 
 
 # ---------------------------------------------------------------- a9

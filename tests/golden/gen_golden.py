@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz|json by RUNNING THE REFERENCE'S OWN HELPERS in the build
+container (where /root/reference exists).  Never runs on the GPU box; the fixtures it writes are
+data (inputs + the outputs the reference produced) and are committed.
+
+What is imported from the reference (read-only, with inert stand-in modules for third-party
+imports that are not installed here and that these helpers never call -- cv2, pycocotools,
+pyquaternion, shapely, nuscenes, ...):
+    src/nuscenes/utils/pcd.py   : LidarPointCloud.translate / .rotate, view_points
+    src/nuscenes/2d_to_3d.py    : get_medoid, push_centroid, circle_nms,
+                                  lane_yaws_distances_and_coords, get_detection_name, get_shape_prior
+The per-mask loop body (2d_to_3d.py:553-620) is inline script code; G2 re-runs it here statement by
+statement on top of the imported LidarPointCloud / view_points with the same torch calls.
+
+Usage: python tests/golden/gen_golden.py   (from the repo root)
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/src/nuscenes"
+
+from cm3d_amd import geometry as geo, rle as rlemod, synthetic as syn  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        m = _Stub(self.__name__ + "." + k)
+        setattr(self, k, m)
+        return m
+
+    def __call__(self, *a, **k):
+        return None
+
+
+def _load_reference():
+    absent = ["cv2", "torchvision", "pycocotools", "hdbscan", "pyquaternion", "groundingdino.datasets.transforms",
+              "groundingdino.models", "groundingdino.util.slconfig", "groundingdino.util.utils", "segment_anything",
+              "shapely.geometry", "nuscenes.nuscenes", "nuscenes.utils.data_classes", "nuscenes.utils.geometry_utils",
+              "nuscenes.map_expansion.map_api", "nuscenes.map_expansion.arcline_path_utils", "nuscenes.map_expansion.bitmap",
+              "nuscenes.utils.splits", "numba"]
+    for name in absent:
+        parts = name.split(".")
+        for i in range(1, len(parts) + 1):
+            n = ".".join(parts[:i])
+            try:
+                if n not in sys.modules:
+                    importlib.import_module(n)
+            except Exception:
+                sys.modules[n] = _Stub(n)
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    pcd = load(os.path.join(REF, "utils/pcd.py"), "utils.pcd")
+    utils = types.ModuleType("utils")
+    utils.pcd = pcd
+    sys.modules["utils"] = utils
+    ref = load(os.path.join(REF, "2d_to_3d.py"), "ref_2d_to_3d")
+    ref.timer = {"closest lane": 0}       # module global the function accumulates into (2d_to_3d.py:300)
+    return pcd, ref
+
+
+def reference_mask_body(pcd, pts, cam, eroded_hw, min_dist=2.3):
+    """2d_to_3d.py:543-617 on CPU tensors; cam = our float32 camera record (the tensors the
+    reference builds at :570-577,:585-587).  Returns track_points (ascending point indices)."""
+    DEVICE = "cpu"
+    aggr_pc_points = torch.from_numpy(np.ascontiguousarray(pts.T))            # (4,N)
+    maskarr_1 = np.asarray(eroded_hw)[:, :].astype(bool)
+    maskarr_1 = torch.transpose(torch.from_numpy(maskarr_1).to(device=DEVICE, dtype=bool), 1, 0)   # :544
+    track_points = np.array(range(aggr_pc_points.shape[1]))                   # :548
+    cam_pc = pcd.LidarPointCloud(torch.clone(aggr_pc_points))                 # :553
+    stages = int(cam[33])
+    for s in range(stages):
+        cam_pc.translate(torch.from_numpy(cam[12 * s:12 * s + 3].copy()))     # :570 / :576
+        cam_pc.rotate(torch.from_numpy(cam[12 * s + 3:12 * s + 12].reshape(3, 3).copy()))   # :571 / :577
+    depths = cam_pc.points[2, :]                                              # :581
+    camera_intrinsic = torch.from_numpy(cam[24:33].reshape(3, 3).copy())
+    points, point_depths = pcd.view_points(cam_pc.points[:3, :], camera_intrinsic, normalize=True, device=DEVICE)  # :590
+    image_mask = maskarr_1
+    masked_pixels = (image_mask == 1)
+    points_within_image = torch.logical_and(torch.logical_and(torch.logical_and(torch.logical_and(
+        depths > min_dist, points[0] > 0), points[0] < image_mask.shape[0] - 1), points[1] > 0),
+        points[1] < image_mask.shape[1] - 1)                                  # :597-603
+    floored_points = torch.floor(points[:, points_within_image]).to(dtype=int)   # :605
+    track_points = track_points[points_within_image.cpu()]                    # :606
+    points_within_mask = torch.logical_and(floored_points, masked_pixels[floored_points[0], floored_points[1]])   # :608-611
+    indices_within_mask = torch.where(torch.logical_and(torch.logical_and(
+        points_within_mask[0, :], points_within_mask[1, :]), points_within_mask[2, :]))[0]   # :613
+    track_points = track_points[indices_within_mask.cpu()]                    # :617
+    uvd = torch.stack([points[0], points[1], depths]).T.contiguous().numpy()
+    return np.asarray(track_points, np.int32).reshape(-1), uvd
+
+
+def pyquaternion_from_rz(yaw_f32):
+    """What `Quaternion(matrix=align_mat)` holds for align_mat = Rz(lane_yaw) built at
+    2d_to_3d.py:788-789 (np.cos/np.sin of a float32 are float32).  pyquaternion 0.9.9 is not
+    installed here; this is its trace method on M^T, restated."""
+    c, s = float(np.cos(np.float32(yaw_f32))), float(np.sin(np.float32(yaw_f32)))
+    if c < -c:
+        t = 1.0 - c - c + 1.0
+        q = np.array([2 * s, 0.0, 0.0, t]) * (0.5 / np.sqrt(t))
+    else:
+        t = 1.0 + c + c + 1.0
+        q = np.array([t, 0.0, 0.0, 2 * s]) * (0.5 / np.sqrt(t))
+    return q
+
+
+def main():
+    pcd, ref = _load_reference()
+    rng = np.random.default_rng(20240101)
+    report = {}
+
+    # ---------------- G1: translate / rotate / view_points, bit-exact float32
+    cfg = syn.config("tiny")
+    fr = syn.make_frame(cfg, 3)
+    pts = np.concatenate([orc.sweep_prep(r, x[0:9], x[9:12], x[12:21], x[21:24]) for r, x in zip(fr.sweeps_raw, fr.sweep_xf)], 0)
+    pts = pts[rng.choice(pts.shape[0], 4096, replace=False)]
+    g1_uvd = []
+    for c in range(fr.cams.shape[0]):
+        _, uvd = reference_mask_body(pcd, pts, fr.cams[c], np.ones((cfg.height, cfg.width), np.uint8))
+        g1_uvd.append(uvd)
+        mine = orc.project_points(pts, fr.cams[c])
+        both_nan = np.isnan(mine) & np.isnan(uvd)
+        report[f"G1 cam{c} mismatches"] = int((~both_nan & (mine.view(np.uint32) != uvd.view(np.uint32))).sum())
+    # a single-stage (Waymo-style) camera too
+    cam1 = geo.single_stage_cam_record(fr.cams[0][0:3], fr.cams[0][3:12], fr.cams[0][24:33])
+    _, uvd1 = reference_mask_body(pcd, pts, cam1, np.ones((cfg.height, cfg.width), np.uint8))
+    np.savez_compressed(os.path.join(HERE, "g1_project.npz"), pts=pts, cams=fr.cams, uvd=np.stack(g1_uvd), cam1=cam1, uvd1=uvd1)
+
+    # ---------------- G2: index lists of whole frames + crafted boundary points
+    g2 = {}
+    n_mis = 0
+    for k, idx in enumerate([0, 1]):
+        f = syn.make_frame(cfg, idx)
+        P = np.concatenate([orc.sweep_prep(r, x[0:9], x[9:12], x[12:21], x[21:24]) for r, x in zip(f.sweeps_raw, f.sweep_xf)], 0)
+        # crafted points: pixel coordinates near 0, 1, W-1, H-1 and depth near min_dist, back-projected to global
+        extra = []
+        for c in range(f.cams.shape[0]):
+            cam = f.cams[c].astype(np.float64)
+            R1, R2, t1, t2, K = cam[3:12].reshape(3, 3), cam[15:24].reshape(3, 3), cam[0:3], cam[12:15], cam[24:33].reshape(3, 3)
+            for _ in range(160):
+                u = rng.choice([0.0, 1.0, cfg.width - 1.0, rng.uniform(0, cfg.width)]) + rng.normal() * 1e-3
+                v = rng.choice([0.0, 1.0, cfg.height - 1.0, rng.uniform(0, cfg.height)]) + rng.normal() * 1e-3
+                z = rng.choice([2.3, rng.uniform(2.0, 40.0)]) + rng.normal() * 1e-6
+                pc = np.array([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z])
+                pg = R1.T @ (R2.T @ pc - t2) - t1
+                extra.append([pg[0], pg[1], pg[2], 1.0])
+        P = np.concatenate([P, np.array(extra, np.float32)], 0)
+        masks = [rlemod.counts_to_dense(rlemod.string_to_counts(r["counts"]), f.width, f.height) for r in f.rles]
+        masks[0] = np.ones_like(masks[0])                      # a full-frame mask: every in-image point
+        lists = []
+        for m, c in zip(masks, f.cam_nums):
+            er = orc.erode3x3(m)
+            tp, _ = reference_mask_body(pcd, P, f.cams[c], er)
+            mine = orc.points_in_mask(P, f.cams[c], er)
+            n_mis += int(not np.array_equal(tp, mine))
+            lists.append(tp)
+        g2[f"pts{k}"] = P
+        g2[f"cams{k}"] = f.cams
+        g2[f"cam_nums{k}"] = np.array(f.cam_nums, np.int32)
+        g2[f"rle_counts{k}"] = np.concatenate([rlemod.dense_to_counts(m) for m in masks])
+        g2[f"rle_off{k}"] = np.concatenate([[0], np.cumsum([rlemod.dense_to_counts(m).size for m in masks])]).astype(np.int32)
+        g2[f"idx{k}"] = np.concatenate(lists) if lists else np.zeros(0, np.int32)
+        g2[f"idx_off{k}"] = np.concatenate([[0], np.cumsum([l.size for l in lists])]).astype(np.int32)
+    g2["wh"] = np.array([cfg.width, cfg.height], np.int32)
+    report["G2 index-list mismatches (oracle vs reference body)"] = n_mis
+    report["G2 total in-mask points"] = int(g2["idx0"].size + g2["idx1"].size)
+    np.savez_compressed(os.path.join(HERE, "g2_index_lists.npz"), **g2)
+
+    # ---------------- G3: get_medoid
+    g3 = {}
+    cases = []
+    for M in [1, 2, 3, 17, 25, 26, 27, 64, 100, 300, 1000, 2000]:
+        for tag, off in [("local", np.zeros(3)), ("global", np.array([612.3, 1587.9, 1.7]))]:
+            p = (rng.normal(size=(M, 3)) * [4.0, 4.0, 0.6] + off).astype(np.float32)
+            j_ref = int(ref.get_medoid(torch.from_numpy(p.T.copy())))
+            P4 = np.concatenate([p, np.zeros((M, 1), np.float32)], 1)
+            j_orc, cs = orc.medoid(P4, np.arange(M), want_colsum=True)
+            srt = np.sort(cs)
+            margin = float((srt[1] - srt[0]) / srt[0]) if M > 1 and srt[0] > 0 else float("inf")
+            name = f"M{M}_{tag}"
+            g3[name] = p
+            cases.append({"name": name, "M": M, "ref_index": j_ref, "oracle_index": j_orc, "rel_margin": margin})
+    report["G3 medoid index mismatches"] = int(sum(c["ref_index"] != c["oracle_index"] for c in cases))
+    np.savez_compressed(os.path.join(HERE, "g3_medoid.npz"), **g3)
+    json.dump(cases, open(os.path.join(HERE, "g3_medoid.json"), "w"), indent=1)
+
+    # ---------------- G4: push_centroid
+    g4 = []
+    priors = orc.PRIORS_WLH
+    worst = 0.0
+    for i in range(240):
+        cls = int(rng.integers(0, len(orc.CLASSES)))
+        yaw = np.float32(rng.uniform(-np.pi, np.pi)) if i % 7 else np.float32([0.0, np.pi / 2, -np.pi / 2, np.pi][i % 4])
+        ego = np.array([600.0 + rng.uniform(-50, 50), 1600.0 + rng.uniform(-50, 50), rng.uniform(0, 2)])
+        d = rng.uniform(3, 60)
+        a = rng.uniform(-np.pi, np.pi)
+        cen = (ego + [d * np.cos(a), d * np.sin(a), rng.uniform(-1, 2)]).astype(np.float32)
+        if i % 31 == 0:
+            cen[1] = np.float32(ego[1])      # ey ~ 0
+        q = pyquaternion_from_rz(yaw)
+        pushed = ref.push_centroid(cen.copy(), list(priors[cls]), list(q), {"translation": list(ego)})
+        t, qo = orc.box_assemble(cen, priors[cls], yaw, ego, True)
+        worst = max(worst, float(np.abs(t - pushed).max()), float(np.abs(qo - q).max()))
+        g4.append({"centroid": [float(v) for v in cen], "class": cls, "yaw": float(yaw), "ego": list(map(float, ego)),
+                   "pushed": [float(v) for v in pushed], "quat_wxyz": [float(v) for v in q]})
+    report["G4 push_centroid max |oracle - reference|"] = worst
+    json.dump(g4, open(os.path.join(HERE, "g4_push_centroid.json"), "w"))
+
+    # ---------------- G5: circle_nms (distinct scores -> no tie ambiguity) + pinned tie fixture
+    g5 = []
+    names = orc.CLASSES
+    thr = {n: float(t) for n, t in zip(names, orc.NMS_THR)}
+    bad = 0
+    for i in range(40):
+        n = int(rng.integers(1, 60))
+        centers = rng.uniform(0, 12, size=(max(1, n // 3), 2))
+        xy = centers[rng.integers(0, centers.shape[0], n)] + rng.normal(scale=0.6, size=(n, 2))
+        scores = rng.permutation(np.arange(1, n + 1) / (n + 1.0))                 # all distinct
+        labels = [names[int(k)] for k in rng.integers(0, 4 if i % 2 else len(names), n)]
+        dets = np.concatenate([xy, scores[:, None]], 1)
+        keep = sorted(int(k) for k in ref.circle_nms(dets, labels, thr))
+        mine = np.flatnonzero(orc.circle_nms(xy[:, 0], xy[:, 1], scores, [names.index(l) for l in labels], orc.NMS_THR)).tolist()
+        bad += int(keep != mine)
+        g5.append({"xy": xy.tolist(), "scores": scores.tolist(), "labels": labels, "keep": keep})
+    report["G5 circle_nms mismatches"] = bad
+    # ties: scores rounded to 2 decimals; expectation = the pinned tie-break (descending score, then descending index)
+    n = 30
+    xy = rng.normal(scale=1.0, size=(n, 2))
+    scores = np.round(rng.uniform(0.3, 0.5, n), 2)
+    labels = ["car"] * n
+    keep = np.flatnonzero(orc.circle_nms(xy[:, 0], xy[:, 1], scores, [0] * n, orc.NMS_THR)).tolist()
+    json.dump({"reference_cases": g5, "tie_case_pinned": {"xy": xy.tolist(), "scores": scores.tolist(), "labels": labels, "keep": keep}},
+              open(os.path.join(HERE, "g5_circle_nms.json"), "w"))
+
+    # ---------------- G6: lane_yaws_distances_and_coords
+    lane = syn.make_lane_table([600.0, 1600.0], 6000, seed=5)
+    cent = np.stack([600 + rng.uniform(-150, 150, 300), 1600 + rng.uniform(-150, 150, 300), rng.uniform(0, 3, 300)], 1).astype(np.float32)
+    # duplicates in the lane table exercise the first-minimum rule
+    lane[100] = lane[50]
+    lane[3000] = lane[2999]
+    yaws, dists, coords = ref.lane_yaws_distances_and_coords(cent.tolist(), lane.tolist())
+    j, d = orc.lane_nn(cent, lane)
+    lane32 = lane.astype(np.float32)
+    report["G6 lane NN mismatches"] = int((lane32[j, 2] != yaws).sum() + (d != dists).sum())
+    np.savez_compressed(os.path.join(HERE, "g6_lane_nn.npz"), lane=lane, centroids=cent, yaws=np.asarray(yaws), dists=np.asarray(dists),
+                        coords=np.asarray(coords), oracle_idx=j)
+
+    # ---------------- small helpers of the reference
+    report["get_detection_name"] = {k: ref.get_detection_name(k) for k in ["trafficcone", "constructionvehicle", "human", "car"]}
+    json.dump(report, open(os.path.join(HERE, "gen_report.json"), "w"), indent=1)
+    print(json.dumps(report, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+"""CPU: host-side logic of the product path (no kernels run here)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cm3d_amd import geometry as geo, rle, synthetic as syn
+
+
+def test_rle_codec_matches_oracle_codec(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(30):
+        H, W = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        img = (rng.uniform(size=(H, W)) < rng.uniform(0.05, 0.9)).astype(np.uint8)
+        if rng.uniform() < 0.2:
+            img[:] = rng.integers(0, 2)
+        cnts = rle.dense_to_counts(img)
+        assert int(cnts.sum()) == H * W
+        s = rle.counts_to_string(cnts)
+        ref = oracle.rle_encode(img.T)           # the producer encodes the (W,H) transpose, F-ordered
+        assert ref["size"] == [W, H] and ref["counts"] == s
+        assert np.array_equal(rle.string_to_counts(s), cnts)
+        assert np.array_equal(rle.counts_to_dense(cnts, W, H), img)
+        assert np.array_equal(oracle.rle_decode({"size": [W, H], "counts": s}).T, img)
+
+
+def test_rle_large_runs_and_negative_deltas():
+    cnts = np.array([0, 5, 1000000, 3, 7, 2000000, 1, 1], np.uint32)
+    s = rle.counts_to_string(cnts)
+    assert np.array_equal(rle.string_to_counts(s), cnts)
+    assert rle.string_to_counts(b"").size == 0
+    with pytest.raises(ValueError):
+        rle.string_to_counts(b"P")          # continuation bit (0x20) set on the last character
+
+
+def test_spans_to_counts_equals_dense():
+    rng = np.random.default_rng(1)
+    W, H = 64, 20
+    rows = np.arange(3, 15)
+    x0 = rng.integers(0, 30, rows.size)
+    x1 = x0 + rng.integers(0, 34, rows.size)
+    x0[2], x1[2] = 0, W - 1            # a full row
+    x1[5] = W - 1
+    x0[6] = 0                          # touches the previous span in linear order
+    img = np.zeros((H, W), np.uint8)
+    for y, a, b in zip(rows, x0, x1):
+        img[y, a:b + 1] = 1
+    assert np.array_equal(rle.spans_to_counts(rows, x0, x1, W, H), rle.dense_to_counts(img))
+    assert np.array_equal(rle.spans_to_counts([], [], [], W, H), [W * H])
+
+
+def test_quaternion_helpers():
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        q = rng.normal(size=4)
+        R = geo.quat_to_rotmat(q)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and np.isclose(np.linalg.det(R), 1.0)
+        q2 = geo.rotmat_to_quat(R)
+        assert np.allclose(geo.quat_to_rotmat(q2), R, atol=1e-12)
+    assert np.allclose(geo.quat_to_rotmat([1, 0, 0, 0]), np.eye(3))
+    assert np.allclose(geo.quat_to_rotmat([np.cos(0.3), 0, 0, np.sin(0.3)]), geo.rot_z(0.6))
+
+
+def test_scaled_intrinsic_is_float32_product():
+    K = np.array([[1266.417203046554, 0.0, 816.2670197447984], [0.0, 1266.417203046554, 491.50706579294757], [0, 0, 1.0]])
+    Ks = geo.scaled_intrinsic_f32(K, 0.64)
+    assert Ks.dtype == np.float32 and Ks[2, 2] == 1.0
+    assert Ks[0, 0] == np.float32(np.float32(K[0, 0]) * np.float32(0.64))
+
+
+def test_synthetic_is_deterministic_and_well_formed():
+    cfg = syn.config("tiny")
+    a, b = syn.make_frame(cfg, 7), syn.make_frame(cfg, 7)
+    assert all(np.array_equal(x, y) for x, y in zip(a.sweeps_raw, b.sweeps_raw))
+    assert [r["counts"] for r in a.rles] == [r["counts"] for r in b.rles]
+    assert len(a.rles) == len(a.labels) == len(a.scores) == len(a.cam_nums) == cfg.n_masks
+    assert all(r["size"] == [cfg.width, cfg.height] for r in a.rles)
+    assert all(0 <= c < cfg.n_cams for c in a.cam_nums)
+    assert a.sweeps_raw[0].shape == (cfg.n_points, 5) and a.sweeps_raw[0].dtype == np.float32
+
+
+def test_pack_frames_layout_and_validation():
+    from cm3d_amd import lifting
+    cfg = syn.config("tiny")
+    frames = [syn.make_frame(cfg, i) for i in range(3)]
+    lanes = [syn.make_lane_table([600, 1600], 500, seed=0)]
+    hb = lifting.pack_frames(frames, lanes, [0, 0, 0])
+    assert hb.n_frames == 3 and hb.n_masks == 3 * cfg.n_masks
+    assert hb.sweep_row_off[-1] == sum(r.shape[0] for f in frames for r in f.sweeps_raw)
+    assert np.array_equal(hb.mask_frame, np.repeat(np.arange(3), cfg.n_masks))
+    assert hb.lane.dtype == np.float32 and hb.lane_off.tolist() == [0, 500]
+    # labels are renamed like get_detection_name and mapped to the class table
+    names = lifting.ClassTable.nuscenes().names
+    assert [names[c] for c in hb.class_id[:cfg.n_masks]] == [lifting.get_detection_name(l) for l in frames[0].labels]
+    bad = syn.make_frame(cfg, 0)
+    bad.labels[0] = "unicorn"
+    with pytest.raises(ValueError):
+        lifting.pack_frames([bad], lanes, [0])
+    bad2 = syn.make_frame(cfg, 0)
+    bad2.rles[0] = {"size": [cfg.width, cfg.height], "counts": rle.counts_to_string(np.array([5], np.uint32))}
+    with pytest.raises(ValueError):
+        lifting.pack_frames([bad2], lanes, [0])
+
+
+def test_reference_tables():
+    from cm3d_amd import lifting
+    assert lifting.get_detection_name("trafficcone") == "traffic_cone"
+    assert lifting.get_detection_name("constructionvehicle") == "construction_vehicle"
+    assert lifting.get_detection_name("human") == "pedestrian"
+    assert lifting.get_detection_name("car") == "car"
+    ct = lifting.ClassTable.nuscenes()
+    assert ct.prior_wlh[ct.index("bus")].tolist() == [2.5, 12.0, 4.0]
+    assert ct.nms_thr[ct.index("pedestrian")] == 0.175 and ct.is_vehicle[ct.index("barrier")] == 1
+    assert ct.is_vehicle[ct.index("bicycle")] == 0
+    assert set(lifting.ATTRIBUTE_NAMES) == set(ct.names)
+
+
+def test_box_records_schema():
+    from cm3d_amd import lifting
+    cfg = syn.config("tiny")
+    frames = [syn.make_frame(cfg, i) for i in range(2)]
+    hb = lifting.pack_frames(frames, [syn.make_lane_table([600, 1600], 100, seed=0)], [0, 0])
+    M = hb.n_masks
+    res = {"flags": np.zeros(M, np.int32), "box": np.zeros((M, 10))}
+    res["flags"][[1, 3]] = 3
+    res["flags"][2] = 1              # has a box but was suppressed
+    res["box"][1] = [1, 2, 3, 0.5, 0.5, 0, 0, 0, 0, 3]
+    out = lifting.box_records(hb, res)
+    assert list(out) == hb.tokens and out[hb.tokens[1]] == []
+    b = out[hb.tokens[0]]
+    assert len(b) == 2 and b[0]["translation"] == [1.0, 2.0, 3.0] and b[0]["rotation"] == [0.5, 0.0, 0.0, 0.5]
+    assert set(b[0]) == {"sample_token", "translation", "size", "rotation", "velocity", "detection_name",
+                         "detection_score", "attribute_name"}
+    json.dumps(out)
+
+
+def test_shard_helpers():
+    from cm3d_amd import dist
+    for n, w in [(10, 4), (3, 8), (28130, 8), (1, 1)]:
+        r = [dist.shard_range(n, k, w) for k in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    sizes = [40, 41, 39, 40, 38, 40, 41, 40, 39, 40, 40]
+    b = dist.shard_scenes(sizes, 4)
+    assert b[0][0] == 0 and b[-1][1] == len(sizes) and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    loads = [sum(sizes[a:c]) for a, c in b]
+    assert max(loads) <= 1.5 * sum(sizes) / 4
