@@ -1,0 +1,201 @@
+"""Dataset-side I/O of the nuScenes entry point: the on-disk contract of the reference
+(src/nuscenes/2d_to_3d.py:55-59,382-503,929-930 and gen_2d_masks_detic.py:497-506).
+
+* `NuscTables` reads the nuScenes JSON tables directly (scene, sample, sample_data, ego_pose,
+  calibrated_sensor, sensor, log); nuscenes-devkit is used when importable, but is not needed
+  for the tables.
+* lane centre-lines: `NuScenesMap.discretize_lanes(..., 0.5)` when the devkit is installed
+  (2d_to_3d.py:228-240), otherwise a pre-discretised `<dataroot>/lanes/<location>.npy` (x,y,yaw).
+* `frames_of_scene` assembles the per-frame kernel inputs (sweeps + transforms, camera records,
+  RLE masks, labels) exactly as the reference gathers them at :422-503.
+* `write_synthetic_dataset` lays a synthetic scene out in that same on-disk form, so the entry point
+  can be exercised end to end without the real dataset.
+"""
+import json
+import os
+import pickle
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import geometry as geo
+from . import synthetic as syn
+
+CAM_LIST = ["CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_BACK_RIGHT", "CAM_BACK", "CAM_BACK_LEFT", "CAM_FRONT_LEFT"]
+TABLES = ["scene", "sample", "sample_data", "ego_pose", "calibrated_sensor", "sensor", "log"]
+
+
+class NuscTables:
+    def __init__(self, version, dataroot):
+        self.version, self.dataroot = version, dataroot
+        base = os.path.join(dataroot, version)
+        self.t = {}
+        for name in TABLES:
+            with open(os.path.join(base, name + ".json")) as f:
+                rows = json.load(f)
+            self.t[name] = {r["token"]: r for r in rows}
+        sensors = self.t["sensor"]
+        cs = self.t["calibrated_sensor"]
+        # sample['data'][channel] like the devkit builds it: key frames only
+        self.sample_data_of = {tok: {} for tok in self.t["sample"]}
+        for sd in self.t["sample_data"].values():
+            if sd.get("is_key_frame", False):
+                ch = sensors[cs[sd["calibrated_sensor_token"]]["sensor_token"]]["channel"]
+                self.sample_data_of[sd["sample_token"]][ch] = sd["token"]
+
+    def get(self, table, token):
+        return self.t[table][token]
+
+    def scenes(self):
+        return sorted(self.t["scene"].values(), key=lambda s: s["name"])
+
+    def scene_by_name(self, name):
+        for s in self.t["scene"].values():
+            if s["name"] == name:
+                return s
+        raise KeyError(name)
+
+    def samples_of_scene(self, scene):
+        out, tok = [], scene["first_sample_token"]
+        while tok != "":
+            s = self.get("sample", tok)
+            out.append(s)
+            tok = s["next"]
+        return out
+
+    def location(self, scene):
+        return self.get("log", scene["log_token"])["location"]
+
+
+def load_lane_points(dataroot, location):
+    """(L,3) float64 rows x, y, yaw of all lanes + lane connectors, discretised at 0.5 m."""
+    try:
+        from nuscenes.map_expansion.map_api import NuScenesMap   # third-party, optional
+        nusc_map = NuScenesMap(dataroot=dataroot, map_name=location)
+        records = nusc_map.lane + nusc_map.lane_connector
+        poses = nusc_map.discretize_lanes([r["token"] for r in records], 0.5)
+        pts = [p for lane in poses.values() for p in lane]
+        return np.asarray(pts, np.float64).reshape(-1, 3)
+    except ImportError:
+        path = os.path.join(dataroot, "lanes", location + ".npy")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"nuscenes-devkit is not installed and {path} does not exist")
+        return np.load(path).astype(np.float64).reshape(-1, 3)
+
+
+def frames_of_scene(tables: NuscTables, scene, mask_dir, n_sweeps=3, ratio=0.64, missing_ok=False):
+    """Kernel inputs of every frame of a scene (reference :415-503)."""
+    frames = []
+    for frame_num, sample in enumerate(tables.samples_of_scene(scene)):
+        mp = os.path.join(mask_dir, scene["name"], f"{frame_num}_masks.pkl")
+        dp = os.path.join(mask_dir, scene["name"], f"{frame_num}_data.json")
+        if not (os.path.exists(mp) and os.path.exists(dp)):
+            if missing_ok:       # the producer writes no files for frames without detections (gen_2d_masks_detic.py:490-491)
+                rles, data = [], {"labels": [], "detection_scores": [], "cam_nums": []}
+            else:
+                raise FileNotFoundError(mp)
+        else:
+            with open(mp, "rb") as f:
+                rles = pickle.load(f)
+            with open(dp) as f:
+                data = json.load(f)
+        # sweeps: the key frame's LIDAR_TOP sample_data and its `next` chain (:433-463)
+        sd = tables.get("sample_data", tables.sample_data_of[sample["token"]]["LIDAR_TOP"])
+        key_pose = tables.get("ego_pose", sd["ego_pose_token"])
+        raws, xfs = [], []
+        for _ in range(n_sweeps):
+            scan = np.fromfile(os.path.join(tables.dataroot, sd["filename"]), dtype=np.float32).reshape(-1, 5)
+            cs = tables.get("calibrated_sensor", sd["calibrated_sensor_token"])
+            pose = tables.get("ego_pose", sd["ego_pose_token"])
+            raws.append(scan)
+            xfs.append(geo.sweep_xf_record(cs["translation"], cs["rotation"], pose["translation"], pose["rotation"]))
+            if sd.get("next", "") == "":
+                break
+            sd = tables.get("sample_data", sd["next"])
+        cams = []
+        for ch in CAM_LIST:
+            csd = tables.get("sample_data", tables.sample_data_of[sample["token"]][ch])
+            pose = tables.get("ego_pose", csd["ego_pose_token"])
+            cs = tables.get("calibrated_sensor", csd["calibrated_sensor_token"])
+            cams.append(geo.nusc_cam_record(pose["translation"], pose["rotation"], cs["translation"], cs["rotation"],
+                                            cs["camera_intrinsic"], ratio))
+        if rles:
+            W, H = rles[0]["size"]
+        else:
+            W, H = int(1600 * ratio), int(900 * ratio)
+        frames.append(SimpleNamespace(
+            token=sample["token"], sweeps_raw=raws, sweep_xf=np.stack(xfs), cams=np.stack(cams), rles=list(rles),
+            labels=list(data["labels"]), scores=list(data["detection_scores"]), cam_nums=list(data["cam_nums"]),
+            ego_xyz=np.asarray(key_pose["translation"], np.float64), width=int(W), height=int(H)))
+    return frames
+
+
+# --------------------------------------------------------------------------- synthetic dataset on disk
+def write_synthetic_dataset(root, cfg: syn.SyntheticConfig, n_scenes=2, frames_per_scene=4, version="v1.0-synth",
+                            mask_subdir="mask_outputs/nuscenes-detic", lane_points=4000):
+    """Writes `<root>/data/nuScenes/{<version>/*.json, sweeps/..., lanes/<loc>.npy}` and
+    `<root>/<mask_subdir>/<scene>/<f>_{masks.pkl,data.json}` from synthetic frames.
+    Returns (dataroot, mask_dir, scene_names)."""
+    dataroot = os.path.join(root, "data", "nuScenes")
+    mask_dir = os.path.join(root, mask_subdir)
+    os.makedirs(os.path.join(dataroot, version), exist_ok=True)
+    os.makedirs(os.path.join(dataroot, "sweeps", "LIDAR_TOP"), exist_ok=True)
+    os.makedirs(os.path.join(dataroot, "lanes"), exist_ok=True)
+    tabs = {k: [] for k in TABLES}
+    tok = lambda kind, *a: f"{kind}-" + "-".join(str(x) for x in a)
+    for ch in ["LIDAR_TOP"] + CAM_LIST:
+        tabs["sensor"].append({"token": tok("sensor", ch), "channel": ch, "modality": "lidar" if ch == "LIDAR_TOP" else "camera"})
+    names = []
+    for s in range(n_scenes):
+        name = f"scene-{9000 + s:04d}"
+        names.append(name)
+        loc = f"synthtown-{s}"
+        tabs["log"].append({"token": tok("log", s), "location": loc})
+        os.makedirs(os.path.join(mask_dir, name), exist_ok=True)
+        first_center = None
+        sample_tokens = [tok("sample", s, f) for f in range(frames_per_scene)]
+        for f in range(frames_per_scene):
+            fr = syn.make_frame(cfg, s * 1000 + f)
+            if first_center is None:
+                first_center = fr.ego_xyz[:2].copy()
+            st = sample_tokens[f]
+            tabs["sample"].append({"token": st, "scene_token": tok("scene", s), "timestamp": f,
+                                   "prev": sample_tokens[f - 1] if f else "", "next": sample_tokens[f + 1] if f + 1 < frames_per_scene else ""})
+            # lidar sweeps: a `next`-linked chain, the first one is the key frame
+            for k, (raw, xf) in enumerate(zip(fr.sweeps_raw, fr.sweep_xf)):
+                fn = os.path.join("sweeps", "LIDAR_TOP", f"{name}_{f}_{k}.bin")
+                raw.astype(np.float32).tofile(os.path.join(dataroot, fn))
+                cst, ept = tok("cs", s, f, "L", k), tok("pose", s, f, "L", k)
+                Rcs, tcs = xf[0:9].reshape(3, 3).astype(np.float64), xf[9:12].astype(np.float64)
+                Reg, teg = xf[12:21].reshape(3, 3).astype(np.float64), xf[21:24].astype(np.float64)
+                tabs["calibrated_sensor"].append({"token": cst, "sensor_token": tok("sensor", "LIDAR_TOP"),
+                                                  "translation": tcs.tolist(), "rotation": geo.rotmat_to_quat(Rcs).tolist(), "camera_intrinsic": []})
+                tabs["ego_pose"].append({"token": ept, "translation": teg.tolist() if k else fr.ego_xyz.tolist(),
+                                         "rotation": geo.rotmat_to_quat(Reg).tolist()})
+                tabs["sample_data"].append({"token": tok("sd", s, f, "L", k), "sample_token": st, "ego_pose_token": ept,
+                                            "calibrated_sensor_token": cst, "filename": fn, "is_key_frame": k == 0,
+                                            "next": tok("sd", s, f, "L", k + 1) if k + 1 < len(fr.sweeps_raw) else "", "prev": ""})
+            for c, ch in enumerate(CAM_LIST[: fr.cams.shape[0]]):
+                cam = fr.cams[c].astype(np.float64)
+                cst, ept = tok("cs", s, f, ch), tok("pose", s, f, ch)
+                # invert the record: t1 = -t_ego, R1 = R_ego^T, t2 = -t_cs, R2 = R_cs^T, K' = K*ratio
+                K = cam[24:33].reshape(3, 3) / cfg.ratio
+                K[2, 2] = 1.0
+                tabs["calibrated_sensor"].append({"token": cst, "sensor_token": tok("sensor", ch), "translation": (-cam[12:15]).tolist(),
+                                                  "rotation": geo.rotmat_to_quat(cam[15:24].reshape(3, 3).T).tolist(), "camera_intrinsic": K.tolist()})
+                tabs["ego_pose"].append({"token": ept, "translation": (-cam[0:3]).tolist(),
+                                         "rotation": geo.rotmat_to_quat(cam[3:12].reshape(3, 3).T).tolist()})
+                tabs["sample_data"].append({"token": tok("sd", s, f, ch), "sample_token": st, "ego_pose_token": ept,
+                                            "calibrated_sensor_token": cst, "filename": f"samples/{ch}/{name}_{f}.jpg",
+                                            "is_key_frame": True, "next": "", "prev": ""})
+            with open(os.path.join(mask_dir, name, f"{f}_masks.pkl"), "wb") as fh:
+                pickle.dump(fr.rles, fh)
+            with open(os.path.join(mask_dir, name, f"{f}_data.json"), "w") as fh:
+                json.dump({"labels": fr.labels, "detection_scores": fr.scores, "cam_nums": fr.cam_nums}, fh)
+        tabs["scene"].append({"token": tok("scene", s), "name": name, "log_token": tok("log", s),
+                              "first_sample_token": sample_tokens[0], "nbr_samples": frames_per_scene})
+        np.save(os.path.join(dataroot, "lanes", loc + ".npy"), syn.make_lane_table(first_center, lane_points, seed=100 + s))
+    for k, rows in tabs.items():
+        with open(os.path.join(dataroot, version, k + ".json"), "w") as fh:
+            json.dump(rows, fh)
+    return dataroot, mask_dir, names

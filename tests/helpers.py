@@ -43,3 +43,20 @@ def oracle_batch(orc, frames, lane_tables, frame_lane, hb):
                 medoid_pos=np.concatenate(medoid_pos), centroid=np.concatenate(centroid, 0).astype(np.float32),
                 lane_idx=np.concatenate(lane_idx), lane_dist=np.concatenate(lane_dist), box=np.concatenate(box, 0),
                 flags=np.concatenate(flags), bbox=np.array(bbox, np.int32))
+
+
+def oracle_results(orc, frames, lane_tables, frame_lane, classes=None):
+    """End-to-end oracle: frames -> {token: [box dict]} like lifting.box_records, through the
+    reference-order oracle (stage 1, stage 2, NMS)."""
+    from cm3d_amd import lifting
+    classes = classes or lifting.ClassTable.nuscenes()
+    live = [i for i, f in enumerate(frames) if len(f.rles) > 0]
+    out = {f.token: [] for f in frames}
+    if not live:
+        return out
+    sub = [frames[i] for i in live]
+    fl = [frame_lane[i] for i in live]
+    hb = lifting.pack_frames(sub, lane_tables, fl, classes)
+    exp = oracle_batch(orc, sub, lane_tables, fl, hb)
+    out.update(lifting.box_records(hb, exp, classes))
+    return out
