@@ -6,12 +6,12 @@
 #include "common.h"
 
 #define LN_THREADS 256
-#define LN_SLICES 32
+#define LN_SLICES 128
 #define LN_TILE 512
 
-// Candidate update shared by both paths.  Reference: d = sqrt(dx*dx+dy*dy), first minimum of d.
-// sqrt is monotone, so a candidate with d2 >= d2cut (the d2 of the current best) cannot have a
-// strictly smaller sqrt and is skipped without evaluating it.
+// Reference: d = sqrt(dx*dx+dy*dy) per pair, first minimum of d (np.argmin).
+// Exact slow form: sqrt is monotone, so a candidate with d2 >= d2cut (the d2 of the current best)
+// cannot have a strictly smaller sqrt and is skipped without evaluating it.
 static __device__ __forceinline__ void ln_update(double d2, int j, double &d2cut, double &sbest, int &jbest)
 {
     if (d2 < d2cut) {
@@ -19,6 +19,14 @@ static __device__ __forceinline__ void ln_update(double d2, int j, double &d2cut
         if (s < sbest) { sbest = s; jbest = j; d2cut = d2; }
     }
 }
+
+// Fast form used in the inner loop: compare squared distances only (branch-free selects) and
+// remember whether a NEAR-TIE was seen, i.e. a later candidate whose d2 is smaller than the
+// running best by less than 1e-15 relative -- the only situation in which sqrt() could round both
+// to the same double and the reference would keep the earlier index.  Such a (centroid, slice)
+// is redone with the exact form.  (d2 smaller by more than 1e-15 relative => sqrt differs by
+// more than 2 ulp => strictly smaller; d2 >= best => sqrt >= best: no switch either way.)
+#define LN_NEAR (1.0 - 1e-15)
 
 // grid (ceil(n_masks/256), LN_SLICES): thread = one centroid, block.y = one slice of its lane table
 __global__ __launch_bounds__(LN_THREADS) void k_lane_nn(const float *__restrict__ centroid,
@@ -44,7 +52,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_lane_nn(const float *__restrict_
     if (s_tb == -2) return;                      // no centroid in this block
     double cx = 0.0, cy = 0.0;
     if (act) { cx = (double)centroid[3 * k]; cy = (double)centroid[3 * k + 1]; }
-    double d2cut = INFINITY, sbest = INFINITY;
+    double sbest = INFINITY;
     int jbest = 0;
     if (s_uni) {
         // every centroid of the block uses the same table: stage it through LDS
@@ -52,6 +60,8 @@ __global__ __launch_bounds__(LN_THREADS) void k_lane_nn(const float *__restrict_
         const int lo = lane_off[tbu], L = lane_off[tbu + 1] - lo;
         const int chunk = (L + LN_SLICES - 1) / LN_SLICES;
         const int j0 = slice * chunk, j1 = min(L, j0 + chunk);
+        double d2best = INFINITY, near_thr = INFINITY;
+        bool amb = false;
         for (int t0 = j0; t0 < j1; t0 += LN_TILE) {
             __syncthreads();
             for (int q = threadIdx.x; q < LN_TILE && t0 + q < j1; q += LN_THREADS) {
@@ -60,19 +70,34 @@ __global__ __launch_bounds__(LN_THREADS) void k_lane_nn(const float *__restrict_
             }
             __syncthreads();
             const int cnt = min(LN_TILE, j1 - t0);
-            if (act) {
-#pragma unroll 4
-                for (int q = 0; q < cnt; ++q) {
-                    const double2 lp = s_lane[q];
-                    const double dx = cx - lp.x, dy = cy - lp.y;
-                    ln_update(dx * dx + dy * dy, t0 + q, d2cut, sbest, jbest);
-                }
+#pragma unroll 8
+            for (int q = 0; q < cnt; ++q) {
+                const double2 lp = s_lane[q];
+                const double dx = cx - lp.x, dy = cy - lp.y;
+                const double d2 = dx * dx + dy * dy;
+                const bool better = d2 < d2best;
+                amb = amb || (better && d2 > near_thr);
+                near_thr = better ? d2 * LN_NEAR : near_thr;
+                jbest = better ? t0 + q : jbest;
+                d2best = better ? d2 : d2best;
             }
         }
+        sbest = sqrt(d2best);
+        if (amb && act) {           // near-tie seen: redo this slice exactly (practically never taken)
+            double d2cut = INFINITY;
+            sbest = INFINITY; jbest = 0;
+            for (int j = j0; j < j1; ++j) {
+                const float *lp = lane + (size_t)(lo + j) * 3;
+                const double dx = cx - (double)lp[0], dy = cy - (double)lp[1];
+                ln_update(dx * dx + dy * dy, j, d2cut, sbest, jbest);
+            }
+        }
+        if (j1 <= j0) { sbest = INFINITY; jbest = 0; }
     } else if (act) {
         const int lo = lane_off[tb], L = lane_off[tb + 1] - lo;
         const int chunk = (L + LN_SLICES - 1) / LN_SLICES;
         const int j0 = slice * chunk, j1 = min(L, j0 + chunk);
+        double d2cut = INFINITY;
         for (int j = j0; j < j1; ++j) {
             const float *lp = lane + (size_t)(lo + j) * 3;
             const double dx = cx - (double)lp[0], dy = cy - (double)lp[1];

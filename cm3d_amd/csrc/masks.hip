@@ -10,7 +10,7 @@
 
 #define EP_THREADS 256
 #define EP_MAX_WP 128          // supports W <= 4096
-#define EP_LDS_WORDS 8192      // 32 KiB of packed rows per workgroup
+#define EP_LDS_WORDS 8192      // at most 32 KiB of packed rows per workgroup (dynamic LDS, sized per launch)
 
 // one bit per non-zero byte of a 16-byte chunk -> 16 bits
 static __device__ __forceinline__ uint32_t pack16(uint4 v)
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(EP_THREADS) void k_erode_pack(const uint8_t *__rest
                                                             int band_rows, uint32_t *__restrict__ packed,
                                                             int32_t *__restrict__ bbox)
 {
-    __shared__ uint32_t s_rows[EP_LDS_WORDS];
+    extern __shared__ __align__(16) uint32_t s_rows[];
     const int m = blockIdx.y;
     const int y0 = blockIdx.x * band_rows;
     const int rows = min(band_rows, H - y0);
@@ -89,14 +89,31 @@ __global__ __launch_bounds__(EP_THREADS) void k_erode_pack(const uint8_t *__rest
     if ((W & 31) == 0) {
         const int cpr = W >> 4;                 // 16-byte chunks per row
         const int nchunks = lrows * cpr;        // even, since cpr is even
-        for (int q = threadIdx.x; q < nchunks; q += EP_THREADS) {
-            const int r = q / cpr, cx = q - r * cpr;
-            const int y = y0 - 1 + r;
-            uint32_t bits = 0xFFFFu;
-            if (y >= 0 && y < H) bits = pack16(*reinterpret_cast<const uint4 *>(img + (size_t)y * W + cx * 16));
-            // q even/odd pairs sit in adjacent lanes (EP_THREADS and the stride are even)
-            uint32_t hi = (uint32_t)__shfl_xor((int)bits, 1, 64);
-            if ((q & 1) == 0) s_rows[r * Wp + (cx >> 1)] = bits | (hi << 16);
+        // the band (with halo) is one contiguous byte range of the image: stream it with
+        // 4 independent 16-byte loads in flight per lane
+        const int y_lo = y0 - 1;
+        for (int q0 = threadIdx.x; q0 < nchunks; q0 += 4 * EP_THREADS) {
+            uint4 v[4];
+            bool inimg[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = q0 + k * EP_THREADS;
+                const int r = q / cpr;
+                const int y = y_lo + r;
+                inimg[k] = q < nchunks && y >= 0 && y < H;
+                v[k] = make_uint4(0, 0, 0, 0);
+                if (inimg[k]) v[k] = *reinterpret_cast<const uint4 *>(img + (size_t)y * W + (q - r * cpr) * 16);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = q0 + k * EP_THREADS;
+                if (q < nchunks) {          // q and its pair partner q^1 are both < nchunks or both not
+                    const int r = q / cpr, cx = q - r * cpr;
+                    const uint32_t bits = inimg[k] ? pack16(v[k]) : 0xFFFFu;
+                    const uint32_t hi = (uint32_t)__shfl_xor((int)bits, 1, 64);
+                    if ((q & 1) == 0) s_rows[r * Wp + (cx >> 1)] = bits | (hi << 16);
+                }
+            }
         }
     } else {
         const int nwords = lrows * Wp;
@@ -131,29 +148,43 @@ extern "C" int cm3d_erode_pack(const uint8_t *dense, int32_t n_masks, int32_t W,
     const int bands = (H + band_rows - 1) / band_rows;
     hipLaunchKernelGGL(k_bbox_init, dim3((n_masks + 255) / 256), dim3(256), 0, st, bbox, n_masks);
     CM3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_erode_pack, dim3(bands, n_masks), dim3(EP_THREADS), 0, st, dense, W, H, Wp, band_rows, packed, bbox);
+    hipLaunchKernelGGL(k_erode_pack, dim3(bands, n_masks), dim3(EP_THREADS), (size_t)(band_rows + 2) * Wp * 4, st, dense, W, H, Wp, band_rows, packed, bbox);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }
 
 // ---------------------------------------------------------------------------
-// RLE: run lengths -> inclusive run ends (per mask), in the workspace.
+// RLE: run lengths -> inclusive run ends (per mask) in the workspace, plus the first / last
+// image row that holds a set pixel (yrange[m] = {y_first, y_last}, y_first > y_last when empty).
 __global__ __launch_bounds__(1024) void k_rle_ends(const uint32_t *__restrict__ cnts, const int32_t *__restrict__ rle_off,
-                                                   uint32_t *__restrict__ ends)
+                                                   int W, uint32_t *__restrict__ ends, int2 *__restrict__ yrange)
 {
     __shared__ int s_part[16];
+    __shared__ unsigned int s_lo, s_hi;
     const int m = blockIdx.x;
     const int o = rle_off[m], n = rle_off[m + 1] - o;
+    if (threadIdx.x == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
     int carry = 0;
+    unsigned int lo = 0xFFFFFFFFu, hi = 0u;
     for (int base = 0; base < n; base += 1024) {
         int i = base + threadIdx.x;
         int v = i < n ? (int)cnts[o + i] : 0;
         int tot;
         int ex = cm3d_block1024_excl_scan(v, s_part, tot);
-        if (i < n) ends[o + i] = (uint32_t)(carry + ex + v);
+        if (i < n) {
+            ends[o + i] = (uint32_t)(carry + ex + v);
+            if ((i & 1) && v > 0) {                       // a 1-run [start, end)
+                lo = min(lo, (unsigned int)(carry + ex));
+                hi = max(hi, (unsigned int)(carry + ex + v));
+            }
+        }
         carry += tot;
         __syncthreads();
     }
+    if (lo != 0xFFFFFFFFu) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        yrange[m] = s_hi > 0 ? make_int2((int)(s_lo / (unsigned int)W), (int)((s_hi - 1) / (unsigned int)W)) : make_int2(1, 0);
 }
 
 // first run r in [0,n) with ends[r] > p  (n if none)
@@ -196,17 +227,22 @@ __global__ __launch_bounds__(256) void k_rle_to_dense(const uint32_t *__restrict
     }
 }
 
-// f1: RLE -> packed band in LDS -> erode -> store.  grid (bands, n_masks)
+// f1: RLE -> packed band in LDS -> erode -> store.  grid (bands, n_masks).
+// Bands that cannot hold an eroded pixel (outside the row range of the mask's set pixels) exit
+// at once and write nothing: rows outside [bbox.y0, bbox.y1] are never read downstream.
 __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *__restrict__ ends_all,
-                                                                const int32_t *__restrict__ rle_off, int W, int H, int Wp,
+                                                                const int32_t *__restrict__ rle_off,
+                                                                const int2 *__restrict__ yrange, int W, int H, int Wp,
                                                                 int band_rows, uint32_t *__restrict__ packed,
                                                                 int32_t *__restrict__ bbox)
 {
-    __shared__ uint32_t s_rows[EP_LDS_WORDS];
+    extern __shared__ __align__(16) uint32_t s_rows[];
     __shared__ int s_range[2];
     const int m = blockIdx.y;
     const int y0 = blockIdx.x * band_rows;
     const int rows = min(band_rows, H - y0);
+    const int2 yr = yrange[m];
+    if (yr.x > yr.y || y0 > yr.y || y0 + rows - 1 < yr.x) return;   // no set pixel in rows y0..y0+rows-1
     const int lrows = rows + 2;
     const int o = rle_off[m], n = rle_off[m + 1] - o;
     const uint32_t *ends = ends_all + o;
@@ -219,10 +255,19 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
         const int y = ya + r;
         s_rows[q] = (y < 0 || y >= H) ? 0xFFFFFFFFu : (xw == Wp - 1 ? pad : 0u);
     }
+    if (threadIdx.x < 2) s_range[threadIdx.x] = 0;
+    __syncthreads();
     const int yc0 = max(ya, 0), yc1 = min(yb, H - 1);      // image rows held in LDS
     const uint32_t px0 = (uint32_t)yc0 * W, px1 = (uint32_t)(yc1 + 1) * W;   // pixel range [px0, px1)
-    if (threadIdx.x == 0) s_range[0] = rle_find(ends, n, px0);
-    if (threadIdx.x == 64) s_range[1] = rle_find(ends, n, px1 - 1);
+    // cooperative lower bounds (ends is ascending): #runs with end <= px0, #runs with end <= px1-1
+    int c0 = 0, c1 = 0;
+    for (int i = threadIdx.x; i < n; i += EP_THREADS) {
+        const uint32_t e = ends[i];
+        c0 += e <= px0 ? 1 : 0;
+        c1 += e <= px1 - 1 ? 1 : 0;
+    }
+    c0 = cm3d_wave_sum(c0); c1 = cm3d_wave_sum(c1);
+    if (cm3d_lane() == 0) { atomicAdd(&s_range[0], c0); atomicAdd(&s_range[1], c1); }
     __syncthreads();
     const int r_first = s_range[0], r_last = min(s_range[1], n - 1);
     // every 1-run (odd index) overlapping the band sets its bits, row by row
@@ -252,7 +297,9 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
 
 extern "C" int64_t cm3d_rle_workspace_bytes(int32_t total_runs)
 {
-    return total_runs > 0 ? (int64_t)total_runs * 4 : 0;
+    // run ends (4 B per run, padded to 16) followed by the per-mask row range is sized by the caller's
+    // n_masks; to keep the signature simple the row ranges live behind the ends: 8 B per run bounds it
+    return total_runs > 0 ? (((int64_t)total_runs * 4 + 15) / 16) * 16 + (int64_t)total_runs * 8 : 0;
 }
 
 extern "C" int cm3d_rle_to_dense(const uint32_t *rle_counts, const int32_t *rle_off, int32_t n_masks, int32_t total_runs,
@@ -264,7 +311,9 @@ extern "C" int cm3d_rle_to_dense(const uint32_t *rle_counts, const int32_t *rle_
     if (workspace_bytes < cm3d_rle_workspace_bytes(total_runs)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     uint32_t *ends = (uint32_t *)workspace;
-    hipLaunchKernelGGL(k_rle_ends, dim3(n_masks), dim3(1024), 0, st, rle_counts, rle_off, ends);
+    int2 *yrange = (int2 *)((char *)workspace + (((size_t)total_runs * 4 + 15) / 16) * 16);
+    if (n_masks > total_runs) return CM3D_ERR_ARG;
+    hipLaunchKernelGGL(k_rle_ends, dim3(n_masks), dim3(1024), 0, st, rle_counts, rle_off, W, ends, yrange);
     CM3D_CHECK_LAUNCH();
     const int total_px = W * H;
     int chunks = (total_px / 16 + 255) / 256;
@@ -289,11 +338,13 @@ extern "C" int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rl
     if (band_rows > 62) band_rows = 62;
     if (band_rows < 1) return CM3D_ERR_ARG;
     const int bands = (H + band_rows - 1) / band_rows;
-    hipLaunchKernelGGL(k_rle_ends, dim3(n_masks), dim3(1024), 0, st, rle_counts, rle_off, ends);
+    int2 *yrange = (int2 *)((char *)workspace + (((size_t)total_runs * 4 + 15) / 16) * 16);
+    if (n_masks > total_runs) return CM3D_ERR_ARG;
+    hipLaunchKernelGGL(k_rle_ends, dim3(n_masks), dim3(1024), 0, st, rle_counts, rle_off, W, ends, yrange);
     CM3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_bbox_init, dim3((n_masks + 255) / 256), dim3(256), 0, st, bbox, n_masks);
     CM3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_rle_erode_pack, dim3(bands, n_masks), dim3(EP_THREADS), 0, st, ends, rle_off, W, H, Wp, band_rows,
+    hipLaunchKernelGGL(k_rle_erode_pack, dim3(bands, n_masks), dim3(EP_THREADS), (size_t)(band_rows + 2) * Wp * 4, st, ends, rle_off, yrange, W, H, Wp, band_rows,
                        packed, bbox);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;

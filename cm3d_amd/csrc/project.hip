@@ -11,104 +11,165 @@
 #include "common.h"
 
 #define PH_THREADS 256
-#define PH_CHUNK 128          // mask descriptors staged per pass (4 hit planes)
+#define PH_PT 4                                   // points per thread
+#define PH_BLOCK_PTS (PH_THREADS * PH_PT)
+#define PH_BUCKETS (32 * CM3D_MAX_CAMS)           // (plane, camera) buckets of a frame's masks
 
+// One pinhole projection through the reference's float32 op chain.  Returns the pixel code
+// (iv << 16 | iu) or -1.  cm = camera record in LDS.
+static __device__ __forceinline__ int project_pixel(const float *cm, float4 pt, bool in_range, float min_dist, float wlim,
+                                                    float hlim)
+{
+    // global -> ego(cam time) -> camera: p += t1; p = R1 p; p += t2; p = R2 p   (2d_to_3d.py:569-577)
+    float x = pt.x + cm[0], y = pt.y + cm[1], z = pt.z + cm[2];
+    float ax, ay, az;
+    cm3d_rot3(cm + 3, x, y, z, ax, ay, az);
+    if (cm[33] > 1.5f) {
+        x = ax + cm[12]; y = ay + cm[13]; z = az + cm[14];
+        cm3d_rot3(cm + 15, x, y, z, ax, ay, az);
+    }
+    const float depth = az;                                   // :581
+    if (!(in_range && depth > min_dist)) return -1;           // first term of :597-603
+    // view_points: viewpad(4x4) @ [p;1], rows 0..2, k-sequential fma chain (pcd.py:269-282)
+    const float *K = cm + 24;
+    float uh = K[0] * ax; uh = fmaf(K[1], ay, uh); uh = fmaf(K[2], az, uh); uh = fmaf(0.0f, 1.0f, uh);
+    float vh = K[3] * ax; vh = fmaf(K[4], ay, vh); vh = fmaf(K[5], az, vh); vh = fmaf(0.0f, 1.0f, vh);
+    float zh = K[6] * ax; zh = fmaf(K[7], ay, zh); zh = fmaf(K[8], az, zh); zh = fmaf(0.0f, 1.0f, zh);
+    const float u = uh / zh, v = vh / zh;
+    // :597-603 in-image test, :605 floor, :608-613 truthiness quirk.  The third row of the quirk,
+    // floor(zh/zh) != 0, holds whenever u passed 0 < u < W-1: a finite non-zero u needs a finite
+    // non-zero zh, and then zh/zh == 1 exactly.
+    if (!(u > 0.0f && u < wlim && v > 0.0f && v < hlim)) return -1;
+    const int iu = (int)floorf(u), iv = (int)floorf(v);
+    if (iu == 0 || iv == 0) return -1;
+    return (iv << 16) | iu;
+}
+
+// grid (ceil(max_pts/1024), F).  A block owns 1024 consecutive points of one frame, 4 per thread
+// (4 independent gathers in flight), and walks the frame's masks bucketed by (plane, camera).
 __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     const float4 *__restrict__ points, const int32_t *__restrict__ pt_off, int n_points_total,
     const float *__restrict__ cams, int n_cams, const int32_t *__restrict__ mask_off,
     const int32_t *__restrict__ mask_cam, const int4 *__restrict__ bbox, const uint32_t *__restrict__ packed,
-    int W, int H, int Wp, float min_dist, uint32_t *__restrict__ hit_words, int32_t *__restrict__ hit_count,
+    int W, int H, int Wp, float min_dist, int nm_cap, uint32_t *__restrict__ hit_words, int32_t *__restrict__ hit_count,
     int32_t *__restrict__ status)
 {
     const int f = blockIdx.y;
     const int p0 = pt_off[f], n = pt_off[f + 1] - p0;
-    const int base = blockIdx.x * PH_THREADS;
+    const int base = blockIdx.x * PH_BLOCK_PTS;
     if (base >= n) return;
     const int m0 = mask_off[f];
     int nm = mask_off[f + 1] - m0;
-    if (nm > CM3D_MAX_MASKS_PER_FRAME) {
+    if (nm > nm_cap) {                       // more masks than the caller's `planes` allows
         if (threadIdx.x == 0) atomicOr(&status[0], 4);
-        nm = CM3D_MAX_MASKS_PER_FRAME;
+        nm = nm_cap;
     }
+    const int planes = (nm + 31) >> 5;
 
     __shared__ float s_cam[CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
-    __shared__ int s_pix[CM3D_MAX_CAMS][PH_THREADS];
-    __shared__ int s_mcam[PH_CHUNK];
-    __shared__ int4 s_bbox[PH_CHUNK];
+    __shared__ int s_boff[PH_BUCKETS + 1];              // bucket start offsets (exclusive scan)
+    __shared__ int s_bcnt[PH_BUCKETS];
+    // dynamic LDS: bbox[nm_cap] (bucket-sorted), pixel codes [n_cams][PH_BLOCK_PTS], order[nm_cap]
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    int4 *s_bbox = reinterpret_cast<int4 *>(s_dyn);
+    int *s_pix = reinterpret_cast<int *>(s_dyn + (size_t)nm_cap * sizeof(int4));
+    short *s_order = reinterpret_cast<short *>(s_dyn + (size_t)nm_cap * sizeof(int4) + (size_t)n_cams * PH_BLOCK_PTS * sizeof(int));
 
-    for (int i = threadIdx.x; i < n_cams * CM3D_CAM_STRIDE; i += PH_THREADS)
-        s_cam[i] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + i];
+    for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS)
+        s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
+    for (int q = threadIdx.x; q < PH_BUCKETS; q += PH_THREADS) s_bcnt[q] = 0;
+    __syncthreads();
+    // bucket = plane * MAX_CAMS + camera; counting sort with LDS atomics (order inside a bucket is free)
+    for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
+        const int c = mask_cam[m0 + k];
+        if (c < 0 || c >= n_cams) atomicOr(&status[0], 4);
+        else atomicAdd(&s_bcnt[(k >> 5) * CM3D_MAX_CAMS + c], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {             // exclusive scan of the 256 bucket counts by one wave (4 per lane)
+        int v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = s_bcnt[threadIdx.x * 4 + q]; sum += v[q]; }
+        int ex = cm3d_wave_incl_scan(sum) - sum;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s_boff[threadIdx.x * 4 + q] = ex; ex += v[q]; }
+        if (threadIdx.x == 63) s_boff[PH_BUCKETS] = ex;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < PH_BUCKETS; q += PH_THREADS) s_bcnt[q] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
+        const int c = mask_cam[m0 + k];
+        if (c < 0 || c >= n_cams) continue;
+        const int b = (k >> 5) * CM3D_MAX_CAMS + c;
+        const int pos = s_boff[b] + atomicAdd(&s_bcnt[b], 1);
+        s_order[pos] = (short)k;
+        s_bbox[pos] = bbox[m0 + k];
+    }
     __syncthreads();
 
-    const int i = base + threadIdx.x;
-    const bool in_range = i < n;
-    float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (in_range) pt = points[p0 + i];
-
     const float wlim = (float)(W - 1), hlim = (float)(H - 1);
+    int idx[PH_PT];
+    bool in_range[PH_PT];
+    float4 pt[PH_PT];
+#pragma unroll
+    for (int j = 0; j < PH_PT; ++j) {
+        idx[j] = base + j * PH_THREADS + threadIdx.x;
+        in_range[j] = idx[j] < n;
+        pt[j] = in_range[j] ? points[p0 + idx[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     uint32_t cam_any = 0;     // wave-uniform: cameras that see at least one point of this wave
+#pragma unroll 1
     for (int c = 0; c < n_cams; ++c) {
-        const float *cm = s_cam + c * CM3D_CAM_STRIDE;
-        // global -> ego(cam time) -> camera: p += t1; p = R1 p; p += t2; p = R2 p   (2d_to_3d.py:569-577)
-        float x = pt.x + cm[0], y = pt.y + cm[1], z = pt.z + cm[2];
-        float ax, ay, az;
-        cm3d_rot3(cm + 3, x, y, z, ax, ay, az);
-        if (cm[33] > 1.5f) {
-            x = ax + cm[12]; y = ay + cm[13]; z = az + cm[14];
-            cm3d_rot3(cm + 15, x, y, z, ax, ay, az);
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < PH_PT; ++j) {
+            const int px = project_pixel(s_cam + c * CM3D_CAM_STRIDE, pt[j], in_range[j], min_dist, wlim, hlim);
+            s_pix[c * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x] = px;     // read back by this thread only
+            any = any || px >= 0;
         }
-        const float depth = az;                                   // :581
-        // view_points: viewpad(4x4) @ [p;1], rows 0..2, k-sequential fma chain (pcd.py:269-282)
-        const float *K = cm + 24;
-        float uh = K[0] * ax; uh = fmaf(K[1], ay, uh); uh = fmaf(K[2], az, uh); uh = fmaf(0.0f, 1.0f, uh);
-        float vh = K[3] * ax; vh = fmaf(K[4], ay, vh); vh = fmaf(K[5], az, vh); vh = fmaf(0.0f, 1.0f, vh);
-        float zh = K[6] * ax; zh = fmaf(K[7], ay, zh); zh = fmaf(K[8], az, zh); zh = fmaf(0.0f, 1.0f, zh);
-        const float u = uh / zh, v = vh / zh, w = zh / zh;
-        // :597-603 in-image test, :605 floor, :608-613 truthiness quirk (floor(.) != 0 on all three rows)
-        bool ok = in_range && depth > min_dist && u > 0.0f && u < wlim && v > 0.0f && v < hlim;
-        int iu = 0, iv = 0;
-        if (ok) {
-            iu = (int)floorf(u); iv = (int)floorf(v);
-            ok = iu != 0 && iv != 0 && (int)floorf(w) != 0;
-        }
-        s_pix[c][threadIdx.x] = ok ? ((iv << 16) | iu) : -1;
-        if (__ballot(ok)) cam_any |= 1u << c;
+        if (__ballot(any)) cam_any |= 1u << c;
     }
 
     const size_t mask_words = (size_t)H * Wp;
-    for (int cbase = 0; cbase < nm; cbase += PH_CHUNK) {
-        const int cn = min(PH_CHUNK, nm - cbase);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cn; k += PH_THREADS) {
-            int c = mask_cam[m0 + cbase + k];
-            if (c < 0 || c >= n_cams) { atomicOr(&status[0], 4); c = 0; s_bbox[k] = make_int4(1, 1, 0, 0); }
-            else s_bbox[k] = bbox[m0 + cbase + k];
-            s_mcam[k] = c;
-        }
-        __syncthreads();
-        uint32_t bits = 0;
-        for (int k = 0; k < cn; ++k) {
-            const int c = s_mcam[k];
-            bool hit = false;
-            if ((cam_any >> c) & 1u) {
-                const int pix = s_pix[c][threadIdx.x];
-                if (pix >= 0) {
-                    const int iu = pix & 0xFFFF, iv = pix >> 16;
-                    const int4 bb = s_bbox[k];
-                    if (iu >= bb.x && iu <= bb.z && iv >= bb.y && iv <= bb.w) {
-                        const uint32_t word = packed[(size_t)(m0 + cbase + k) * mask_words + (size_t)iv * Wp + (iu >> 5)];
-                        hit = (word >> (iu & 31)) & 1u;
-                    }
+    for (int plane = 0; plane < planes; ++plane) {
+        uint32_t bits[PH_PT];
+#pragma unroll
+        for (int j = 0; j < PH_PT; ++j) bits[j] = 0;
+#pragma unroll 1
+        for (int c = 0; c < n_cams; ++c) {
+            if (!((cam_any >> c) & 1u)) continue;            // wave-uniform
+            int px[PH_PT];
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) px[j] = s_pix[c * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x];
+            const int b = plane * CM3D_MAX_CAMS + c;
+            const int k0 = s_boff[b], k1 = s_boff[b + 1];
+            for (int kk = k0; kk < k1; ++kk) {
+                const int k = s_order[kk];
+                const int4 bb = s_bbox[kk];
+                const uint32_t *mw = packed + (size_t)(m0 + k) * mask_words;
+                uint32_t word[PH_PT];
+                bool cand[PH_PT];
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j) {
+                    const int iu = px[j] & 0xFFFF, iv = px[j] >> 16;
+                    cand[j] = px[j] >= 0 && iu >= bb.x && iu <= bb.z && iv >= bb.y && iv <= bb.w;
+                    word[j] = 0;
+                    if (cand[j]) word[j] = mw[(size_t)iv * Wp + (iu >> 5)];
                 }
-                const uint64_t bal = __ballot(hit);
-                if (bal && cm3d_lane() == 0) atomicAdd(&hit_count[m0 + cbase + k], __popcll(bal));
-            }
-            bits |= (hit ? 1u : 0u) << (k & 31);
-            if ((k & 31) == 31 || k == cn - 1) {
-                if (in_range) hit_words[(size_t)((cbase + k) >> 5) * n_points_total + p0 + i] = bits;
-                bits = 0;
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j) {
+                    const bool hit = cand[j] && ((word[j] >> (px[j] & 31)) & 1u);
+                    bits[j] |= (hit ? 1u : 0u) << (k & 31);
+                    cnt += __popcll(__ballot(hit));
+                }
+                if (cnt && cm3d_lane() == 0) atomicAdd(&hit_count[m0 + k], cnt);
             }
         }
+#pragma unroll
+        for (int j = 0; j < PH_PT; ++j)
+            if (in_range[j]) hit_words[(size_t)plane * n_points_total + p0 + idx[j]] = bits[j];
     }
 }
 
@@ -224,9 +285,12 @@ extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int
         return CM3D_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int Wp = (W + 31) / 32;
-    dim3 grid((max_pts_per_frame + PH_THREADS - 1) / PH_THREADS, n_frames);
-    hipLaunchKernelGGL(k_project_hits, grid, dim3(PH_THREADS), 0, st, (const float4 *)points, pt_off, n_points_total, cams,
-                       n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, hit_words, hit_count,
+    dim3 grid((max_pts_per_frame + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS, n_frames);
+    int nm_cap = planes * 32;
+    if (nm_cap > CM3D_MAX_MASKS_PER_FRAME) nm_cap = CM3D_MAX_MASKS_PER_FRAME;
+    const size_t lds = (size_t)nm_cap * (sizeof(int4) + sizeof(short)) + (size_t)n_cams * PH_BLOCK_PTS * sizeof(int);
+    hipLaunchKernelGGL(k_project_hits, grid, dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off, n_points_total, cams,
+                       n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, nm_cap, hit_words, hit_count,
                        status);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;

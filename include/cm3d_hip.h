@@ -100,7 +100,8 @@ int cm3d_erode_pack(const uint8_t *dense, int32_t n_masks, int32_t W, int32_t H,
                     int32_t *bbox, cm3d_stream_t stream);
 
 /* f1: same result straight from run lengths, no dense intermediate
- * (fuses 2d_to_3d.py:425 with :526-527,542-544). */
+ * (fuses 2d_to_3d.py:425 with :526-527,542-544).  Only the rows that can hold an eroded pixel are
+ * written: `packed` rows outside [bbox.y0, bbox.y1] are unspecified (nothing downstream reads them). */
 int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int32_t n_masks, int32_t total_runs,
                         int32_t W, int32_t H, uint32_t *packed, int32_t *bbox, void *workspace,
                         int64_t workspace_bytes, cm3d_stream_t stream);
