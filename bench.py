@@ -101,7 +101,9 @@ def main():
     cfg = syn.config(args.config)
     t_gen = time.perf_counter()
     frames = [syn.make_frame(cfg, rank * args.frames + i) for i in range(args.frames)]
-    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], args.lane_points, seed=7 + rank)]
+    # one HD-map lane table covering the region all frames of the batch drive in (ego positions are drawn
+    # from (600,1600) +- 200 m, objects up to 55 m further out)
+    lanes = [syn.make_lane_table([600.0, 1600.0], args.lane_points, seed=7 + rank, extent=260.0)]
     frame_lane = [0] * len(frames)
     hb = lifting.pack_frames(frames, lanes, frame_lane)
     t_gen = time.perf_counter() - t_gen
@@ -122,8 +124,12 @@ def main():
         stages = list(eng.STAGES)
         ev = {s: [] for s in stages}
         st = torch.cuda.current_stream(dev).cuda_stream
+        def lanes(s):
+            eng.wait_lane_grid()        # the lane-grid build runs on the engine's side stream since stage_begin
+            eng.stage_lanes(s)
+
         calls = {"sweeps": eng.stage_sweeps, "masks": lambda s: eng.stage_masks(s, mode), "project": eng.stage_project,
-                 "compact": eng.stage_compact, "medoid": eng.stage_medoid, "lanes": eng.stage_lanes, "boxes": eng.stage_boxes}
+                 "compact": eng.stage_compact, "medoid": eng.stage_medoid, "lanes": lanes, "boxes": eng.stage_boxes}
         for _ in range(args.warmup):
             eng.run(masks=mode)
         torch.cuda.synchronize()

@@ -15,7 +15,7 @@ SWEEP_XF_STRIDE = 24
 MAX_CAMS = 8
 MAX_MASKS_PER_FRAME = 1024
 BOX_STRIDE = 10
-MEDOID_TILE = 256
+MEDOID_TILE = 64
 STATUS_WORDS = 4
 
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -31,13 +31,16 @@ SIGNATURES = {
     "cm3d_rle_to_dense": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p]),
     "cm3d_erode_pack": (_i32, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "cm3d_rle_erode_pack": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p]),
+    "cm3d_project_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "cm3d_project_hits": (_i32, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32,
-                                 _p, _p, _p, _p]),
-    "cm3d_compact_hits": (_i32, [_p, _i32, _p, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i32, _p, _p]),
+                                 _p, _p, _p, _p, _i64, _p]),
+    "cm3d_compact_hits": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i32, _p, _p, _i64, _p]),
     "cm3d_medoid_workspace_bytes": (_i64, [_i32, _i32]),
     "cm3d_medoid": (_i32, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _i64, _p]),
+    "cm3d_lane_grid_bytes": (_i64, [_i32, _i32]),
+    "cm3d_lane_grid_build": (_i32, [_p, _p, _i32, _i32, _p, _i64, _p]),
     "cm3d_lane_nn_workspace_bytes": (_i64, [_i32]),
-    "cm3d_lane_nn": (_i32, [_p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "cm3d_lane_nn": (_i32, [_p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
     "cm3d_circle_nms": (_i32, [_p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p]),
     "cm3d_box_nms": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
 }

@@ -5,8 +5,205 @@
 // latency-bound (NMS); no HBM roofline applies.
 #include "common.h"
 
+// ---- nearest lane point (a10) ------------------------------------------------------------------
+// Reference: scipy cdist (float64) between every centroid and every lane point, np.argmin (first
+// minimum).  Brute force is K x L pairs; here each lane table is binned into a uniform grid
+// (rebuilt on every call, it is cheap) and a centroid only looks at the cells of growing square
+// rings around it.  The result is the brute-force result exactly:
+//  * after ring r every unvisited point is >= r*cell away (it differs by >= r cells along one
+//    axis), so the search stops once the best distance is below r*cell (with a 1e-9 margin);
+//  * candidates are compared as (sqrt(d2), original index) lexicographically, so visiting order
+//    does not matter and the first minimum wins on ties, like np.argmin.
+#define LG_MAX_CELLS 32768          // cells per table: the whole cell index lives in LDS (128 KiB) during the build
+#define LG_CELL0 4.0f               // preferred cell edge [m]
+#define LG_MAX_RINGS 10             // rings a centroid may visit before it is handed to the brute-force kernel
+#define LG_BUILD_THREADS 1024
+
+struct LaneGrid { float x0, y0, h, inv_h; int gw, gh, cell_base; float margin; };
+struct LanePt { float x, y; int idx, pad; };
+
+static __device__ __forceinline__ int lg_cell_coord(float v, float v0, float inv_h, int n)
+{
+    // the same expression bins lane points and (clamped later) centroids
+    int c = (int)floorf((v - v0) * inv_h);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+// One workgroup builds the whole index of one lane table: bounding box -> grid geometry -> cell
+// counts (LDS atomics) -> exclusive scan (LDS) -> scatter into cell order.  Three passes over the
+// table (it sits in L2), one launch, no global atomics, no memset.
+__global__ __launch_bounds__(LG_BUILD_THREADS) void k_lane_grid_build(const float *__restrict__ lane,
+                                                                      const int32_t *__restrict__ lane_off,
+                                                                      LaneGrid *__restrict__ grids, int32_t *__restrict__ cell_start,
+                                                                      LanePt *__restrict__ sorted)
+{
+    extern __shared__ __align__(16) int s_cell[];          // LG_MAX_CELLS + 1 ints
+    __shared__ float s_red[4][16];
+    __shared__ int s_part[16];
+    __shared__ LaneGrid s_g;
+    const int t = blockIdx.x;
+    const int lo = lane_off[t], L = lane_off[t + 1] - lo;
+    // pass 1: bounding box
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int i = threadIdx.x; i < L; i += LG_BUILD_THREADS) {
+        const float x = lane[(size_t)(lo + i) * 3], y = lane[(size_t)(lo + i) * 3 + 1];
+        if (x == x && y == y) { mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
+        mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+    }
+    const int wave = threadIdx.x >> 6;
+    if (cm3d_lane() == 0) { s_red[0][wave] = mnx; s_red[1][wave] = mny; s_red[2][wave] = mxx; s_red[3][wave] = mxy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) {
+            mnx = fminf(mnx, s_red[0][w]); mny = fminf(mny, s_red[1][w]);
+            mxx = fmaxf(mxx, s_red[2][w]); mxy = fmaxf(mxy, s_red[3][w]);
+        }
+        LaneGrid g;
+        if (!(mxx >= mnx)) { mnx = mny = 0.f; mxx = mxy = 0.f; }      // empty table
+        float h = LG_CELL0;
+        const float ex = mxx - mnx, ey = mxy - mny;
+        while ((double)(floorf(ex / h) + 1.f) * (double)(floorf(ey / h) + 1.f) > (double)LG_MAX_CELLS) h *= 1.25f;
+        g.x0 = mnx; g.y0 = mny; g.h = h; g.inv_h = 1.0f / h;
+        g.gw = (int)floorf(ex / h) + 1; g.gh = (int)floorf(ey / h) + 1;
+        g.cell_base = t * (LG_MAX_CELLS + 1);
+        // points are binned with float32 arithmetic: a point can sit in the neighbouring cell of its
+        // exact position by a few ulp of the coordinate magnitude; the ring bound gives that much away
+        g.margin = 16.0f * 1.1920929e-7f * fmaxf(fmaxf(fabsf(mnx), fabsf(mxx)), fmaxf(fabsf(mny), fabsf(mxy))) + 1e-4f * h;
+        s_g = g;
+        grids[t] = g;
+    }
+    __syncthreads();
+    const LaneGrid g = s_g;
+    const int ncell = g.gw * g.gh;
+    for (int c = threadIdx.x; c <= ncell; c += LG_BUILD_THREADS) s_cell[c] = 0;
+    __syncthreads();
+    // pass 2: counts
+    for (int i = threadIdx.x; i < L; i += LG_BUILD_THREADS) {
+        const float x = lane[(size_t)(lo + i) * 3], y = lane[(size_t)(lo + i) * 3 + 1];
+        if (x == x && y == y)
+            atomicAdd(&s_cell[lg_cell_coord(y, g.y0, g.inv_h, g.gh) * g.gw + lg_cell_coord(x, g.x0, g.inv_h, g.gw)], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the cells (positions are global indices into `sorted`)
+    int carry = lo;
+    for (int base = 0; base < ncell; base += LG_BUILD_THREADS * 4) {
+        const int c0 = base + threadIdx.x * 4;
+        int v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = c0 + q < ncell ? s_cell[c0 + q] : 0; sum += v[q]; }
+        int tot;
+        int ex = carry + cm3d_block1024_excl_scan(sum, s_part, tot);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (c0 + q < ncell) { s_cell[c0 + q] = ex; cell_start[g.cell_base + c0 + q] = ex; }
+            ex += v[q];
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cell_start[g.cell_base + ncell] = carry;
+    __syncthreads();
+    // pass 3: scatter (the LDS copy of the start offsets doubles as the fill cursor)
+    for (int i = threadIdx.x; i < L; i += LG_BUILD_THREADS) {
+        const float x = lane[(size_t)(lo + i) * 3], y = lane[(size_t)(lo + i) * 3 + 1];
+        if (x == x && y == y) {
+            const int c = lg_cell_coord(y, g.y0, g.inv_h, g.gh) * g.gw + lg_cell_coord(x, g.x0, g.inv_h, g.gw);
+            sorted[atomicAdd(&s_cell[c], 1)] = LanePt{x, y, i, 0};
+        }
+    }
+}
+
+// candidate (d2, j) against the running best under the reference's semantics:
+// minimise sqrt(d2) (float64), ties -> smaller original index.
+static __device__ __forceinline__ void lg_consider(double d2, int j, double &d2cut, double &sbest, int &jbest)
+{
+    if (d2 <= d2cut * (1.0 + 1e-15)) {               // otherwise sqrt(d2) > sbest for sure
+        const double s = sqrt(d2);
+        if (s < sbest || (s == sbest && j < jbest)) { sbest = s; jbest = j; d2cut = d2; }
+    }
+}
+
+// One wave per centroid.  Ring r has 8r cells (one for r = 0); lane u takes cell u of the ring,
+// scans that cell's points and the wave merges (sqrt(d2), index) lexicographically.
+__global__ __launch_bounds__(256) void k_lane_nn_grid(const float *__restrict__ centroid, const int32_t *__restrict__ medoid_pos,
+                                                      const int32_t *__restrict__ mask_frame, int n_masks,
+                                                      const int32_t *__restrict__ lane_off, const int32_t *__restrict__ frame_lane,
+                                                      const LaneGrid *__restrict__ grids, const int32_t *__restrict__ cell_start,
+                                                      const LanePt *__restrict__ sorted, int max_rings,
+                                                      int32_t *__restrict__ unres, int32_t *__restrict__ n_unres,
+                                                      int32_t *__restrict__ lane_idx, double *__restrict__ lane_dist)
+{
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = cm3d_lane();
+    if (k >= n_masks) return;
+    if (medoid_pos[k] < 0) { if (lane == 0) { lane_idx[k] = -1; lane_dist[k] = INFINITY; } return; }
+    const int tb = frame_lane[mask_frame[k]];
+    const LaneGrid g = grids[tb];
+    const double cx = (double)centroid[3 * k], cy = (double)centroid[3 * k + 1];
+    double d2cut = INFINITY, sbest = INFINITY;
+    int jbest = 0x7FFFFFFF;
+    bool resolved = true;
+    if (lane_off[tb + 1] > lane_off[tb] && cx == cx && cy == cy) {
+        resolved = false;
+        // (virtual) cell of the centroid; may lie outside the grid
+        const double fi = floor((cx - (double)g.x0) * (double)g.inv_h), fj = floor((cy - (double)g.y0) * (double)g.inv_h);
+        const int qi = (int)fmax(-1.0e6, fmin(1.0e6, fi)), qj = (int)fmax(-1.0e6, fmin(1.0e6, fj));
+        const int out_i = qi < 0 ? -qi : (qi >= g.gw ? qi - g.gw + 1 : 0);
+        const int out_j = qj < 0 ? -qj : (qj >= g.gh ? qj - g.gh + 1 : 0);
+        const int32_t *cs = cell_start + g.cell_base;
+        int rings = 0;
+        for (int r = max(out_i, out_j); rings < max_rings; ++r, ++rings) {
+            const int ncells = r == 0 ? 1 : 8 * r;
+            for (int u = lane; u < ncells; u += 64) {
+                int ci = qi, cj = qj;
+                if (r > 0) {
+                    const int side = u / (2 * r), t = u - side * 2 * r;
+                    if (side == 0)      { cj = qj - r; ci = qi - r + t; }
+                    else if (side == 1) { ci = qi + r; cj = qj - r + t; }
+                    else if (side == 2) { cj = qj + r; ci = qi + r - t; }
+                    else                { ci = qi - r; cj = qj + r - t; }
+                }
+                if (ci < 0 || ci >= g.gw || cj < 0 || cj >= g.gh) continue;
+                const int a = cs[cj * g.gw + ci], b = cs[cj * g.gw + ci + 1];
+                for (int q = a; q < b; ++q) {
+                    const LanePt p = sorted[q];
+                    const double dx = cx - (double)p.x, dy = cy - (double)p.y;
+                    lg_consider(dx * dx + dy * dy, p.idx, d2cut, sbest, jbest);
+                }
+            }
+            // wave-wide best distance so far
+            double wb = sbest;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wb = fmin(wb, __shfl_xor(wb, o, 64));
+            // every unvisited point is at least r*h - margin away
+            if (wb < (double)r * (double)g.h - (double)g.margin) { resolved = true; break; }
+            if (qi - r <= 0 && qi + r >= g.gw - 1 && qj - r <= 0 && qj + r >= g.gh - 1) { resolved = true; break; }   // whole grid seen
+        }
+    }
+    if (!resolved) {            // far from every lane: hand over to the exact brute-force kernel
+        if (lane == 0) unres[atomicAdd(n_unres, 1)] = k;
+        return;
+    }
+    // lexicographic (distance, index) minimum over the lanes
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double os = __shfl_xor(sbest, o, 64);
+        const int oj = __shfl_xor(jbest, o, 64);
+        if (os < sbest || (os == sbest && oj < jbest)) { sbest = os; jbest = oj; }
+    }
+    if (lane == 0) {
+        if (jbest == 0x7FFFFFFF) jbest = 0;      // empty table / NaN centroid: np.argmin of an all-inf/NaN row
+        lane_idx[k] = jbest;
+        lane_dist[k] = sbest;
+    }
+}
+
 #define LN_THREADS 256
-#define LN_SLICES 128
+#define LN_SLICES 64
 #define LN_TILE 512
 
 // Reference: d = sqrt(dx*dx+dy*dy) per pair, first minimum of d (np.argmin).
@@ -28,19 +225,23 @@ static __device__ __forceinline__ void ln_update(double d2, int j, double &d2cut
 // more than 2 ulp => strictly smaller; d2 >= best => sqrt >= best: no switch either way.)
 #define LN_NEAR (1.0 - 1e-15)
 
-// grid (ceil(n_masks/256), LN_SLICES): thread = one centroid, block.y = one slice of its lane table
-__global__ __launch_bounds__(LN_THREADS) void k_lane_nn(const float *__restrict__ centroid,
-                                                         const int32_t *__restrict__ medoid_pos,
-                                                         const int32_t *__restrict__ mask_frame, int n_masks,
-                                                         const float *__restrict__ lane, const int32_t *__restrict__ lane_off,
-                                                         const int32_t *__restrict__ frame_lane,
-                                                         double *__restrict__ part_s, int32_t *__restrict__ part_j)
+// Exact brute force for the centroids the ring search gave up on (far from every lane).
+// grid (ceil(n_masks/256), LN_SLICES): thread = one unresolved centroid, block.y = one slice of its table.
+__global__ __launch_bounds__(LN_THREADS) void k_lane_nn_brute(const float *__restrict__ centroid,
+                                                               const int32_t *__restrict__ unres, const int32_t *__restrict__ n_unres,
+                                                               const int32_t *__restrict__ mask_frame, int n_masks,
+                                                               const float *__restrict__ lane, const int32_t *__restrict__ lane_off,
+                                                               const int32_t *__restrict__ frame_lane,
+                                                               double *__restrict__ part_s, int32_t *__restrict__ part_j)
 {
     __shared__ double2 s_lane[LN_TILE];
     __shared__ int s_tb, s_uni;
-    const int k = blockIdx.x * LN_THREADS + threadIdx.x;
+    const int U = *n_unres;
+    if ((int)blockIdx.x * LN_THREADS >= U) return;
+    const int u = blockIdx.x * LN_THREADS + threadIdx.x;
     const int slice = blockIdx.y;
-    const bool act = k < n_masks && medoid_pos[k] >= 0;
+    const bool act = u < U;
+    const int k = act ? unres[u] : 0;
     const int tb = act ? frame_lane[mask_frame[k]] : -1;
     if (threadIdx.x == 0) { s_tb = -2; s_uni = 1; }
     __syncthreads();
@@ -104,53 +305,103 @@ __global__ __launch_bounds__(LN_THREADS) void k_lane_nn(const float *__restrict_
             ln_update(dx * dx + dy * dy, j, d2cut, sbest, jbest);
         }
     }
-    if (k < n_masks) {
-        part_s[(size_t)slice * n_masks + k] = sbest;
-        part_j[(size_t)slice * n_masks + k] = jbest;
+    if (act) {
+        part_s[(size_t)slice * n_masks + u] = sbest;
+        part_j[(size_t)slice * n_masks + u] = jbest;
     }
 }
 
-__global__ __launch_bounds__(256) void k_lane_nn_reduce(const int32_t *__restrict__ medoid_pos, int n_masks,
-                                                        const double *__restrict__ part_s, const int32_t *__restrict__ part_j,
-                                                        int32_t *__restrict__ lane_idx, double *__restrict__ lane_dist)
+__global__ __launch_bounds__(256) void k_lane_nn_brute_reduce(const int32_t *__restrict__ unres, const int32_t *__restrict__ n_unres,
+                                                              int n_masks, const double *__restrict__ part_s,
+                                                              const int32_t *__restrict__ part_j, int32_t *__restrict__ lane_idx,
+                                                              double *__restrict__ lane_dist)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_masks) return;
-    if (medoid_pos[k] < 0) { lane_idx[k] = -1; lane_dist[k] = INFINITY; return; }
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= *n_unres) return;
     double sb = INFINITY; int jb = 0;
-    bool have = false;
     for (int s = 0; s < LN_SLICES; ++s) {
-        const double v = part_s[(size_t)s * n_masks + k];
-        const int j = part_j[(size_t)s * n_masks + k];
+        const double v = part_s[(size_t)s * n_masks + u];
+        const int j = part_j[(size_t)s * n_masks + u];
         // slices cover ascending j ranges, so a strict < keeps the first minimum
-        if (v < sb) { sb = v; jb = j; have = true; }
+        if (v < sb) { sb = v; jb = j; }
     }
-    (void)have;
+    const int k = unres[u];
     lane_idx[k] = jb;
     lane_dist[k] = sb;
 }
 
+static inline size_t lg_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct LgLayout { LaneGrid *grids; int32_t *cell_start; LanePt *sorted; };
+static inline LgLayout lg_layout(void *grid, int n_tables, int n_lane_points)
+{
+    char *w = (char *)grid;
+    LgLayout l;
+    l.grids = (LaneGrid *)w;          w += lg_align(sizeof(LaneGrid) * (size_t)n_tables);
+    l.cell_start = (int32_t *)w;      w += lg_align(sizeof(int32_t) * (size_t)n_tables * (LG_MAX_CELLS + 1));
+    l.sorted = (LanePt *)w;
+    (void)n_lane_points;
+    return l;
+}
+
+extern "C" int64_t cm3d_lane_grid_bytes(int32_t n_tables, int32_t n_lane_points)
+{
+    if (n_tables <= 0 || n_lane_points <= 0) return 0;
+    return (int64_t)(lg_align(sizeof(LaneGrid) * (size_t)n_tables) + lg_align(sizeof(int32_t) * (size_t)n_tables * (LG_MAX_CELLS + 1)) +
+                     lg_align(sizeof(LanePt) * (size_t)n_lane_points));
+}
+
+extern "C" int cm3d_lane_grid_build(const float *lane, const int32_t *lane_off, int32_t n_tables, int32_t n_lane_points, void *grid,
+                                    int64_t grid_bytes, cm3d_stream_t stream)
+{
+    if (!lane || !lane_off || !grid || n_tables <= 0 || n_lane_points <= 0) return CM3D_ERR_ARG;
+    if (grid_bytes < cm3d_lane_grid_bytes(n_tables, n_lane_points)) return CM3D_ERR_WORKSPACE;
+    const LgLayout l = lg_layout(grid, n_tables, n_lane_points);
+    static bool attr_set = false;
+    const size_t lds = sizeof(int) * (size_t)(LG_MAX_CELLS + 1);
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_lane_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return CM3D_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_lane_grid_build, dim3(n_tables), dim3(LG_BUILD_THREADS), lds, (hipStream_t)stream, lane, lane_off, l.grids,
+                       l.cell_start, l.sorted);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
+}
+
 extern "C" int64_t cm3d_lane_nn_workspace_bytes(int32_t n_masks)
 {
-    return n_masks > 0 ? (int64_t)n_masks * LN_SLICES * (int64_t)(sizeof(double) + sizeof(int32_t)) : 0;
+    if (n_masks <= 0) return 0;
+    return (int64_t)(lg_align(sizeof(int32_t) * ((size_t)n_masks + 64)) +
+                     lg_align((sizeof(double) + sizeof(int32_t)) * (size_t)n_masks * LN_SLICES));
 }
 
 extern "C" int cm3d_lane_nn(const float *centroid, const int32_t *medoid_pos, const int32_t *mask_frame, int32_t n_masks,
-                            const float *lane, const int32_t *lane_off, const int32_t *frame_lane, int32_t *lane_idx,
-                            double *lane_dist, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream)
+                            const float *lane, const int32_t *lane_off, const int32_t *frame_lane, int32_t n_tables,
+                            int32_t n_lane_points, const void *grid, int32_t *lane_idx, double *lane_dist, void *workspace,
+                            int64_t workspace_bytes, cm3d_stream_t stream)
 {
-    if (!centroid || !medoid_pos || !mask_frame || !lane || !lane_off || !frame_lane || !lane_idx || !lane_dist || !workspace)
+    if (!centroid || !medoid_pos || !mask_frame || !lane || !lane_off || !frame_lane || !grid || !lane_idx || !lane_dist || !workspace)
         return CM3D_ERR_ARG;
-    if (n_masks <= 0) return CM3D_ERR_ARG;
+    if (n_masks <= 0 || n_tables <= 0 || n_lane_points <= 0) return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_lane_nn_workspace_bytes(n_masks)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    double *part_s = (double *)workspace;
+    const LgLayout l = lg_layout(const_cast<void *>(grid), n_tables, n_lane_points);
+    char *w = (char *)workspace;
+    int32_t *n_unres = (int32_t *)w;                    // counter, then the list
+    int32_t *unres = n_unres + 64;                      w += lg_align(sizeof(int32_t) * ((size_t)n_masks + 64));
+    double *part_s = (double *)w;
     int32_t *part_j = (int32_t *)(part_s + (size_t)n_masks * LN_SLICES);
-    dim3 grid((n_masks + LN_THREADS - 1) / LN_THREADS, LN_SLICES);
-    hipLaunchKernelGGL(k_lane_nn, grid, dim3(LN_THREADS), 0, st, centroid, medoid_pos, mask_frame, n_masks, lane, lane_off,
-                       frame_lane, part_s, part_j);
+    if (hipMemsetAsync(n_unres, 0, sizeof(int32_t), st) != hipSuccess) return CM3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_lane_nn_grid, dim3((n_masks + 3) / 4), dim3(256), 0, st, centroid, medoid_pos, mask_frame, n_masks, lane_off,
+                       frame_lane, l.grids, l.cell_start, l.sorted, LG_MAX_RINGS, unres, n_unres, lane_idx, lane_dist);
     CM3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_lane_nn_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, medoid_pos, n_masks, part_s, part_j,
+    // exact brute force for whatever the ring search left unresolved (blocks beyond the count exit at once)
+    hipLaunchKernelGGL(k_lane_nn_brute, dim3((n_masks + LN_THREADS - 1) / LN_THREADS, LN_SLICES), dim3(LN_THREADS), 0, st, centroid,
+                       unres, n_unres, mask_frame, n_masks, lane, lane_off, frame_lane, part_s, part_j);
+    CM3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_lane_nn_brute_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, unres, n_unres, n_masks, part_s, part_j,
                        lane_idx, lane_dist);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;

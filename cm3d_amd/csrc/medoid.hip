@@ -8,41 +8,50 @@
 // of the reference's behaviour and is reproduced, not fixed.)
 // Column j lives in one thread and is summed over rows i in ascending order, so the float32
 // column sums do not depend on the launch geometry.  A tile = 256 columns of one mask; rows are
-// staged through LDS 256 at a time and read back as wave-wide broadcasts.  VALU-bound
+// staged through LDS 64 at a time and read back as wave-wide broadcasts.  VALU-bound
 // (about 20 ops per pair incl. the IEEE sqrt); nothing M x M ever touches HBM.
 #include "common.h"
 
-#define MD_THREADS CM3D_MEDOID_TILE
+#define MD_WAVES 4                       // waves per workgroup, one tile each
+#define MD_THREADS (MD_WAVES * 64)
 
 struct TileBest { float s; int j; };
+struct TileDesc { int m, off, M, jt; };  // mask, start in hit_idx, list length, tile index inside the mask
 
+// thread per mask: one descriptor per 64-column tile of its index list
+__global__ __launch_bounds__(256) void k_medoid_desc(int n_masks, const int32_t *__restrict__ hit_off,
+                                                     const int32_t *__restrict__ tile_off, int idx_cap, int tile_cap,
+                                                     TileDesc *__restrict__ desc)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_masks) return;
+    const int off = hit_off[m];
+    int M = hit_off[m + 1] - off;
+    if (off + M > idx_cap) M = max(0, idx_cap - off);     // index capacity overflow: stay in bounds
+    const int t0 = tile_off[m], t1 = min(tile_off[m + 1], tile_cap);
+    for (int t = t0; t < t1; ++t) desc[t] = TileDesc{m, off, M, t - t0};
+}
+
+// One wave = one tile = 64 columns of one mask; rows are staged 64 at a time through the wave's own
+// LDS slice and read back as broadcasts.  No workgroup barrier: waves of a block are independent.
 __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__restrict__ points,
                                                               const int32_t *__restrict__ pt_off,
                                                               const int32_t *__restrict__ mask_frame, int n_masks,
-                                                              const int32_t *__restrict__ hit_off,
                                                               const int32_t *__restrict__ tile_off,
-                                                              const int32_t *__restrict__ hit_idx, int idx_cap,
+                                                              const int32_t *__restrict__ hit_idx,
+                                                              const TileDesc *__restrict__ desc,
                                                               TileBest *__restrict__ tile_best, int tile_cap,
                                                               float *__restrict__ colsum_opt)
 {
-    __shared__ float4 s_row[MD_THREADS];
-    __shared__ float s_ws[MD_THREADS / 64];
-    __shared__ int s_wj[MD_THREADS / 64];
+    __shared__ float4 s_row_all[MD_WAVES][64];
+    const int wave = threadIdx.x >> 6, lane = cm3d_lane();
+    float4 *s_row = s_row_all[wave];
     const int ntiles = min(tile_off[n_masks], tile_cap);
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        // mask of this tile: largest m with tile_off[m] <= t (uniform binary search)
-        int lo = 0, hi = n_masks;
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (tile_off[mid] <= t) lo = mid; else hi = mid;
-        }
-        const int m = lo;
-        const int off = hit_off[m];
-        int M = hit_off[m + 1] - off;
-        if (off + M > idx_cap) M = max(0, idx_cap - off);     // index capacity overflow: stay in bounds
-        const int jt = t - tile_off[m];
-        const float4 *P = points + pt_off[mask_frame[m]];
-        const int j = jt * MD_THREADS + threadIdx.x;
+    for (int t = blockIdx.x * MD_WAVES + wave; t < ntiles; t += gridDim.x * MD_WAVES) {
+        const TileDesc d = desc[t];
+        const int off = d.off, M = d.M;
+        const float4 *P = points + pt_off[mask_frame[d.m]];
+        const int j = d.jt * 64 + lane;
         const bool act = j < M;
         float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
         if (act) {
@@ -52,23 +61,25 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
         }
         float s = 0.f;
         const bool direct = M <= 25;
-        for (int i0 = 0; i0 < M; i0 += MD_THREADS) {
-            __syncthreads();
-            const int i = i0 + threadIdx.x;
+        for (int i0 = 0; i0 < M; i0 += 64) {
+            __builtin_amdgcn_wave_barrier();
+            const int i = i0 + lane;
             if (i < M) {
                 float4 r = P[hit_idx[off + i]];
                 r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
-                s_row[threadIdx.x] = r;
+                s_row[lane] = r;
             }
-            __syncthreads();
-            const int cnt = min(MD_THREADS, M - i0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int cnt = min(64, M - i0);
             if (direct) {
                 for (int ii = 0; ii < cnt; ++ii) {
                     const float4 r = s_row[ii];
-                    float d = fabsf(r.x - qx);
-                    float agg = fmaf(d, d, 0.0f);
-                    d = fabsf(r.y - qy); agg = fmaf(d, d, agg);
-                    d = fabsf(r.z - qz); agg = fmaf(d, d, agg);
+                    float dd = fabsf(r.x - qx);
+                    float agg = fmaf(dd, dd, 0.0f);
+                    dd = fabsf(r.y - qy); agg = fmaf(dd, dd, agg);
+                    dd = fabsf(r.z - qz); agg = fmaf(dd, dd, agg);
                     s = s + sqrtf(agg);
                 }
             } else {
@@ -101,14 +112,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
             const int oj = __shfl_xor(bj, o, 64);
             if (better(os, oj, bs, bj)) { bs = os; bj = oj; }
         }
-        if (cm3d_lane() == 0) { s_ws[threadIdx.x >> 6] = bs; s_wj[threadIdx.x >> 6] = bj; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < MD_THREADS / 64; ++w)
-                if (better(s_ws[w], s_wj[w], bs, bj)) { bs = s_ws[w]; bj = s_wj[w]; }
-            tile_best[t].s = bs;
-            tile_best[t].j = bj;
-        }
+        if (lane == 0) { tile_best[t].s = bs; tile_best[t].j = bj; }
     }
 }
 
@@ -140,11 +144,15 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
     centroid[3 * m + 0] = cx; centroid[3 * m + 1] = cy; centroid[3 * m + 2] = cz;
 }
 
+static inline int64_t md_tile_cap(int32_t n_masks, int32_t idx_cap)
+{
+    return (int64_t)n_masks + (int64_t)idx_cap / CM3D_MEDOID_TILE + 1;
+}
+
 extern "C" int64_t cm3d_medoid_workspace_bytes(int32_t n_masks, int32_t idx_cap)
 {
     if (n_masks <= 0 || idx_cap <= 0) return 0;
-    int64_t tiles = (int64_t)n_masks + (int64_t)idx_cap / CM3D_MEDOID_TILE + 1;
-    return tiles * (int64_t)sizeof(TileBest);
+    return md_tile_cap(n_masks, idx_cap) * (int64_t)(sizeof(TileBest) + sizeof(TileDesc));
 }
 
 extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_frame, int32_t n_masks,
@@ -157,14 +165,19 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     if (n_masks <= 0 || idx_cap <= 0) return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_medoid_workspace_bytes(n_masks, idx_cap)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t tile_cap64 = (int64_t)n_masks + (int64_t)idx_cap / CM3D_MEDOID_TILE + 1;
+    const int64_t tile_cap64 = md_tile_cap(n_masks, idx_cap);
     const int tile_cap = (int)(tile_cap64 > 0x7FFFFFFF ? 0x7FFFFFFF : tile_cap64);
-    int grid = tile_cap < 8192 ? tile_cap : 8192;
+    TileDesc *desc = (TileDesc *)workspace;
+    TileBest *best = (TileBest *)(desc + tile_cap);
+    hipLaunchKernelGGL(k_medoid_desc, dim3((n_masks + 255) / 256), dim3(256), 0, st, n_masks, hit_off, tile_off, idx_cap, tile_cap, desc);
+    CM3D_CHECK_LAUNCH();
+    int grid = (tile_cap + MD_WAVES - 1) / MD_WAVES;
+    if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_medoid_tiles, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
-                       hit_off, tile_off, hit_idx, idx_cap, (TileBest *)workspace, tile_cap, colsum_opt);
+                       tile_off, hit_idx, desc, best, tile_cap, colsum_opt);
     CM3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_medoid_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, (const float4 *)points, pt_off, mask_frame,
-                       n_masks, hit_off, tile_off, hit_idx, idx_cap, (const TileBest *)workspace, tile_cap, medoid_pos, centroid);
+                       n_masks, hit_off, tile_off, hit_idx, idx_cap, best, tile_cap, medoid_pos, centroid);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

@@ -5,15 +5,15 @@
 // Here every point is read ONCE (float4, coalesced), projected into every camera of its frame,
 // and tested against the bit-packed eroded masks of that camera (bounding-box test first, so
 // only points that can hit a mask touch mask memory).  Results leave as one hit word per point
-// per 32 masks; k_compact_hits turns them into ascending index lists (wave ballot + mbcnt
-// prefix, two passes, no atomics on the output order).
+// per 32 masks plus one count per (1024-point block, mask); an exclusive scan of those counts
+// gives every block its exact output offset, and k_compact_hits writes the ascending index
+// lists with wave ballot + mbcnt prefixes (no atomics on the output order, deterministic).
 // HBM-bound: algorithmic bytes = 16 N + n*ceil(W*H/8) + 4*sum(M) + 4(n+1) per frame.
 #include "common.h"
 
 #define PH_THREADS 256
 #define PH_PT 4                                   // points per thread
 #define PH_BLOCK_PTS (PH_THREADS * PH_PT)
-#define PH_BUCKETS (32 * CM3D_MAX_CAMS)           // (plane, camera) buckets of a frame's masks
 
 // One pinhole projection through the reference's float32 op chain.  Returns the pixel code
 // (iv << 16 | iu) or -1.  cm = camera record in LDS.
@@ -45,19 +45,20 @@ static __device__ __forceinline__ int project_pixel(const float *cm, float4 pt, 
     return (iv << 16) | iu;
 }
 
-// grid (ceil(max_pts/1024), F).  A block owns 1024 consecutive points of one frame, 4 per thread
-// (4 independent gathers in flight), and walks the frame's masks bucketed by (plane, camera).
+// grid (G, F).  A block walks 1024-point chunks of one frame (chunk = blockIdx.x, += gridDim.x),
+// 4 points per thread (4 independent mask gathers in flight).  Per-frame tables (cameras, mask
+// cameras, mask bounding boxes) are staged into LDS once per block.
 __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     const float4 *__restrict__ points, const int32_t *__restrict__ pt_off, int n_points_total,
     const float *__restrict__ cams, int n_cams, const int32_t *__restrict__ mask_off,
     const int32_t *__restrict__ mask_cam, const int4 *__restrict__ bbox, const uint32_t *__restrict__ packed,
-    int W, int H, int Wp, float min_dist, int nm_cap, uint32_t *__restrict__ hit_words, int32_t *__restrict__ hit_count,
-    int32_t *__restrict__ status)
+    int W, int H, int Wp, float min_dist, int nm_cap, int nblk_max, uint32_t *__restrict__ hit_words,
+    int32_t *__restrict__ hit_count, int32_t *__restrict__ blk_cnt, int32_t *__restrict__ status)
 {
     const int f = blockIdx.y;
     const int p0 = pt_off[f], n = pt_off[f + 1] - p0;
-    const int base = blockIdx.x * PH_BLOCK_PTS;
-    if (base >= n) return;
+    const int nblk = (n + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
+    if ((int)blockIdx.x >= nblk) return;
     const int m0 = mask_off[f];
     int nm = mask_off[f + 1] - m0;
     if (nm > nm_cap) {                       // more masks than the caller's `planes` allows
@@ -67,91 +68,77 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     const int planes = (nm + 31) >> 5;
 
     __shared__ float s_cam[CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
-    __shared__ int s_boff[PH_BUCKETS + 1];              // bucket start offsets (exclusive scan)
-    __shared__ int s_bcnt[PH_BUCKETS];
-    // dynamic LDS: bbox[nm_cap] (bucket-sorted), pixel codes [n_cams][PH_BLOCK_PTS], order[nm_cap]
+    // dynamic LDS: bbox[nm_cap], pixel codes [n_cams][PH_BLOCK_PTS], mask camera[nm_cap], counts[nm_cap]
     extern __shared__ __align__(16) unsigned char s_dyn[];
     int4 *s_bbox = reinterpret_cast<int4 *>(s_dyn);
     int *s_pix = reinterpret_cast<int *>(s_dyn + (size_t)nm_cap * sizeof(int4));
-    short *s_order = reinterpret_cast<short *>(s_dyn + (size_t)nm_cap * sizeof(int4) + (size_t)n_cams * PH_BLOCK_PTS * sizeof(int));
+    int *s_mcam = s_pix + (size_t)n_cams * PH_BLOCK_PTS;
+    int *s_cnt = s_mcam + nm_cap;
 
+    // points of the first chunk are requested before the table staging so that both latencies overlap
+    float4 pt[PH_PT];
+#pragma unroll
+    for (int j = 0; j < PH_PT; ++j) {
+        const int i0 = (int)blockIdx.x * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x;
+        pt[j] = i0 < n ? points[p0 + i0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS)
         s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
-    for (int q = threadIdx.x; q < PH_BUCKETS; q += PH_THREADS) s_bcnt[q] = 0;
-    __syncthreads();
-    // bucket = plane * MAX_CAMS + camera; counting sort with LDS atomics (order inside a bucket is free)
     for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
-        const int c = mask_cam[m0 + k];
-        if (c < 0 || c >= n_cams) atomicOr(&status[0], 4);
-        else atomicAdd(&s_bcnt[(k >> 5) * CM3D_MAX_CAMS + c], 1);
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {             // exclusive scan of the 256 bucket counts by one wave (4 per lane)
-        int v[4], sum = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] = s_bcnt[threadIdx.x * 4 + q]; sum += v[q]; }
-        int ex = cm3d_wave_incl_scan(sum) - sum;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { s_boff[threadIdx.x * 4 + q] = ex; ex += v[q]; }
-        if (threadIdx.x == 63) s_boff[PH_BUCKETS] = ex;
-    }
-    __syncthreads();
-    for (int q = threadIdx.x; q < PH_BUCKETS; q += PH_THREADS) s_bcnt[q] = 0;
-    __syncthreads();
-    for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
-        const int c = mask_cam[m0 + k];
-        if (c < 0 || c >= n_cams) continue;
-        const int b = (k >> 5) * CM3D_MAX_CAMS + c;
-        const int pos = s_boff[b] + atomicAdd(&s_bcnt[b], 1);
-        s_order[pos] = (short)k;
-        s_bbox[pos] = bbox[m0 + k];
+        int c = mask_cam[m0 + k];
+        int4 bb = bbox[m0 + k];
+        if (c < 0 || c >= n_cams) { atomicOr(&status[0], 4); c = 0; bb = make_int4(1, 1, 0, 0); }
+        s_mcam[k] = c; s_bbox[k] = bb; s_cnt[k] = 0;
     }
     __syncthreads();
 
     const float wlim = (float)(W - 1), hlim = (float)(H - 1);
-    int idx[PH_PT];
-    bool in_range[PH_PT];
-    float4 pt[PH_PT];
-#pragma unroll
-    for (int j = 0; j < PH_PT; ++j) {
-        idx[j] = base + j * PH_THREADS + threadIdx.x;
-        in_range[j] = idx[j] < n;
-        pt[j] = in_range[j] ? points[p0 + idx[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    uint32_t cam_any = 0;     // wave-uniform: cameras that see at least one point of this wave
-#pragma unroll 1
-    for (int c = 0; c < n_cams; ++c) {
-        bool any = false;
+    const size_t mask_words = (size_t)H * Wp;
+    for (int chunk = blockIdx.x; chunk < nblk; chunk += gridDim.x) {
+        const int base = chunk * PH_BLOCK_PTS;
+        int idx[PH_PT];
+        bool in_range[PH_PT];
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) {
-            const int px = project_pixel(s_cam + c * CM3D_CAM_STRIDE, pt[j], in_range[j], min_dist, wlim, hlim);
-            s_pix[c * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x] = px;     // read back by this thread only
-            any = any || px >= 0;
+            idx[j] = base + j * PH_THREADS + threadIdx.x;
+            in_range[j] = idx[j] < n;
         }
-        if (__ballot(any)) cam_any |= 1u << c;
-    }
-
-    const size_t mask_words = (size_t)H * Wp;
-    for (int plane = 0; plane < planes; ++plane) {
-        uint32_t bits[PH_PT];
-#pragma unroll
-        for (int j = 0; j < PH_PT; ++j) bits[j] = 0;
+        uint32_t cam_any = 0;     // wave-uniform: cameras that see at least one point of this wave
 #pragma unroll 1
         for (int c = 0; c < n_cams; ++c) {
-            if (!((cam_any >> c) & 1u)) continue;            // wave-uniform
-            int px[PH_PT];
+            bool any = false;
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) px[j] = s_pix[c * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x];
-            const int b = plane * CM3D_MAX_CAMS + c;
-            const int k0 = s_boff[b], k1 = s_boff[b + 1];
-            for (int kk = k0; kk < k1; ++kk) {
-                const int k = s_order[kk];
-                const int4 bb = s_bbox[kk];
+            for (int j = 0; j < PH_PT; ++j) {
+                const int px = project_pixel(s_cam + c * CM3D_CAM_STRIDE, pt[j], in_range[j], min_dist, wlim, hlim);
+                s_pix[c * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x] = px;     // read back by this thread only
+                any = any || px >= 0;
+            }
+            if (__ballot(any)) cam_any |= 1u << c;
+        }
+        // prefetch the next chunk's points (if this block has one) under the mask phase
+        if (chunk + (int)gridDim.x < nblk) {
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) {
+                const int i1 = (chunk + (int)gridDim.x) * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x;
+                pt[j] = i1 < n ? points[p0 + i1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        for (int plane = 0; plane < planes; ++plane) {
+            uint32_t bits[PH_PT];
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) bits[j] = 0;
+            const int kend = min(nm, plane * 32 + 32);
+            for (int k = plane * 32; k < kend; ++k) {
+                const int c = s_mcam[k];
+                if (!((cam_any >> c) & 1u)) continue;            // wave-uniform
+                const int4 bb = s_bbox[k];
                 const uint32_t *mw = packed + (size_t)(m0 + k) * mask_words;
                 uint32_t word[PH_PT];
+                int px[PH_PT];
                 bool cand[PH_PT];
 #pragma unroll
                 for (int j = 0; j < PH_PT; ++j) {
+                    px[j] = s_pix[c * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x];
                     const int iu = px[j] & 0xFFFF, iv = px[j] >> 16;
                     cand[j] = px[j] >= 0 && iu >= bb.x && iu <= bb.z && iv >= bb.y && iv <= bb.w;
                     word[j] = 0;
@@ -164,12 +151,21 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                     bits[j] |= (hit ? 1u : 0u) << (k & 31);
                     cnt += __popcll(__ballot(hit));
                 }
-                if (cnt && cm3d_lane() == 0) atomicAdd(&hit_count[m0 + k], cnt);
+                if (cnt && cm3d_lane() == 0) atomicAdd(&s_cnt[k], cnt);
             }
-        }
 #pragma unroll
-        for (int j = 0; j < PH_PT; ++j)
-            if (in_range[j]) hit_words[(size_t)plane * n_points_total + p0 + idx[j]] = bits[j];
+            for (int j = 0; j < PH_PT; ++j)
+                if (in_range[j]) hit_words[(size_t)plane * n_points_total + p0 + idx[j]] = bits[j];
+        }
+        __syncthreads();
+        // per-(block, mask) counts: exact output offsets come from their exclusive scan
+        for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
+            const int c = s_cnt[k];
+            blk_cnt[((size_t)f * nblk_max + chunk) * nm_cap + k] = c;
+            if (c) atomicAdd(&hit_count[m0 + k], c);
+            s_cnt[k] = 0;
+        }
+        __syncthreads();
     }
 }
 
@@ -200,59 +196,111 @@ __global__ __launch_bounds__(1024) void k_scan_hits(const int32_t *__restrict__ 
     }
 }
 
-// grid (planes, F), 16 waves: wave w owns a contiguous run of 64-point groups.
-// pass 1 counts per (wave, mask), LDS prefix over waves, pass 2 writes in order.
-__global__ __launch_bounds__(1024) void k_compact_hits(const uint32_t *__restrict__ hit_words, int n_points_total,
-                                                       const int32_t *__restrict__ pt_off,
-                                                       const int32_t *__restrict__ mask_off,
-                                                       const int32_t *__restrict__ hit_off,
-                                                       int32_t *__restrict__ hit_idx, int idx_cap)
+// thread per mask: turn its per-block counts into exclusive output offsets, in place.
+__global__ __launch_bounds__(256) void k_blk_prefix(const int32_t *__restrict__ pt_off, const int32_t *__restrict__ mask_off,
+                                                    const int32_t *__restrict__ hit_off, int nm_cap, int nblk_max,
+                                                    int32_t *__restrict__ blk_cnt)
 {
-    const int plane = blockIdx.x, f = blockIdx.y;
+    // grid (ceil(nm_cap/256), F): thread = mask k of frame f
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int m0 = mask_off[f];
-    const int nm = min(mask_off[f + 1] - m0, CM3D_MAX_MASKS_PER_FRAME);
-    if (plane * 32 >= nm) return;
-    const int p0 = pt_off[f], n = pt_off[f + 1] - p0;
-    const uint32_t *hw = hit_words + (size_t)plane * n_points_total + p0;
-    const int wave = threadIdx.x >> 6, lane = cm3d_lane();
-    const int G = (n + 63) >> 6, gpw = (G + 15) >> 4;
-    const int g0 = wave * gpw, g1 = min(g0 + gpw, G);
+    const int nm = min(mask_off[f + 1] - m0, nm_cap);
+    if (k >= nm) return;
+    const int n = pt_off[f + 1] - pt_off[f];
+    const int nblk = (n + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
+    int run = hit_off[m0 + k];
+    int32_t *p = blk_cnt + (size_t)f * nblk_max * nm_cap + k;
+    for (int b = 0; b < nblk; ++b) {
+        const int c = p[(size_t)b * nm_cap];
+        p[(size_t)b * nm_cap] = run;
+        run += c;
+    }
+}
 
-    __shared__ int s_cnt[16][32];
-    int mycnt = 0;                         // lane b < 32 counts the hits of mask bit b
-    for (int g = g0; g < g1; ++g) {
-        const int idx = g * 64 + lane;
-        const uint32_t w = idx < n ? hw[idx] : 0u;
-        uint32_t orw = cm3d_wave_or(w);
-        while (orw) {
-            const int b = __builtin_ctz(orw);
-            orw &= orw - 1;
-            const uint64_t mk = __ballot((w >> b) & 1u);
-            if (lane == b) mycnt += __popcll(mk);
-        }
-    }
-    if (lane < 32) s_cnt[wave][lane] = mycnt;
-    __syncthreads();
-    int run = 0;
-    if (lane < 32) {
-        for (int k = 0; k < wave; ++k) run += s_cnt[k][lane];
-        if (plane * 32 + lane < nm) run += hit_off[m0 + plane * 32 + lane];
-    }
-    for (int g = g0; g < g1; ++g) {
-        const int idx = g * 64 + lane;
-        const uint32_t w = idx < n ? hw[idx] : 0u;
-        uint32_t orw = cm3d_wave_or(w);
-        while (orw) {
-            const int b = __builtin_ctz(orw);
-            orw &= orw - 1;
-            const bool mine = (w >> b) & 1u;
-            const uint64_t mk = __ballot(mine);
-            const int basepos = __builtin_amdgcn_readlane(run, b);
-            if (mine) {
-                const int pos = basepos + cm3d_mbcnt(mk);
-                if (pos < idx_cap) hit_idx[pos] = idx;
+// grid (nblk_max, F): the same 1024 points and the same thread<->point map as k_project_hits.
+// Order inside a block is (j, wave, lane); per present mask bit: counts per (j, wave) through
+// LDS, then ballot + mbcnt positions on top of the block's exclusive offset.
+__global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__restrict__ hit_words, int n_points_total,
+                                                             const int32_t *__restrict__ pt_off,
+                                                             const int32_t *__restrict__ mask_off, int nm_cap, int nblk_max,
+                                                             const int32_t *__restrict__ blk_base,
+                                                             int32_t *__restrict__ hit_idx, int idx_cap)
+{
+    const int f = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = pt_off[f], n = pt_off[f + 1] - p0;
+    const int base = chunk * PH_BLOCK_PTS;
+    if (base >= n) return;
+    const int m0 = mask_off[f];
+    const int nm = min(mask_off[f + 1] - m0, nm_cap);
+    const int planes = (nm + 31) >> 5;
+    const int wave = threadIdx.x >> 6, lane = cm3d_lane();
+    __shared__ int s_c[PH_PT][PH_THREADS / 64][32];
+    int idx[PH_PT];
+#pragma unroll
+    for (int j = 0; j < PH_PT; ++j) idx[j] = base + j * PH_THREADS + threadIdx.x;
+    for (int plane = 0; plane < planes; ++plane) {
+        const uint32_t *hw = hit_words + (size_t)plane * n_points_total + p0;
+        uint32_t w[PH_PT];
+        uint32_t any = 0;
+#pragma unroll
+        for (int j = 0; j < PH_PT; ++j) { w[j] = idx[j] < n ? hw[idx[j]] : 0u; any |= w[j]; }
+        const uint32_t orw = cm3d_wave_or(any);
+        int mycnt[PH_PT];
+#pragma unroll
+        for (int j = 0; j < PH_PT; ++j) mycnt[j] = 0;
+        for (uint32_t r = orw; r; r &= r - 1) {
+            const int b = __builtin_ctz(r);
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) {
+                const int c = __popcll(__ballot((w[j] >> b) & 1u));
+                if (lane == b) mycnt[j] = c;
             }
-            if (lane == b) run += __popcll(mk);
+        }
+        __syncthreads();               // previous plane's readers are done with s_c
+        if (lane < 32) {
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) s_c[j][wave][lane] = mycnt[j];
+        }
+        __syncthreads();
+        if (orw) {
+            // lane b < 32: running output position of mask bit b for this wave's (j = 0) segment
+            int run = 0;
+            int after[PH_PT];          // increments between this wave's consecutive j segments
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) after[j] = 0;
+            if (lane < 32) {
+                const int k = plane * 32 + lane;
+                run = k < nm ? blk_base[((size_t)f * nblk_max + chunk) * nm_cap + k] : 0;
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j) {
+                    int before = 0, rest = 0;
+                    for (int w2 = 0; w2 < PH_THREADS / 64; ++w2) {
+                        const int c = s_c[j][w2][lane];
+                        if (w2 < wave) before += c;
+                        if (w2 > wave) rest += c;
+                    }
+                    if (j == 0) run += before;
+                    // from the end of (j, wave) to the start of (j+1, wave): the waves after us in j and
+                    // the waves before us in j+1
+                    after[j] = rest;
+                    if (j > 0) after[j - 1] += before;
+                }
+            }
+            for (uint32_t r = orw; r; r &= r - 1) {
+                const int b = __builtin_ctz(r);
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j) {
+                    const bool mine = (w[j] >> b) & 1u;
+                    const uint64_t mk = __ballot(mine);
+                    const int basepos = __builtin_amdgcn_readlane(run, b);
+                    if (mine) {
+                        const int pos = basepos + cm3d_mbcnt(mk);
+                        if (pos >= 0 && pos < idx_cap) hit_idx[pos] = idx[j];
+                    }
+                    if (lane == b) run += __popcll(mk) + after[j];
+                }
+            }
         }
     }
 }
@@ -272,42 +320,72 @@ extern "C" int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_m
     return CM3D_OK;
 }
 
+static inline int ph_nm_cap(int planes)
+{
+    int c = planes * 32;
+    return c > CM3D_MAX_MASKS_PER_FRAME ? CM3D_MAX_MASKS_PER_FRAME : c;
+}
+
+extern "C" int64_t cm3d_project_workspace_bytes(int32_t n_frames, int32_t max_pts_per_frame, int32_t planes)
+{
+    if (n_frames <= 0 || max_pts_per_frame <= 0 || planes <= 0) return 0;
+    const int64_t nblk_max = (max_pts_per_frame + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
+    return (int64_t)n_frames * nblk_max * ph_nm_cap(planes) * (int64_t)sizeof(int32_t);
+}
+
 extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
                                  int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off,
                                  const int32_t *mask_cam, const int32_t *bbox, const uint32_t *packed, int32_t n_masks,
                                  int32_t W, int32_t H, float min_dist, int32_t planes, uint32_t *hit_words,
-                                 int32_t *hit_count, int32_t *status, cm3d_stream_t stream)
+                                 int32_t *hit_count, int32_t *status, void *workspace, int64_t workspace_bytes,
+                                 cm3d_stream_t stream)
 {
-    if (!points || !pt_off || !cams || !mask_off || !mask_cam || !bbox || !packed || !hit_words || !hit_count || !status)
+    if (!points || !pt_off || !cams || !mask_off || !mask_cam || !bbox || !packed || !hit_words || !hit_count || !status ||
+        !workspace)
         return CM3D_ERR_ARG;
     if (n_frames <= 0 || max_pts_per_frame <= 0 || n_points_total <= 0 || n_cams <= 0 || n_cams > CM3D_MAX_CAMS ||
         n_masks <= 0 || W <= 1 || H <= 1 || W > 32767 || H > 32767 || planes <= 0)
         return CM3D_ERR_ARG;
+    if (workspace_bytes < cm3d_project_workspace_bytes(n_frames, max_pts_per_frame, planes)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int Wp = (W + 31) / 32;
-    dim3 grid((max_pts_per_frame + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS, n_frames);
-    int nm_cap = planes * 32;
-    if (nm_cap > CM3D_MAX_MASKS_PER_FRAME) nm_cap = CM3D_MAX_MASKS_PER_FRAME;
-    const size_t lds = (size_t)nm_cap * (sizeof(int4) + sizeof(short)) + (size_t)n_cams * PH_BLOCK_PTS * sizeof(int);
-    hipLaunchKernelGGL(k_project_hits, grid, dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off, n_points_total, cams,
-                       n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, nm_cap, hit_words, hit_count,
-                       status);
+    const int nblk_max = (max_pts_per_frame + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
+    const int nm_cap = ph_nm_cap(planes);
+    // enough blocks to fill the chip (256 CUs x ~8), each walking several chunks of its frame
+    int gx = nblk_max;
+    const long long max_blocks = 16384;          // beyond that blocks walk several chunks
+    if ((long long)gx * n_frames > max_blocks) gx = (int)((max_blocks + n_frames - 1) / n_frames);
+    if (gx > nblk_max) gx = nblk_max;
+    if (gx < 1) gx = 1;
+    const size_t lds = (size_t)nm_cap * (sizeof(int4) + 2 * sizeof(int)) + (size_t)n_cams * PH_BLOCK_PTS * sizeof(int);
+    hipLaunchKernelGGL(k_project_hits, dim3(gx, n_frames), dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off, n_points_total,
+                       cams, n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, nm_cap, nblk_max, hit_words,
+                       hit_count, (int32_t *)workspace, status);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }
 
 extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, const int32_t *pt_off, int32_t n_frames,
-                                 int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
+                                 int32_t max_pts_per_frame, int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
                                  const int32_t *hit_count, int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx,
-                                 int32_t idx_cap, int32_t *status, cm3d_stream_t stream)
+                                 int32_t idx_cap, int32_t *status, void *workspace, int64_t workspace_bytes,
+                                 cm3d_stream_t stream)
 {
-    if (!hit_words || !pt_off || !mask_off || !hit_count || !hit_off || !tile_off || !hit_idx || !status) return CM3D_ERR_ARG;
-    if (planes <= 0 || n_frames <= 0 || n_points_total <= 0 || n_masks <= 0 || idx_cap <= 0) return CM3D_ERR_ARG;
+    if (!hit_words || !pt_off || !mask_off || !hit_count || !hit_off || !tile_off || !hit_idx || !status || !workspace)
+        return CM3D_ERR_ARG;
+    if (planes <= 0 || n_frames <= 0 || max_pts_per_frame <= 0 || n_points_total <= 0 || n_masks <= 0 || idx_cap <= 0)
+        return CM3D_ERR_ARG;
+    if (workspace_bytes < cm3d_project_workspace_bytes(n_frames, max_pts_per_frame, planes)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    const int nblk_max = (max_pts_per_frame + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
+    const int nm_cap = ph_nm_cap(planes);
     hipLaunchKernelGGL(k_scan_hits, dim3(1), dim3(1024), 0, st, hit_count, n_masks, hit_off, tile_off, idx_cap, status);
     CM3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_compact_hits, dim3(planes, n_frames), dim3(1024), 0, st, hit_words, n_points_total, pt_off, mask_off,
-                       hit_off, hit_idx, idx_cap);
+    hipLaunchKernelGGL(k_blk_prefix, dim3((nm_cap + 255) / 256, n_frames), dim3(256), 0, st, pt_off, mask_off, hit_off, nm_cap,
+                       nblk_max, (int32_t *)workspace);
+    CM3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_compact_hits, dim3(nblk_max, n_frames), dim3(PH_THREADS), 0, st, hit_words, n_points_total, pt_off, mask_off,
+                       nm_cap, nblk_max, (const int32_t *)workspace, hit_idx, idx_cap);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

@@ -188,6 +188,8 @@ class LiftEngine:
         self.keep_colsum = keep_colsum
         self.b = None
         d = self.dev
+        self.side = torch.cuda.Stream(device=d)              # lane-grid build overlaps the point/mask stages
+        self.grid_done = torch.cuda.Event()
         self.prior_wlh = torch.from_numpy(self.classes.prior_wlh).to(d)
         self.is_vehicle = torch.from_numpy(self.classes.is_vehicle).to(d)
         self.nms_thr = torch.from_numpy(self.classes.nms_thr).to(d)
@@ -233,12 +235,19 @@ class LiftEngine:
         b.box = e(M, _lib.BOX_STRIDE, dtype=torch.float64); b.flags = e(M)
         L = self.lib
         ws = max(L.cm3d_sweep_prep_workspace_bytes(S, hb.max_rows_per_sweep), L.cm3d_rle_workspace_bytes(max(1, hb.rle_counts.size)),
-                 L.cm3d_medoid_workspace_bytes(M, b.idx_cap), L.cm3d_lane_nn_workspace_bytes(M))
+                 L.cm3d_medoid_workspace_bytes(M, b.idx_cap),
+                 L.cm3d_lane_nn_workspace_bytes(M))
         b.ws_bytes = int(ws)
         b.ws = torch.empty(b.ws_bytes, dtype=torch.uint8, device=d)
+        # per-(block, mask) hit counts: written by project_hits, consumed by compact_hits
+        b.pg_ws_bytes = int(L.cm3d_project_workspace_bytes(F, b.max_pts, b.planes))
+        b.pg_ws = torch.empty(max(b.pg_ws_bytes, 16), dtype=torch.uint8, device=d)
         # the RLE run ends stay alive across the whole pass, so they get their own buffer
         b.rle_ws_bytes = int(L.cm3d_rle_workspace_bytes(max(1, hb.rle_counts.size)))
         b.rle_ws = torch.empty(b.rle_ws_bytes, dtype=torch.uint8, device=d)
+        b.n_tables, b.n_lane = len(hb.lane_off) - 1, int(hb.lane.shape[0])
+        b.grid_bytes = int(L.cm3d_lane_grid_bytes(b.n_tables, b.n_lane))
+        b.grid = torch.empty(b.grid_bytes, dtype=torch.uint8, device=d)
         b.dense = dense_masks
         self.b = b
         return b
@@ -255,8 +264,17 @@ class LiftEngine:
 
     # -- the stages, in reference order
     def stage_begin(self, st):
+        """Resets the per-pass state and starts the lane-grid build on the side stream."""
         b = self.b
         check(self.lib.cm3d_batch_begin(_ptr(b.status), _ptr(b.hit_count), b.M, st), "cm3d_batch_begin")
+        main = torch.cuda.current_stream(self.dev)
+        self.side.wait_stream(main)          # the previous pass's lane queries have been issued before this point
+        with torch.cuda.stream(self.side):
+            self.stage_lane_grid(self.side.cuda_stream)
+            self.grid_done.record(self.side)
+
+    def wait_lane_grid(self):
+        torch.cuda.current_stream(self.dev).wait_event(self.grid_done)
 
     def stage_sweeps(self, st):
         b = self.b
@@ -281,14 +299,14 @@ class LiftEngine:
         b = self.b
         check(self.lib.cm3d_project_hits(_ptr(b.points), _ptr(b.pt_off), b.F, b.max_pts, b.pt_cap, _ptr(b.cams), b.hb.n_cams,
                                          _ptr(b.mask_off), _ptr(b.mask_cam), _ptr(b.bbox), _ptr(b.packed), b.M, b.W, b.H,
-                                         self.min_dist, b.planes, _ptr(b.hit_words), _ptr(b.hit_count), _ptr(b.status), st),
-              "cm3d_project_hits")
+                                         self.min_dist, b.planes, _ptr(b.hit_words), _ptr(b.hit_count), _ptr(b.status),
+                                         _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_project_hits")
 
     def stage_compact(self, st):
         b = self.b
-        check(self.lib.cm3d_compact_hits(_ptr(b.hit_words), b.planes, _ptr(b.pt_off), b.F, b.pt_cap, _ptr(b.mask_off), b.M,
-                                         _ptr(b.hit_count), _ptr(b.hit_off), _ptr(b.tile_off), _ptr(b.hit_idx), b.idx_cap,
-                                         _ptr(b.status), st), "cm3d_compact_hits")
+        check(self.lib.cm3d_compact_hits(_ptr(b.hit_words), b.planes, _ptr(b.pt_off), b.F, b.max_pts, b.pt_cap, _ptr(b.mask_off),
+                                         b.M, _ptr(b.hit_count), _ptr(b.hit_off), _ptr(b.tile_off), _ptr(b.hit_idx), b.idx_cap,
+                                         _ptr(b.status), _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_compact_hits")
 
     def stage_medoid(self, st):
         b = self.b
@@ -296,11 +314,18 @@ class LiftEngine:
                                    _ptr(b.hit_idx), b.idx_cap, _ptr(b.medoid_pos), _ptr(b.centroid), _ptr(b.colsum),
                                    _ptr(b.ws), b.ws_bytes, st), "cm3d_medoid")
 
+    def stage_lane_grid(self, st):
+        """Spatial index of the lane tables.  It depends on the lane tables only, so `run` issues it on
+        the side stream at the start of the pass; it overlaps the sweep / mask / projection stages."""
+        b = self.b
+        check(self.lib.cm3d_lane_grid_build(_ptr(b.lane), _ptr(b.lane_off), b.n_tables, b.n_lane, _ptr(b.grid), b.grid_bytes, st),
+              "cm3d_lane_grid_build")
+
     def stage_lanes(self, st):
         b = self.b
         check(self.lib.cm3d_lane_nn(_ptr(b.centroid), _ptr(b.medoid_pos), _ptr(b.mask_frame), b.M, _ptr(b.lane), _ptr(b.lane_off),
-                                    _ptr(b.frame_lane), _ptr(b.lane_idx), _ptr(b.lane_dist), _ptr(b.ws), b.ws_bytes, st),
-              "cm3d_lane_nn")
+                                    _ptr(b.frame_lane), b.n_tables, b.n_lane, _ptr(b.grid), _ptr(b.lane_idx),
+                                    _ptr(b.lane_dist), _ptr(b.ws), b.ws_bytes, st), "cm3d_lane_nn")
 
     def stage_boxes(self, st):
         b = self.b
@@ -320,6 +345,7 @@ class LiftEngine:
         self.stage_project(st)
         self.stage_compact(st)
         self.stage_medoid(st)
+        self.wait_lane_grid()
         self.stage_lanes(st)
         self.stage_boxes(st)
 

@@ -109,13 +109,15 @@ def points_in_masks(points, cams, packed, bbox, cam_nums, W, H, min_dist=2.3):
     cap = max(1024, N * 8)
     hit_idx = _e(cap)
     st = _st()
+    ws = _ws(L.cm3d_project_workspace_bytes(1, N, planes))
     check(L.cm3d_batch_begin(status.data_ptr(), hit_count.data_ptr(), n, st), "cm3d_batch_begin")
     check(L.cm3d_project_hits(pts.data_ptr(), pt_off.data_ptr(), 1, N, N, d_cams.data_ptr(), d_cams.shape[0], mask_off.data_ptr(),
                               mask_cam.data_ptr(), bbox.data_ptr(), packed.data_ptr(), n, W, H, float(np.float32(min_dist)), planes,
-                              hit_words.data_ptr(), hit_count.data_ptr(), status.data_ptr(), st), "cm3d_project_hits")
-    check(L.cm3d_compact_hits(hit_words.data_ptr(), planes, pt_off.data_ptr(), 1, N, mask_off.data_ptr(), n, hit_count.data_ptr(),
-                              hit_off.data_ptr(), tile_off.data_ptr(), hit_idx.data_ptr(), cap, status.data_ptr(), st),
-          "cm3d_compact_hits")
+                              hit_words.data_ptr(), hit_count.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), st),
+          "cm3d_project_hits")
+    check(L.cm3d_compact_hits(hit_words.data_ptr(), planes, pt_off.data_ptr(), 1, N, N, mask_off.data_ptr(), n, hit_count.data_ptr(),
+                              hit_off.data_ptr(), tile_off.data_ptr(), hit_idx.data_ptr(), cap, status.data_ptr(), ws.data_ptr(),
+                              ws.numel(), st), "cm3d_compact_hits")
     s = status.cpu().numpy()
     if s[0]:
         raise _lib.Cm3dError(f"status {s}")
@@ -160,8 +162,12 @@ def lane_yaws_distances_and_coords(all_centroids, all_lane_pts):
     lane_off, frame_lane = _t(np.array([0, lane.shape[0]], np.int32)), _t(np.array([0], np.int32))
     idx, dist = _e(K), _e(K, dtype=torch.float64)
     ws = _ws(L.cm3d_lane_nn_workspace_bytes(K))
+    grid = _ws(L.cm3d_lane_grid_bytes(1, lane.shape[0]))
+    check(L.cm3d_lane_grid_build(d_l.data_ptr(), lane_off.data_ptr(), 1, lane.shape[0], grid.data_ptr(), grid.numel(), _st()),
+          "cm3d_lane_grid_build")
     check(L.cm3d_lane_nn(d_c.data_ptr(), med.data_ptr(), mask_frame.data_ptr(), K, d_l.data_ptr(), lane_off.data_ptr(),
-                         frame_lane.data_ptr(), idx.data_ptr(), dist.data_ptr(), ws.data_ptr(), ws.numel(), _st()), "cm3d_lane_nn")
+                         frame_lane.data_ptr(), 1, lane.shape[0], grid.data_ptr(), idx.data_ptr(), dist.data_ptr(), ws.data_ptr(),
+                         ws.numel(), _st()), "cm3d_lane_nn")
     j = idx.cpu().numpy()
     return lane[j, 2], dist.cpu().numpy(), lane[j, :2]
 

@@ -42,7 +42,7 @@ extern "C" {
 #define CM3D_MAX_CAMS 8          /* cameras per frame                                  */
 #define CM3D_MAX_MASKS_PER_FRAME 1024
 #define CM3D_BOX_STRIDE 10       /* doubles per box record, see cm3d_box_nms           */
-#define CM3D_MEDOID_TILE 256     /* columns per medoid tile                            */
+#define CM3D_MEDOID_TILE 64      /* columns per medoid tile (one wave)                 */
 
 /* status word written by kernels (int32[4] in device memory, zero it per batch):
  *  [0] bit0: point capacity overflow (cm3d_sweep_prep), bit1: hit-index capacity
@@ -116,12 +116,16 @@ int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int3
  *        hands them to translate/rotate/view_points.
  *  hit_words uint32[planes][n_points_total] OUT, planes = (max masks per frame + 31)/32;
  *        bit (k&31) of hit_words[k>>5][p] = point p lies in mask mask_off[f]+k
- *  hit_count int32[n_masks] IN/OUT accumulated with atomics; zeroed by cm3d_batch_begin */
+ *  hit_count int32[n_masks] IN/OUT accumulated with atomics; zeroed by cm3d_batch_begin
+ *  workspace: cm3d_project_workspace_bytes(F, max_pts_per_frame, planes); it receives the per-(1024-point block,
+ *        mask) hit counts and must be handed unchanged to cm3d_compact_hits */
+int64_t cm3d_project_workspace_bytes(int32_t n_frames, int32_t max_pts_per_frame, int32_t planes);
 int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
                       int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off,
                       const int32_t *mask_cam, const int32_t *bbox, const uint32_t *packed, int32_t n_masks,
                       int32_t W, int32_t H, float min_dist, int32_t planes, uint32_t *hit_words,
-                      int32_t *hit_count, int32_t *status, cm3d_stream_t stream);
+                      int32_t *hit_count, int32_t *status, void *workspace, int64_t workspace_bytes,
+                      cm3d_stream_t stream);
 
 /* ---- a7-a8: ordered compaction of the hits ----------------------------------
  * Replaces torch.where + the two .cpu() index-tracking steps at 2d_to_3d.py:606,613-617.
@@ -129,9 +133,10 @@ int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_fram
  *  tile_off int32[n_masks+1] OUT exclusive scan of ceil(hit_count/CM3D_MEDOID_TILE)
  *  hit_idx  int32[idx_cap]   OUT ascending frame-local point indices of mask m at [hit_off[m], hit_off[m+1]) */
 int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, const int32_t *pt_off, int32_t n_frames,
-                      int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
+                      int32_t max_pts_per_frame, int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
                       const int32_t *hit_count, int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx,
-                      int32_t idx_cap, int32_t *status, cm3d_stream_t stream);
+                      int32_t idx_cap, int32_t *status, void *workspace, int64_t workspace_bytes,
+                      cm3d_stream_t stream);
 
 /* ---- a9: medoid --------------------------------------------------------------
  * Replaces get_medoid (2d_to_3d.py:116-119) + the gather at :620,645-647:
@@ -153,11 +158,21 @@ int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_
  *  lane_off  int32[T+1]         lane tables back to back
  *  frame_lane int32[F]          table of each frame
  *  lane_idx  int32[n_masks] OUT index into the frame's table (-1 for masks without centroid)
- *  lane_dist double[n_masks] OUT */
+ *  lane_dist double[n_masks] OUT
+ *  Exactly the brute-force result (first minimum of the float64 distance); internally the lane points are
+ *  binned into a uniform grid per table (cm3d_lane_grid_build) and searched in growing rings, one wave per
+ *  centroid; centroids farther than ~10 cells from every lane fall back to a brute-force kernel.
+ *  grid: the buffer cm3d_lane_grid_build filled; workspace: cm3d_lane_nn_workspace_bytes(n_masks) */
+/* Spatial index of the lane tables (uniform grid per table, points in cell order): built by one
+ * workgroup per table; depends only on the lane tables, so a driver may build it on a side stream. */
+int64_t cm3d_lane_grid_bytes(int32_t n_tables, int32_t n_lane_points);
+int cm3d_lane_grid_build(const float *lane, const int32_t *lane_off, int32_t n_tables, int32_t n_lane_points, void *grid,
+                         int64_t grid_bytes, cm3d_stream_t stream);
 int64_t cm3d_lane_nn_workspace_bytes(int32_t n_masks);
 int cm3d_lane_nn(const float *centroid, const int32_t *medoid_pos, const int32_t *mask_frame, int32_t n_masks,
-                 const float *lane, const int32_t *lane_off, const int32_t *frame_lane, int32_t *lane_idx,
-                 double *lane_dist, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream);
+                 const float *lane, const int32_t *lane_off, const int32_t *frame_lane, int32_t n_tables,
+                 int32_t n_lane_points, const void *grid, int32_t *lane_idx, double *lane_dist, void *workspace,
+                 int64_t workspace_bytes, cm3d_stream_t stream);
 
 /* ---- a11-a15: box assembly + class-aware circle NMS ----------------------------
  * Replaces stage 2 (2d_to_3d.py:745-817: shape prior, lane-yaw rotation, push_centroid

@@ -41,7 +41,7 @@ def test_argument_validation_never_launches():
     assert L.cm3d_batch_begin(0, 0, 0, 0) == -1
     assert L.cm3d_rle_workspace_bytes(100) == 400 + 800
     assert L.cm3d_sweep_prep_workspace_bytes(3, 2048) == (2 * 3 * 2 + 2) * 4
-    assert L.cm3d_medoid_workspace_bytes(10, 1000) > 0 and L.cm3d_lane_nn_workspace_bytes(10) > 0
+    assert L.cm3d_medoid_workspace_bytes(10, 1000) > 0 and L.cm3d_lane_nn_workspace_bytes(10) > 0 and L.cm3d_lane_grid_bytes(1, 1000) > 0
 
 
 def test_product_path_fails_loudly_without_gpu():

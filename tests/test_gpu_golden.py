@@ -109,3 +109,25 @@ def test_erode_and_decode_kernels_equal_oracle(oracle):
             ys, xs = np.nonzero(e)
             want = [xs.min(), ys.min(), xs.max(), ys.max()] if xs.size else [0x7FFFFFFF, 0x7FFFFFFF, -1, -1]
             assert bbox.cpu().numpy()[i].tolist() == want and bbox2.cpu().numpy()[i].tolist() == want
+
+
+def test_lane_nn_grid_equals_brute_force(oracle):
+    """The grid/ring search must return exactly what the float64 brute force (the oracle, pinned to the
+    reference by G6) returns: table sizes from 1 point to 50k, far-away centroids, centroids on lane
+    points, duplicates (first index wins), several tables in one call."""
+    from cm3d_amd import ops, synthetic as syn
+    rng = np.random.default_rng(0)
+    for trial in range(10):
+        L = int([1, 7, 300, 5000, 50000][trial % 5])
+        lane = syn.make_lane_table([600.0, 1600.0], L, seed=trial, extent=float([50, 200, 450][trial % 3]))
+        if L > 3:
+            lane[L // 2] = lane[L // 3]
+        K = 300
+        cent = np.stack([600 + rng.uniform(-500, 500, K), 1600 + rng.uniform(-500, 500, K), np.zeros(K)], 1).astype(np.float32)
+        lane32 = lane.astype(np.float32)
+        cent[:20, :2] = lane32[rng.integers(0, L, 20), :2]
+        cent[20:40, :2] = ((lane32[rng.integers(0, L, 20), :2].astype(np.float64) + lane32[rng.integers(0, L, 20), :2]) / 2).astype(np.float32)
+        yaws, dists, coords = ops.lane_yaws_distances_and_coords(cent, lane)
+        j, d = oracle.lane_nn(cent, lane)
+        assert np.array_equal(dists, d), f"trial {trial} L={L}: {(dists != d).sum()} distances differ"
+        assert np.array_equal(yaws, lane32[j, 2]) and np.array_equal(coords, lane32[j, :2]), f"trial {trial}"
