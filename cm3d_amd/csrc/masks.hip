@@ -1,16 +1,19 @@
 // a1/a3/f1: mask expansion, 3x3 erosion and bit-packing.
 //   reference: pycocotools decode at src/nuscenes/2d_to_3d.py:425, cv2.erode at :526-527,
 //   bool/transpose/H2D at :542-544.
-// All three kernels are HBM-bound streaming kernels (no MFMA):
+// HBM-bound streaming kernels (no MFMA):
 //   k_erode_pack      reads n*W*H dense bytes once (+ 2 halo rows per band), writes n*H*Wp*4
 //   k_rle_to_dense    reads the run ends (KBs), writes n*W*H
-//   k_rle_erode_pack  reads the run ends (KBs), writes n*H*Wp*4
-// A band of packed rows lives in LDS; the erosion is 9 word reads + shifts per output word.
+//   k_rle_erode_pack  reads the run ends (KBs), writes only the rectangle of packed words that can
+//                     hold an eroded pixel (rows/words outside a mask's bbox are never read downstream)
+// A tile of packed rows (plus a one-word halo column on each side) lives in LDS; the erosion is
+// 9 word reads + shifts per output word; out-of-image neighbours count as set (cv2's border rule).
 #include "common.h"
 
 #define EP_THREADS 256
 #define EP_MAX_WP 128          // supports W <= 4096
-#define EP_LDS_WORDS 8192      // at most 32 KiB of packed rows per workgroup (dynamic LDS, sized per launch)
+#define EP_LDS_WORDS 8192      // dense kernel: at most 32 KiB of packed rows per workgroup (dynamic LDS)
+#define RLE_LDS_WORDS 4096     // RLE kernel: 16 KiB tiles (they are as narrow as the mask's rectangle)
 
 // one bit per non-zero byte of a 16-byte chunk -> 16 bits
 static __device__ __forceinline__ uint32_t pack16(uint4 v)
@@ -19,38 +22,34 @@ static __device__ __forceinline__ uint32_t pack16(uint4 v)
         // 0x01 in every non-zero byte, then gather the four flags into a nibble
         uint32_t t = ((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w;
         t = (t >> 7) & 0x01010101u;
-        return (t * 0x01020408u) >> 24;   // bit k = byte k != 0  (erode_pack)
+        return (t * 0x01020408u) >> 24;   // bit k = byte k != 0
     };
     return (nz4(v.x) & 0xF) | ((nz4(v.y) & 0xF) << 4) | ((nz4(v.z) & 0xF) << 8) | ((nz4(v.w) & 0xF) << 12);
 }
 
-// Erode the LDS band and write rows [y0, y0+rows) of one mask; also reduces the bbox.
-// s_rows holds packed rows y0-1 .. y0+rows (row index r = y - (y0-1)), rows outside the
-// image are all-ones (the reference's erosion ignores out-of-image neighbours).
-static __device__ __forceinline__ void erode_band_store(const uint32_t *s_rows, int Wp, int W, int H, int y0, int rows,
-                                                         uint32_t *__restrict__ out_mask, int32_t *__restrict__ bbox4)
+// LDS tile: rows+2 rows of lw = wc + 2 words.  LDS row r holds image row ya + r, column c holds packed
+// word xw0 - 1 + c of that row.  Erodes LDS rows 1..rows / columns 1..wc, stores them, reduces the bbox.
+static __device__ __forceinline__ void erode_tile_store(const uint32_t *s_rows, int lw, int wc, int xw0, int ya, int rows, int W,
+                                                         int Wp, uint32_t *__restrict__ out_mask, int32_t *__restrict__ bbox4)
 {
     const uint32_t tail_mask = (W & 31) ? ((1u << (W & 31)) - 1u) : 0xFFFFFFFFu;
     int minx = 0x7FFFFFFF, miny = 0x7FFFFFFF, maxx = -1, maxy = -1;
-    const int nwords = rows * Wp;
+    const int nwords = rows * wc;
     for (int q = threadIdx.x; q < nwords; q += EP_THREADS) {
-        const int r = q / Wp, xw = q - r * Wp;
+        const int r = q / wc, c = q - r * wc;        // output row ya + 1 + r, word xw0 + c
         uint32_t e = 0xFFFFFFFFu;
 #pragma unroll
         for (int dr = 0; dr < 3; ++dr) {
-            const uint32_t *row = s_rows + (r + dr) * Wp;
-            uint32_t c = row[xw];
-            // neighbours beyond the image edge count as set
-            uint32_t l = xw > 0 ? row[xw - 1] : 0xFFFFFFFFu;
-            uint32_t rr = xw < Wp - 1 ? row[xw + 1] : 0xFFFFFFFFu;
-            uint32_t left = (c << 1) | (l >> 31);      // pixel x-1
-            uint32_t right = (c >> 1) | (rr << 31);    // pixel x+1
-            e &= c & left & right;
+            const uint32_t *row = s_rows + (r + dr) * lw + c;      // row[0] left, row[1] centre, row[2] right
+            const uint32_t ce = row[1];
+            const uint32_t left = (ce << 1) | (row[0] >> 31);      // pixel x-1
+            const uint32_t right = (ce >> 1) | (row[2] << 31);     // pixel x+1
+            e &= ce & left & right;
         }
+        const int xw = xw0 + c, y = ya + 1 + r;
         if (xw == Wp - 1) e &= tail_mask;
-        out_mask[(size_t)(y0 + r) * Wp + xw] = e;
+        out_mask[(size_t)y * Wp + xw] = e;
         if (e) {
-            int y = y0 + r;
             minx = min(minx, xw * 32 + __builtin_ctz(e));
             maxx = max(maxx, xw * 32 + 31 - __builtin_clz(e));
             miny = min(miny, y);
@@ -75,7 +74,7 @@ __global__ void k_bbox_init(int32_t *__restrict__ bbox, int n)
 }
 
 // grid (bands, n_masks).  Fast path W % 32 == 0: 16-byte coalesced loads, 16 bits per lane,
-// lane pairs merged with one DPP-class shuffle.  Other widths: byte loads (parity sizes only).
+// lane pairs merged with one shuffle.  Other widths: byte loads (parity sizes only).
 __global__ __launch_bounds__(EP_THREADS) void k_erode_pack(const uint8_t *__restrict__ dense, int W, int H, int Wp,
                                                             int band_rows, uint32_t *__restrict__ packed,
                                                             int32_t *__restrict__ bbox)
@@ -85,11 +84,15 @@ __global__ __launch_bounds__(EP_THREADS) void k_erode_pack(const uint8_t *__rest
     const int y0 = blockIdx.x * band_rows;
     const int rows = min(band_rows, H - y0);
     const uint8_t *img = dense + (size_t)m * W * H;
-    const int lrows = rows + 2;                 // with halo
+    const int lrows = rows + 2, lw = Wp + 2;
+    for (int r = threadIdx.x; r < lrows; r += EP_THREADS) {        // halo columns lie outside the image
+        s_rows[r * lw] = 0xFFFFFFFFu;
+        s_rows[r * lw + lw - 1] = 0xFFFFFFFFu;
+    }
     if ((W & 31) == 0) {
         const int cpr = W >> 4;                 // 16-byte chunks per row
         const int nchunks = lrows * cpr;        // even, since cpr is even
-        // the band (with halo) is one contiguous byte range of the image: stream it with
+        // the band (with halo rows) is one contiguous byte range of the image: stream it with
         // 4 independent 16-byte loads in flight per lane
         const int y_lo = y0 - 1;
         for (int q0 = threadIdx.x; q0 < nchunks; q0 += 4 * EP_THREADS) {
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(EP_THREADS) void k_erode_pack(const uint8_t *__rest
                     const int r = q / cpr, cx = q - r * cpr;
                     const uint32_t bits = inimg[k] ? pack16(v[k]) : 0xFFFFu;
                     const uint32_t hi = (uint32_t)__shfl_xor((int)bits, 1, 64);
-                    if ((q & 1) == 0) s_rows[r * Wp + (cx >> 1)] = bits | (hi << 16);
+                    if ((q & 1) == 0) s_rows[r * lw + 1 + (cx >> 1)] = bits | (hi << 16);
                 }
             }
         }
@@ -128,11 +131,17 @@ __global__ __launch_bounds__(EP_THREADS) void k_erode_pack(const uint8_t *__rest
                 for (int k = 0; k < cnt; ++k) bits |= (p[k] != 0 ? 1u : 0u) << k;
                 if (cnt < 32) bits |= ~((1u << cnt) - 1u);   // beyond the right edge: counts as set
             }
-            s_rows[q] = bits;
+            s_rows[r * lw + 1 + xw] = bits;
         }
     }
     __syncthreads();
-    erode_band_store(s_rows, Wp, W, H, y0, rows, packed + (size_t)m * H * Wp, bbox + 4 * m);
+    erode_tile_store(s_rows, lw, Wp, 0, y0 - 1, rows, W, Wp, packed + (size_t)m * H * Wp, bbox + 4 * m);
+}
+
+static inline int ep_band_rows(int Wp)
+{
+    int b = EP_LDS_WORDS / (Wp + 2) - 2;
+    return b > 62 ? 62 : b;
 }
 
 extern "C" int cm3d_erode_pack(const uint8_t *dense, int32_t n_masks, int32_t W, int32_t H, uint32_t *packed,
@@ -142,49 +151,73 @@ extern "C" int cm3d_erode_pack(const uint8_t *dense, int32_t n_masks, int32_t W,
     if (n_masks <= 0 || W <= 0 || H <= 0 || W > 32 * EP_MAX_WP || W > 32767 || H > 32767) return CM3D_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int Wp = (W + 31) / 32;
-    int band_rows = EP_LDS_WORDS / Wp - 2;
-    if (band_rows > 62) band_rows = 62;
+    const int band_rows = ep_band_rows(Wp);
     if (band_rows < 1) return CM3D_ERR_ARG;
     const int bands = (H + band_rows - 1) / band_rows;
     hipLaunchKernelGGL(k_bbox_init, dim3((n_masks + 255) / 256), dim3(256), 0, st, bbox, n_masks);
     CM3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_erode_pack, dim3(bands, n_masks), dim3(EP_THREADS), (size_t)(band_rows + 2) * Wp * 4, st, dense, W, H, Wp, band_rows, packed, bbox);
+    hipLaunchKernelGGL(k_erode_pack, dim3(bands, n_masks), dim3(EP_THREADS), (size_t)(band_rows + 2) * (Wp + 2) * 4, st, dense, W, H,
+                       Wp, band_rows, packed, bbox);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }
 
 // ---------------------------------------------------------------------------
-// RLE: run lengths -> inclusive run ends (per mask) in the workspace, plus the first / last
-// image row that holds a set pixel (yrange[m] = {y_first, y_last}, y_first > y_last when empty).
-__global__ __launch_bounds__(1024) void k_rle_ends(const uint32_t *__restrict__ cnts, const int32_t *__restrict__ rle_off,
-                                                   int W, uint32_t *__restrict__ ends, int2 *__restrict__ yrange)
+// RLE: run lengths -> inclusive run ends (per mask) in the workspace, plus the rectangle of the
+// set pixels: mrect[m] = {y_first, y_last, first word, last word} (y_first > y_last when empty).
+// 256 threads, 8 consecutive runs per thread; also resets the mask's bbox.
+#define RE_THREADS 256
+#define RE_PER 8
+__global__ __launch_bounds__(RE_THREADS) void k_rle_ends(const uint32_t *__restrict__ cnts, const int32_t *__restrict__ rle_off,
+                                                         int W, uint32_t *__restrict__ ends, int4 *__restrict__ mrect,
+                                                         int32_t *__restrict__ bbox)
 {
-    __shared__ int s_part[16];
-    __shared__ unsigned int s_lo, s_hi;
+    __shared__ int s_w[RE_THREADS / 64];
+    __shared__ int s_lo[2], s_hi[2];
     const int m = blockIdx.x;
     const int o = rle_off[m], n = rle_off[m + 1] - o;
-    if (threadIdx.x == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
+    if (threadIdx.x == 0) {
+        s_lo[0] = 0x7FFFFFFF; s_lo[1] = 0x7FFFFFFF; s_hi[0] = -1; s_hi[1] = -1;
+        if (bbox) { bbox[4 * m + 0] = 0x7FFFFFFF; bbox[4 * m + 1] = 0x7FFFFFFF; bbox[4 * m + 2] = -1; bbox[4 * m + 3] = -1; }
+    }
     int carry = 0;
-    unsigned int lo = 0xFFFFFFFFu, hi = 0u;
-    for (int base = 0; base < n; base += 1024) {
-        int i = base + threadIdx.x;
-        int v = i < n ? (int)cnts[o + i] : 0;
-        int tot;
-        int ex = cm3d_block1024_excl_scan(v, s_part, tot);
-        if (i < n) {
-            ends[o + i] = (uint32_t)(carry + ex + v);
-            if ((i & 1) && v > 0) {                       // a 1-run [start, end)
-                lo = min(lo, (unsigned int)(carry + ex));
-                hi = max(hi, (unsigned int)(carry + ex + v));
+    int ylo = 0x7FFFFFFF, yhi = -1, xlo = 0x7FFFFFFF, xhi = -1;
+    const int wave = threadIdx.x >> 6, lane = cm3d_lane();
+    for (int base = 0; base < n; base += RE_THREADS * RE_PER) {
+        const int i0 = base + threadIdx.x * RE_PER;
+        int v[RE_PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < RE_PER; ++q) { v[q] = i0 + q < n ? (int)cnts[o + i0 + q] : 0; sum += v[q]; }
+        const int inc = cm3d_wave_incl_scan(sum);
+        __syncthreads();
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < RE_THREADS / 64; ++w) { const int c = s_w[w]; if (w < wave) wbase += c; tot += c; }
+        int run = carry + wbase + inc - sum;          // start pixel of this thread's first run
+#pragma unroll
+        for (int q = 0; q < RE_PER; ++q) {
+            if (i0 + q < n) {
+                const int s = run, e = run + v[q];
+                ends[o + i0 + q] = (uint32_t)e;
+                if (((i0 + q) & 1) && v[q] > 0) {                     // a 1-run [s, e)
+                    const int ys = s / W, ye = (e - 1) / W;
+                    ylo = min(ylo, ys); yhi = max(yhi, ye);
+                    if (ys == ye) { xlo = min(xlo, s - ys * W); xhi = max(xhi, e - 1 - ys * W); }
+                    else { xlo = 0; xhi = W - 1; }
+                }
             }
+            run += v[q];
         }
         carry += tot;
-        __syncthreads();
     }
-    if (lo != 0xFFFFFFFFu) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    ylo = cm3d_wave_min(ylo); xlo = cm3d_wave_min(xlo); yhi = cm3d_wave_max(yhi); xhi = cm3d_wave_max(xhi);
+    __syncthreads();
+    if (lane == 0 && yhi >= 0) { atomicMin(&s_lo[0], ylo); atomicMin(&s_lo[1], xlo); atomicMax(&s_hi[0], yhi); atomicMax(&s_hi[1], xhi); }
     __syncthreads();
     if (threadIdx.x == 0)
-        yrange[m] = s_hi > 0 ? make_int2((int)(s_lo / (unsigned int)W), (int)((s_hi - 1) / (unsigned int)W)) : make_int2(1, 0);
+        mrect[m] = s_hi[0] >= 0 ? make_int4(s_lo[0], s_hi[0], s_lo[1] >> 5, s_hi[1] >> 5) : make_int4(1, 0, 1, 0);
 }
 
 // first run r in [0,n) with ends[r] > p  (n if none)
@@ -227,37 +260,44 @@ __global__ __launch_bounds__(256) void k_rle_to_dense(const uint32_t *__restrict
     }
 }
 
-// f1: RLE -> packed band in LDS -> erode -> store.  grid (bands, n_masks).
-// Bands that cannot hold an eroded pixel (outside the row range of the mask's set pixels) exit
-// at once and write nothing: rows outside [bbox.y0, bbox.y1] are never read downstream.
+// f1: RLE -> packed tile in LDS -> erode -> store.  grid (max_bands, n_masks).
+// A mask's work is its own rectangle (rows y_first..y_last, words xw0..xw1): the tile is as wide as the
+// rectangle (+ halo) and as tall as LDS allows, so most masks need one or two workgroups; the
+// other workgroups of the mask exit at once.  Nothing outside the rectangle is written.
 __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *__restrict__ ends_all,
                                                                 const int32_t *__restrict__ rle_off,
-                                                                const int2 *__restrict__ yrange, int W, int H, int Wp,
-                                                                int band_rows, uint32_t *__restrict__ packed,
-                                                                int32_t *__restrict__ bbox)
+                                                                const int4 *__restrict__ mrect, int W, int H, int Wp,
+                                                                uint32_t *__restrict__ packed, int32_t *__restrict__ bbox)
 {
     extern __shared__ __align__(16) uint32_t s_rows[];
     __shared__ int s_range[2];
     const int m = blockIdx.y;
-    const int y0 = blockIdx.x * band_rows;
-    const int rows = min(band_rows, H - y0);
-    const int2 yr = yrange[m];
-    if (yr.x > yr.y || y0 > yr.y || y0 + rows - 1 < yr.x) return;   // no set pixel in rows y0..y0+rows-1
+    const int4 rc = mrect[m];
+    if (rc.x > rc.y) return;                                    // empty mask
+    const int xw0 = rc.z, wc = rc.w - rc.z + 1, lw = wc + 2;
+    int br = RLE_LDS_WORDS / lw - 2;                            // output rows per tile
+    const int need = rc.y - rc.x + 1;
+    if (br > need) br = need;
+    const int y0 = rc.x + (int)blockIdx.x * br;                 // first output row of this tile
+    if (y0 > rc.y) return;
+    const int rows = min(br, rc.y - y0 + 1);
     const int lrows = rows + 2;
     const int o = rle_off[m], n = rle_off[m + 1] - o;
     const uint32_t *ends = ends_all + o;
-    const int ya = y0 - 1, yb = y0 + rows;          // first / last LDS row (may lie outside the image)
-    // rows outside the image are all ones, rows inside start at zero; bits beyond W in the
-    // last word of a row are ones (they only ever act as "neighbour beyond the edge")
+    const int ya = y0 - 1;                                      // image row of LDS row 0
+    // initial tile: ones outside the image, zeros inside; pad bits of a row's last word are ones
     const uint32_t pad = (W & 31) ? ~((1u << (W & 31)) - 1u) : 0u;
-    for (int q = threadIdx.x; q < lrows * Wp; q += EP_THREADS) {
-        const int r = q / Wp, xw = q - r * Wp;
-        const int y = ya + r;
-        s_rows[q] = (y < 0 || y >= H) ? 0xFFFFFFFFu : (xw == Wp - 1 ? pad : 0u);
+    for (int q = threadIdx.x; q < lrows * lw; q += EP_THREADS) {
+        const int r = q / lw, c = q - r * lw;
+        const int y = ya + r, xw = xw0 - 1 + c;
+        uint32_t v = 0u;
+        if (y < 0 || y >= H || xw < 0 || xw >= Wp) v = 0xFFFFFFFFu;
+        else if (xw == Wp - 1) v = pad;
+        s_rows[q] = v;
     }
     if (threadIdx.x < 2) s_range[threadIdx.x] = 0;
     __syncthreads();
-    const int yc0 = max(ya, 0), yc1 = min(yb, H - 1);      // image rows held in LDS
+    const int yc0 = max(ya, 0), yc1 = min(ya + lrows - 1, H - 1);            // image rows held in LDS
     const uint32_t px0 = (uint32_t)yc0 * W, px1 = (uint32_t)(yc1 + 1) * W;   // pixel range [px0, px1)
     // cooperative lower bounds (ends is ascending): #runs with end <= px0, #runs with end <= px1-1
     int c0 = 0, c1 = 0;
@@ -270,7 +310,8 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
     if (cm3d_lane() == 0) { atomicAdd(&s_range[0], c0); atomicAdd(&s_range[1], c1); }
     __syncthreads();
     const int r_first = s_range[0], r_last = min(s_range[1], n - 1);
-    // every 1-run (odd index) overlapping the band sets its bits, row by row
+    // every 1-run (odd index) overlapping the tile sets its bits, row by row (all of them lie inside
+    // the word range of the rectangle)
     for (int r = r_first + threadIdx.x; r <= r_last; r += EP_THREADS) {
         if (!(r & 1)) continue;
         uint32_t s = r > 0 ? ends[r - 1] : 0u, e = ends[r];
@@ -278,7 +319,7 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
         while (s < e) {
             const uint32_t y = s / W, x = s - y * W;
             const uint32_t xe = min((uint32_t)W, x + (e - s));   // exclusive end within this row
-            uint32_t *row = s_rows + (y - ya) * Wp;
+            uint32_t *row = s_rows + ((int)y - ya) * lw + 1 - xw0;    // row[xw] = packed word xw
             uint32_t w0 = x >> 5, w1 = (xe - 1) >> 5;
             uint32_t m0 = 0xFFFFFFFFu << (x & 31);
             uint32_t m1 = 0xFFFFFFFFu >> (31 - ((xe - 1) & 31));
@@ -292,14 +333,15 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
         }
     }
     __syncthreads();
-    erode_band_store(s_rows, Wp, W, H, y0, rows, packed + (size_t)m * H * Wp, bbox + 4 * m);
+    erode_tile_store(s_rows, lw, wc, xw0, ya, rows, W, Wp, packed + (size_t)m * H * Wp, bbox + 4 * m);
 }
+
+static inline size_t rle_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 extern "C" int64_t cm3d_rle_workspace_bytes(int32_t total_runs)
 {
-    // run ends (4 B per run, padded to 16) followed by the per-mask row range is sized by the caller's
-    // n_masks; to keep the signature simple the row ranges live behind the ends: 8 B per run bounds it
-    return total_runs > 0 ? (((int64_t)total_runs * 4 + 15) / 16) * 16 + (int64_t)total_runs * 8 : 0;
+    // run ends (4 B per run) followed by one int4 rectangle per mask; a mask has at least one run
+    return total_runs > 0 ? (int64_t)(rle_align16((size_t)total_runs * 4) + (size_t)total_runs * 16) : 0;
 }
 
 extern "C" int cm3d_rle_to_dense(const uint32_t *rle_counts, const int32_t *rle_off, int32_t n_masks, int32_t total_runs,
@@ -307,13 +349,12 @@ extern "C" int cm3d_rle_to_dense(const uint32_t *rle_counts, const int32_t *rle_
                                  cm3d_stream_t stream)
 {
     if (!rle_counts || !rle_off || !dense || !workspace) return CM3D_ERR_ARG;
-    if (n_masks <= 0 || total_runs <= 0 || W <= 0 || H <= 0 || (int64_t)W * H >= (1ll << 31)) return CM3D_ERR_ARG;
+    if (n_masks <= 0 || total_runs <= 0 || n_masks > total_runs || W <= 0 || H <= 0 || (int64_t)W * H >= (1ll << 31)) return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_rle_workspace_bytes(total_runs)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     uint32_t *ends = (uint32_t *)workspace;
-    int2 *yrange = (int2 *)((char *)workspace + (((size_t)total_runs * 4 + 15) / 16) * 16);
-    if (n_masks > total_runs) return CM3D_ERR_ARG;
-    hipLaunchKernelGGL(k_rle_ends, dim3(n_masks), dim3(1024), 0, st, rle_counts, rle_off, W, ends, yrange);
+    int4 *mrect = (int4 *)((char *)workspace + rle_align16((size_t)total_runs * 4));
+    hipLaunchKernelGGL(k_rle_ends, dim3(n_masks), dim3(RE_THREADS), 0, st, rle_counts, rle_off, W, ends, mrect, (int32_t *)nullptr);
     CM3D_CHECK_LAUNCH();
     const int total_px = W * H;
     int chunks = (total_px / 16 + 255) / 256;
@@ -329,23 +370,20 @@ extern "C" int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rl
                                    int64_t workspace_bytes, cm3d_stream_t stream)
 {
     if (!rle_counts || !rle_off || !packed || !bbox || !workspace) return CM3D_ERR_ARG;
-    if (n_masks <= 0 || total_runs <= 0 || W <= 0 || H <= 0 || W > 32 * EP_MAX_WP || W > 32767 || H > 32767) return CM3D_ERR_ARG;
+    if (n_masks <= 0 || total_runs <= 0 || n_masks > total_runs || W <= 0 || H <= 0 || W > 32 * EP_MAX_WP || W > 32767 || H > 32767)
+        return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_rle_workspace_bytes(total_runs)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     uint32_t *ends = (uint32_t *)workspace;
+    int4 *mrect = (int4 *)((char *)workspace + rle_align16((size_t)total_runs * 4));
     const int Wp = (W + 31) / 32;
-    int band_rows = EP_LDS_WORDS / Wp - 2;
-    if (band_rows > 62) band_rows = 62;
-    if (band_rows < 1) return CM3D_ERR_ARG;
-    const int bands = (H + band_rows - 1) / band_rows;
-    int2 *yrange = (int2 *)((char *)workspace + (((size_t)total_runs * 4 + 15) / 16) * 16);
-    if (n_masks > total_runs) return CM3D_ERR_ARG;
-    hipLaunchKernelGGL(k_rle_ends, dim3(n_masks), dim3(1024), 0, st, rle_counts, rle_off, W, ends, yrange);
+    const int min_rows = RLE_LDS_WORDS / (Wp + 2) - 2;          // tile height of a full-width mask
+    if (min_rows < 1) return CM3D_ERR_ARG;
+    const int max_bands = (H + min_rows - 1) / min_rows;
+    hipLaunchKernelGGL(k_rle_ends, dim3(n_masks), dim3(RE_THREADS), 0, st, rle_counts, rle_off, W, ends, mrect, bbox);
     CM3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_bbox_init, dim3((n_masks + 255) / 256), dim3(256), 0, st, bbox, n_masks);
-    CM3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_rle_erode_pack, dim3(bands, n_masks), dim3(EP_THREADS), (size_t)(band_rows + 2) * Wp * 4, st, ends, rle_off, yrange, W, H, Wp, band_rows,
-                       packed, bbox);
+    hipLaunchKernelGGL(k_rle_erode_pack, dim3(max_bands, n_masks), dim3(EP_THREADS), (size_t)RLE_LDS_WORDS * 4, st, ends, rle_off, mrect,
+                       W, H, Wp, packed, bbox);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }
