@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=48, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--lane-points", type=int, default=50000)
     ap.add_argument("--no-secondary", action="store_true", help="skip the second mask mode")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="override a field of the synthetic config (e.g. --set n_masks=80); for experiments")
     args = ap.parse_args()
 
     rank, world, local_rank = cdist.init_from_env()
@@ -98,7 +100,11 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
-    cfg = syn.config(args.config)
+    over = {}
+    for kv in args.set:
+        k, v = kv.split("=", 1)
+        over[k] = type(getattr(syn.SyntheticConfig(), k))(float(v)) if not isinstance(getattr(syn.SyntheticConfig(), k), str) else v
+    cfg = syn.config(args.config, **over)
     t_gen = time.perf_counter()
     frames = [syn.make_frame(cfg, rank * args.frames + i) for i in range(args.frames)]
     # one HD-map lane table covering the region all frames of the batch drive in (ego positions are drawn

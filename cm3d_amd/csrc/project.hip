@@ -15,34 +15,85 @@
 #define PH_PT 4                                   // points per thread
 #define PH_BLOCK_PTS (PH_THREADS * PH_PT)
 
-// One pinhole projection through the reference's float32 op chain.  Returns the pixel code
-// (iv << 16 | iu) or -1.  cm = camera record in LDS.
-static __device__ __forceinline__ int project_pixel(const float *cm, float4 pt, bool in_range, float min_dist, float wlim,
-                                                    float hlim)
+// Block-local slot of a thread's j-th point: wave w owns the 256 consecutive points [256 w, 256 w + 256)
+// (LiDAR points are stored ring by ring, so a wave then sees one short arc and few cameras); for a fixed j
+// the 64 lanes read 64 consecutive points (1 KiB, coalesced).  Order inside a block = (wave, j, lane).
+static __device__ __forceinline__ int ph_slot(int j) { return (int)(threadIdx.x >> 6) * (64 * PH_PT) + j * 64 + (int)(threadIdx.x & 63); }
+
+// One pinhole projection through the reference's float32 op chain, branch-free (the kernel is
+// instruction-issue bound and divergent control flow costs scalar instructions).  Returns the pixel
+// code (iv << 16 | iu) or -1.  cm = camera record in LDS.
+static __device__ __forceinline__ int project_pixel(const float *cm, float4 pt, bool pre_ok, float min_dist, int W, int H)
 {
     // global -> ego(cam time) -> camera: p += t1; p = R1 p; p += t2; p = R2 p   (2d_to_3d.py:569-577)
     float x = pt.x + cm[0], y = pt.y + cm[1], z = pt.z + cm[2];
     float ax, ay, az;
     cm3d_rot3(cm + 3, x, y, z, ax, ay, az);
-    if (cm[33] > 1.5f) {
+    if (cm[33] > 1.5f) {                                      // block-uniform
         x = ax + cm[12]; y = ay + cm[13]; z = az + cm[14];
         cm3d_rot3(cm + 15, x, y, z, ax, ay, az);
     }
     const float depth = az;                                   // :581
-    if (!(in_range && depth > min_dist)) return -1;           // first term of :597-603
     // view_points: viewpad(4x4) @ [p;1], rows 0..2, k-sequential fma chain (pcd.py:269-282)
     const float *K = cm + 24;
     float uh = K[0] * ax; uh = fmaf(K[1], ay, uh); uh = fmaf(K[2], az, uh); uh = fmaf(0.0f, 1.0f, uh);
     float vh = K[3] * ax; vh = fmaf(K[4], ay, vh); vh = fmaf(K[5], az, vh); vh = fmaf(0.0f, 1.0f, vh);
     float zh = K[6] * ax; zh = fmaf(K[7], ay, zh); zh = fmaf(K[8], az, zh); zh = fmaf(0.0f, 1.0f, zh);
-    const float u = uh / zh, v = vh / zh;
-    // :597-603 in-image test, :605 floor, :608-613 truthiness quirk.  The third row of the quirk,
-    // floor(zh/zh) != 0, holds whenever u passed 0 < u < W-1: a finite non-zero u needs a finite
-    // non-zero zh, and then zh/zh == 1 exactly.
-    if (!(u > 0.0f && u < wlim && v > 0.0f && v < hlim)) return -1;
+    const float u = uh / zh, v = vh / zh;                     // IEEE division, any operand
+    // :597-603 in-image test, :605 floor, :608-613 truthiness quirk, folded into integer range checks:
+    //   u > 0 && u < W-1 && floor(u) != 0   <=>   1 <= floor(u) <= W-2      (u = W-1 gives floor W-1;
+    //   NaN converts to 0 and +-inf saturates, all outside the range).  The third row of the quirk,
+    //   floor(zh/zh) != 0, holds whenever u is finite and non-zero (then zh/zh == 1 exactly).
     const int iu = (int)floorf(u), iv = (int)floorf(v);
-    if (iu == 0 || iv == 0) return -1;
-    return (iv << 16) | iu;
+    const bool ok = pre_ok & (depth > min_dist) & ((unsigned)(iu - 1) <= (unsigned)(W - 3)) & ((unsigned)(iv - 1) <= (unsigned)(H - 3));
+    return ok ? ((iv << 16) | iu) : -1;
+}
+
+// Conservative visibility cone of one camera, from its float32 record: a point can only pass the exact
+// in-image test if it is in front of the camera by more than min_dist (minus a margin) and inside the
+// circular cone around the optical axis that contains the whole image (plus a 2 degree margin).
+// out: [0..2] camera centre (global), [3..5] optical axis (global), [6] min axial distance, [7] 1 + tan^2.
+// The float32 error of this test is ~1e-4 m at nuScenes' global magnitudes -- orders below the margins --
+// and a camera record the derivation does not cover (skew, non-trivial last row of K) disables the test.
+static __device__ void cone_setup(const float *cm, int W, int H, float min_dist, float *out)
+{
+    const bool two = cm[33] > 1.5f;
+    const float *R1 = cm + 3, *R2 = cm + 15, *K = cm + 24;
+    float M[9];                                   // camera <- global rotation
+    if (two) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) M[3 * r + c] = R2[3 * r] * R1[c] + R2[3 * r + 1] * R1[3 + c] + R2[3 * r + 2] * R1[6 + c];
+    } else {
+        for (int q = 0; q < 9; ++q) M[q] = R1[q];
+    }
+    // camera centre: p_cam = 0  <=>  p = -t1 - R1^T t2
+    float ox = -cm[0], oy = -cm[1], oz = -cm[2];
+    if (two) {
+        ox -= R1[0] * cm[12] + R1[3] * cm[13] + R1[6] * cm[14];
+        oy -= R1[1] * cm[12] + R1[4] * cm[13] + R1[7] * cm[14];
+        oz -= R1[2] * cm[12] + R1[5] * cm[13] + R1[8] * cm[14];
+    }
+    out[0] = ox; out[1] = oy; out[2] = oz;
+    out[3] = M[6]; out[4] = M[7]; out[5] = M[8];
+    const bool plain = K[1] == 0.f && K[3] == 0.f && K[6] == 0.f && K[7] == 0.f && K[8] == 1.f && K[0] > 0.f && K[4] > 0.f;
+    // orthonormality of M (a rotation up to float32 rounding)?
+    float dev = 0.f;
+    for (int r = 0; r < 3; ++r)
+        for (int c = r; c < 3; ++c) {
+            const float d = M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1] + M[3 * r + 2] * M[3 * c + 2] - (r == c ? 1.f : 0.f);
+            dev = fmaxf(dev, fabsf(d));
+        }
+    if (!plain || !(dev < 1e-3f)) { out[6] = -INFINITY; out[7] = INFINITY; return; }   // accept everything
+    float t2 = 0.f;
+    for (int cx = 0; cx < 2; ++cx)
+        for (int cy = 0; cy < 2; ++cy) {
+            const float a = ((cx ? (float)W : 0.f) - K[2]) / K[0], b = ((cy ? (float)H : 0.f) - K[5]) / K[4];
+            t2 = fmaxf(t2, a * a + b * b);
+        }
+    const float t = sqrtf(t2), tm = 0.035f;            // tan(2 deg)
+    const float tt = t * tm < 0.9f ? (t + tm) / (1.f - t * tm) : INFINITY;
+    out[6] = min_dist - 0.05f - 1e-4f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+    out[7] = 1.f + tt * tt * 1.01f;
 }
 
 // grid (G, F).  A block walks 1024-point chunks of one frame (chunk = blockIdx.x, += gridDim.x),
@@ -68,6 +119,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     const int planes = (nm + 31) >> 5;
 
     __shared__ float s_cam[CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
+    __shared__ float s_cone[CM3D_MAX_CAMS][8];           // conservative visibility cone per camera
     // dynamic LDS: bbox[nm_cap], pixel codes [n_cams][PH_BLOCK_PTS], mask camera[nm_cap], counts[nm_cap]
     extern __shared__ __align__(16) unsigned char s_dyn[];
     int4 *s_bbox = reinterpret_cast<int4 *>(s_dyn);
@@ -79,11 +131,12 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     float4 pt[PH_PT];
 #pragma unroll
     for (int j = 0; j < PH_PT; ++j) {
-        const int i0 = (int)blockIdx.x * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x;
+        const int i0 = (int)blockIdx.x * PH_BLOCK_PTS + ph_slot(j);
         pt[j] = i0 < n ? points[p0 + i0] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS)
         s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
+    if (threadIdx.x < n_cams) cone_setup(cams + ((size_t)f * n_cams + threadIdx.x) * CM3D_CAM_STRIDE, W, H, min_dist, s_cone[threadIdx.x]);
     for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
         int c = mask_cam[m0 + k];
         int4 bb = bbox[m0 + k];
@@ -92,7 +145,6 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     }
     __syncthreads();
 
-    const float wlim = (float)(W - 1), hlim = (float)(H - 1);
     const size_t mask_words = (size_t)H * Wp;
     for (int chunk = blockIdx.x; chunk < nblk; chunk += gridDim.x) {
         const int base = chunk * PH_BLOCK_PTS;
@@ -100,17 +152,35 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
         bool in_range[PH_PT];
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) {
-            idx[j] = base + j * PH_THREADS + threadIdx.x;
+            idx[j] = base + ph_slot(j);
             in_range[j] = idx[j] < n;
         }
-        uint32_t cam_any = 0;     // wave-uniform: cameras that see at least one point of this wave
+        uint32_t cam_any = 0;
 #pragma unroll 1
         for (int c = 0; c < n_cams; ++c) {
+            // conservative pre-test (a superset of the exact in-image test): is any of this wave's points
+            // inside the camera's visibility cone?  LiDAR points are stored ring by ring, so a wave's
+            // 4 x 64 points cover a small azimuth range and most cameras are rejected here for the whole wave.
+            const float *cn = s_cone[c];
+            bool acc[PH_PT], anyacc = false;
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) {
+                const float vx = pt[j].x - cn[0], vy = pt[j].y - cn[1], vz = pt[j].z - cn[2];
+                const float sdist = fmaf(cn[5], vz, fmaf(cn[4], vy, cn[3] * vx));
+                const float r2 = fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+                acc[j] = in_range[j] && sdist > cn[6] && r2 <= cn[7] * sdist * sdist;
+                anyacc = anyacc || acc[j];
+            }
+            if (!__ballot(anyacc)) {
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j) s_pix[c * PH_BLOCK_PTS + ph_slot(j)] = -1;
+                continue;
+            }
             bool any = false;
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
-                const int px = project_pixel(s_cam + c * CM3D_CAM_STRIDE, pt[j], in_range[j], min_dist, wlim, hlim);
-                s_pix[c * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x] = px;     // read back by this thread only
+                const int px = project_pixel(s_cam + c * CM3D_CAM_STRIDE, pt[j], acc[j], min_dist, W, H);
+                s_pix[c * PH_BLOCK_PTS + ph_slot(j)] = px;     // read back by this thread only
                 any = any || px >= 0;
             }
             if (__ballot(any)) cam_any |= 1u << c;
@@ -119,7 +189,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
         if (chunk + (int)gridDim.x < nblk) {
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
-                const int i1 = (chunk + (int)gridDim.x) * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x;
+                const int i1 = (chunk + (int)gridDim.x) * PH_BLOCK_PTS + ph_slot(j);
                 pt[j] = i1 < n ? points[p0 + i1] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -129,16 +199,18 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             for (int j = 0; j < PH_PT; ++j) bits[j] = 0;
             const int kend = min(nm, plane * 32 + 32);
             for (int k = plane * 32; k < kend; ++k) {
-                const int c = s_mcam[k];
+                const int c = __builtin_amdgcn_readfirstlane(s_mcam[k]);
                 if (!((cam_any >> c) & 1u)) continue;            // wave-uniform
-                const int4 bb = s_bbox[k];
+                int4 bb = s_bbox[k];
+                bb.x = __builtin_amdgcn_readfirstlane(bb.x); bb.y = __builtin_amdgcn_readfirstlane(bb.y);
+                bb.z = __builtin_amdgcn_readfirstlane(bb.z); bb.w = __builtin_amdgcn_readfirstlane(bb.w);
                 const uint32_t *mw = packed + (size_t)(m0 + k) * mask_words;
                 uint32_t word[PH_PT];
                 int px[PH_PT];
                 bool cand[PH_PT];
 #pragma unroll
                 for (int j = 0; j < PH_PT; ++j) {
-                    px[j] = s_pix[c * PH_BLOCK_PTS + j * PH_THREADS + threadIdx.x];
+                    px[j] = s_pix[c * PH_BLOCK_PTS + ph_slot(j)];
                     const int iu = px[j] & 0xFFFF, iv = px[j] >> 16;
                     cand[j] = px[j] >= 0 && iu >= bb.x && iu <= bb.z && iv >= bb.y && iv <= bb.w;
                     word[j] = 0;
@@ -219,8 +291,8 @@ __global__ __launch_bounds__(256) void k_blk_prefix(const int32_t *__restrict__ 
 }
 
 // grid (nblk_max, F): the same 1024 points and the same thread<->point map as k_project_hits.
-// Order inside a block is (j, wave, lane); per present mask bit: counts per (j, wave) through
-// LDS, then ballot + mbcnt positions on top of the block's exclusive offset.
+// Order inside a block is (wave, j, lane); per present mask bit: counts per wave through LDS, then
+// ballot + mbcnt positions on top of the block's exclusive offset.
 __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__restrict__ hit_words, int n_points_total,
                                                              const int32_t *__restrict__ pt_off,
                                                              const int32_t *__restrict__ mask_off, int nm_cap, int nblk_max,
@@ -235,10 +307,10 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
     const int nm = min(mask_off[f + 1] - m0, nm_cap);
     const int planes = (nm + 31) >> 5;
     const int wave = threadIdx.x >> 6, lane = cm3d_lane();
-    __shared__ int s_c[PH_PT][PH_THREADS / 64][32];
+    __shared__ int s_c[PH_THREADS / 64][32];
     int idx[PH_PT];
 #pragma unroll
-    for (int j = 0; j < PH_PT; ++j) idx[j] = base + j * PH_THREADS + threadIdx.x;
+    for (int j = 0; j < PH_PT; ++j) idx[j] = base + ph_slot(j);
     for (int plane = 0; plane < planes; ++plane) {
         const uint32_t *hw = hit_words + (size_t)plane * n_points_total + p0;
         uint32_t w[PH_PT];
@@ -246,46 +318,24 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) { w[j] = idx[j] < n ? hw[idx[j]] : 0u; any |= w[j]; }
         const uint32_t orw = cm3d_wave_or(any);
-        int mycnt[PH_PT];
-#pragma unroll
-        for (int j = 0; j < PH_PT; ++j) mycnt[j] = 0;
+        int mycnt = 0;                         // lane b < 32: hits of mask bit b in this wave's 256 points
         for (uint32_t r = orw; r; r &= r - 1) {
             const int b = __builtin_ctz(r);
+            int c = 0;
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) {
-                const int c = __popcll(__ballot((w[j] >> b) & 1u));
-                if (lane == b) mycnt[j] = c;
-            }
+            for (int j = 0; j < PH_PT; ++j) c += __popcll(__ballot((w[j] >> b) & 1u));
+            if (lane == b) mycnt = c;
         }
         __syncthreads();               // previous plane's readers are done with s_c
-        if (lane < 32) {
-#pragma unroll
-            for (int j = 0; j < PH_PT; ++j) s_c[j][wave][lane] = mycnt[j];
-        }
+        if (lane < 32) s_c[wave][lane] = mycnt;
         __syncthreads();
         if (orw) {
-            // lane b < 32: running output position of mask bit b for this wave's (j = 0) segment
+            // lane b < 32: running output position of mask bit b, starting at this wave's first point
             int run = 0;
-            int after[PH_PT];          // increments between this wave's consecutive j segments
-#pragma unroll
-            for (int j = 0; j < PH_PT; ++j) after[j] = 0;
             if (lane < 32) {
                 const int k = plane * 32 + lane;
                 run = k < nm ? blk_base[((size_t)f * nblk_max + chunk) * nm_cap + k] : 0;
-#pragma unroll
-                for (int j = 0; j < PH_PT; ++j) {
-                    int before = 0, rest = 0;
-                    for (int w2 = 0; w2 < PH_THREADS / 64; ++w2) {
-                        const int c = s_c[j][w2][lane];
-                        if (w2 < wave) before += c;
-                        if (w2 > wave) rest += c;
-                    }
-                    if (j == 0) run += before;
-                    // from the end of (j, wave) to the start of (j+1, wave): the waves after us in j and
-                    // the waves before us in j+1
-                    after[j] = rest;
-                    if (j > 0) after[j - 1] += before;
-                }
+                for (int w2 = 0; w2 < wave; ++w2) run += s_c[w2][lane];
             }
             for (uint32_t r = orw; r; r &= r - 1) {
                 const int b = __builtin_ctz(r);
@@ -298,7 +348,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
                         const int pos = basepos + cm3d_mbcnt(mk);
                         if (pos >= 0 && pos < idx_cap) hit_idx[pos] = idx[j];
                     }
-                    if (lane == b) run += __popcll(mk) + after[j];
+                    if (lane == b) run += __popcll(mk);
                 }
             }
         }
