@@ -97,6 +97,8 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    if os.environ.get("CM3D_SINGLE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box (with CM3D_DIST_BACKEND=gloo)
+        local_rank = 0
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 

@@ -136,13 +136,15 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     }
     for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS)
         s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
-    if (threadIdx.x < n_cams) cone_setup(cams + ((size_t)f * n_cams + threadIdx.x) * CM3D_CAM_STRIDE, W, H, min_dist, s_cone[threadIdx.x]);
     for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
         int c = mask_cam[m0 + k];
         int4 bb = bbox[m0 + k];
         if (c < 0 || c >= n_cams) { atomicOr(&status[0], 4); c = 0; bb = make_int4(1, 1, 0, 0); }
         s_mcam[k] = c; s_bbox[k] = bb; s_cnt[k] = 0;
     }
+    __syncthreads();
+    // visibility cones from the staged records (LDS reads; no dependent global loads)
+    if (threadIdx.x < n_cams) cone_setup(s_cam + threadIdx.x * CM3D_CAM_STRIDE, W, H, min_dist, s_cone[threadIdx.x]);
     __syncthreads();
 
     const size_t mask_words = (size_t)H * Wp;
