@@ -44,7 +44,7 @@ def _compare(hb, got, exp):
     assert np.array_equal(got["lane_dist"][valid], exp["lane_dist"][valid])
     assert np.array_equal(got["flags"], exp["flags"])
     assert np.allclose(got["box"], exp["box"], rtol=0, atol=BOX_TOL)
-    assert np.abs(got["box"] - exp["box"]).max() < 1e-9     # what we actually see
+    assert np.abs(got["box"] - exp["box"]).max() < 1e-6     # what we actually see: ~1e-9 (device vs host float32 cos/sin)
 
 
 @pytest.mark.parametrize("masks", ["dense", "rle"])
@@ -77,3 +77,66 @@ def test_colsum_bit_exact(oracle):
             continue
         _, cs = oracle.medoid(pts, exp["hit_idx"][o:e], want_colsum=True)
         assert np.array_equal(cs.view(np.uint32), got["colsum"][o:e].view(np.uint32)), f"mask {m} column sums differ"
+
+
+def test_waymo_shaped_frame(oracle):
+    # C4 shape at reduced point count: 5 cameras, 1920x1280 masks, 64 beams
+    hb, got, exp = _run("c4", 1, "rle", oracle, n_points=60000)
+    assert exp["hit_idx"].size > 500
+    _compare(hb, got, exp)
+
+
+def test_many_masks_three_planes(oracle):
+    # C5 density: 80 masks per frame -> 3 hit-word planes; 2 sweeps
+    hb, got, exp = _run("c5", 2, "rle", oracle, n_sweeps=2, n_points=20000, width=1024, height=576, ratio=0.64)
+    assert hb.n_masks == 160
+    _compare(hb, got, exp)
+
+
+def test_ragged_batch(oracle):
+    """Frames with different point counts and mask counts in one batch, incl. a frame whose masks are all empty."""
+    import torch
+    from cm3d_amd import lifting, rle
+    cfg = syn.config("tiny")
+    frames = [syn.make_frame(cfg, i) for i in range(4)]
+    frames[1].sweeps_raw = [frames[1].sweeps_raw[0][:700]]
+    frames[1].sweep_xf = frames[1].sweep_xf[:1]
+    frames[2].rles = frames[2].rles[:3]; frames[2].labels = frames[2].labels[:3]
+    frames[2].scores = frames[2].scores[:3]; frames[2].cam_nums = frames[2].cam_nums[:3]
+    empty = rle.counts_to_string(np.array([cfg.width * cfg.height], np.uint32))
+    frames[3].rles = [{"size": [cfg.width, cfg.height], "counts": empty} for _ in frames[3].rles]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 1000, seed=1)]
+    fl = [0, 0, 0, 0]
+    hb = lifting.pack_frames(frames, lanes, fl)
+    eng = lifting.LiftEngine(keep_colsum=True)
+    eng.upload(hb)
+    for masks in ("rle", "dense"):
+        if masks == "dense":
+            eng.decode_masks_dense()
+        eng.run(masks=masks)
+        torch.cuda.synchronize()
+        got = eng.download()
+        exp = oracle_batch(oracle, frames, lanes, fl, hb)
+        _compare(hb, got, exp)
+    m0 = hb.mask_off[3]
+    assert (got["flags"][m0:] == 0).all() and (got["medoid_pos"][m0:] == -1).all()
+
+
+def test_second_pass_is_identical(oracle):
+    """Running the resident batch twice gives bit-identical outputs (no state leaks between passes,
+    no order-dependent atomics on anything that is an output)."""
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config("tiny")
+    frames = [syn.make_frame(cfg, i) for i in range(6)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 2000, seed=1)]
+    hb = lifting.pack_frames(frames, lanes, [0] * 6)
+    eng = lifting.LiftEngine()
+    eng.upload(hb)
+    outs = []
+    for _ in range(3):
+        eng.run(masks="rle")
+        torch.cuda.synchronize()
+        outs.append(eng.download())
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True) and np.array_equal(outs[0][k], outs[2][k], equal_nan=True), k
