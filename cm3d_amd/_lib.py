@@ -42,7 +42,8 @@ SIGNATURES = {
     "cm3d_lane_nn_workspace_bytes": (_i64, [_i32]),
     "cm3d_lane_nn": (_i32, [_p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
     "cm3d_circle_nms": (_i32, [_p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p]),
-    "cm3d_box_nms": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
+    "cm3d_box_nms": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    "cm3d_centroid_transform": (_i32, [_p, _p, _p, _i32, _p, _p, _p]),
 }
 
 

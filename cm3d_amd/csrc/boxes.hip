@@ -457,8 +457,9 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
                                                 const int32_t *__restrict__ lane_off, const int32_t *__restrict__ frame_lane,
                                                 const int32_t *__restrict__ lane_idx, const double *__restrict__ lane_dist,
                                                 const double *__restrict__ prior_wlh, const int32_t *__restrict__ is_vehicle,
-                                                const double *__restrict__ nms_thr, int n_classes,
-                                                const double *__restrict__ ego_xyz, double *__restrict__ box,
+                                                const int32_t *__restrict__ nms_group, const double *__restrict__ nms_thr,
+                                                int n_classes, const double *__restrict__ ego_xyz,
+                                                const float *__restrict__ pose_inv, double *__restrict__ box,
                                                 int32_t *__restrict__ flags)
 {
     __shared__ double s_x[BN_MAX], s_y[BN_MAX], s_s[BN_MAX];
@@ -468,7 +469,13 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
     const int m0 = mask_off[f];
     const int nm = min(mask_off[f + 1] - m0, BN_MAX);
     const int lane_id = threadIdx.x;
-    const double ex0 = ego_xyz[3 * f], ey0 = ego_xyz[3 * f + 1];
+    // nuScenes: boxes live in the global frame, the ego position is needed for the push-back direction.
+    // Waymo (pose_inv != null): centroids arrive in the global frame, boxes leave in the vehicle frame.
+    const bool waymo = pose_inv != nullptr;
+    const double ex0 = waymo ? 0.0 : ego_xyz[3 * f], ey0 = waymo ? 0.0 : ego_xyz[3 * f + 1];
+    double Pi[12];
+    if (waymo)
+        for (int q = 0; q < 12; ++q) Pi[q] = (double)pose_inv[(size_t)f * 16 + q];   // rows 0..2 of the 4x4, float32 -> float64
     const int ltab = lane_off[frame_lane[f]];
 
     for (int k = lane_id; k < nm; k += 64) {
@@ -478,7 +485,14 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
         if (cls < 0 || cls >= n_classes) cls = 0;
         double tx = 0.0, ty = 0.0, tz = 0.0, qw = 1.0, qz = 0.0, yaw_out = 0.0, ld = 0.0;
         if (valid) {
-            const double cx = (double)centroid[3 * m], cy = (double)centroid[3 * m + 1], cz = (double)centroid[3 * m + 2];
+            double cx = (double)centroid[3 * m], cy = (double)centroid[3 * m + 1], cz = (double)centroid[3 * m + 2];
+            if (waymo) {
+                // src/waymo/2d_to_3d.py:812-816: np.dot(inv(float32 pose), [centroid, 1]) in float64
+                const double gx = cx, gy = cy, gz = cz;
+                cx = Pi[0] * gx + Pi[1] * gy + Pi[2] * gz + Pi[3];
+                cy = Pi[4] * gx + Pi[5] * gy + Pi[6] * gz + Pi[7];
+                cz = Pi[8] * gx + Pi[9] * gy + Pi[10] * gz + Pi[11];
+            }
             const float yaw = lane[(size_t)(ltab + lane_idx[m]) * 3 + 2];      // :295, an f32 value
             yaw_out = (double)yaw; ld = lane_dist[m];
             tx = cx; ty = cy; tz = cz;
@@ -506,11 +520,18 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
                 if (o1 != o1 || o2 != o2) off = NAN;
                 tx = cx + off * cos(alpha);
                 ty = cy + off * sin(alpha);
+                if (waymo) {
+                    // src/waymo/2d_to_3d.py:978-1001: align_mat = R_inv . Rz(global lane yaw); heading = as_euler('xyz')[2]
+                    qw = atan2(Pi[4] * cs + Pi[5] * sn, Pi[0] * cs + Pi[1] * sn);
+                    qz = 0.0;
+                }
+            } else if (waymo) {
+                qw = 0.0; qz = 0.0;          // heading of identity (:1003-1010)
             }
         }
         double *b = box + (size_t)m * CM3D_BOX_STRIDE;
         b[0] = tx; b[1] = ty; b[2] = tz; b[3] = qw; b[4] = qz; b[5] = yaw_out; b[6] = ld; b[7] = score[m]; b[8] = (double)cls;
-        s_x[k] = tx; s_y[k] = ty; s_s[k] = score[m]; s_lab[k] = cls;
+        s_x[k] = tx; s_y[k] = ty; s_s[k] = score[m]; s_lab[k] = nms_group[cls];
         s_valid[k] = valid; s_sup[k] = 0; s_keep[k] = 0;
     }
     nms_phase(nm, lane_id, nms_thr, s_x, s_y, s_s, s_lab, s_order, s_valid, s_sup, s_keep);
@@ -521,20 +542,48 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
     }
 }
 
+// Waymo: medoid (vehicle frame) -> global frame for the lane lookup (src/waymo/2d_to_3d.py:684-690):
+// rotate with the float32 rotation, then translate, like LidarPointCloud.rotate/translate on one point.
+__global__ void k_centroid_transform(const float *__restrict__ cin, const int32_t *__restrict__ medoid_pos,
+                                     const int32_t *__restrict__ mask_frame, int n_masks, const float *__restrict__ pose_rt,
+                                     float *__restrict__ cout)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_masks) return;
+    float x = cin[3 * m], y = cin[3 * m + 1], z = cin[3 * m + 2];
+    if (medoid_pos[m] >= 0) {
+        const float *p = pose_rt + (size_t)mask_frame[m] * 12;     // [0..8] R row-major, [9..11] t
+        float ax, ay, az;
+        cm3d_rot3(p, x, y, z, ax, ay, az);
+        x = ax + p[9]; y = ay + p[10]; z = az + p[11];
+    }
+    cout[3 * m] = x; cout[3 * m + 1] = y; cout[3 * m + 2] = z;
+}
+
+extern "C" int cm3d_centroid_transform(const float *centroid_in, const int32_t *medoid_pos, const int32_t *mask_frame,
+                                       int32_t n_masks, const float *pose_rt, float *centroid_out, cm3d_stream_t stream)
+{
+    if (!centroid_in || !medoid_pos || !mask_frame || !pose_rt || !centroid_out || n_masks <= 0) return CM3D_ERR_ARG;
+    hipLaunchKernelGGL(k_centroid_transform, dim3((n_masks + 255) / 256), dim3(256), 0, (hipStream_t)stream, centroid_in, medoid_pos,
+                       mask_frame, n_masks, pose_rt, centroid_out);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
+}
+
 extern "C" int cm3d_box_nms(const float *centroid, const int32_t *medoid_pos, const int32_t *mask_off, int32_t n_frames,
                             int32_t n_masks, const int32_t *class_id, const double *score, const float *lane,
                             const int32_t *lane_off, const int32_t *frame_lane, const int32_t *lane_idx,
                             const double *lane_dist, const double *prior_wlh, const int32_t *is_vehicle,
-                            const double *nms_thr, int32_t n_classes, const double *ego_xyz, double *box, int32_t *flags,
-                            cm3d_stream_t stream)
+                            const int32_t *nms_group, const double *nms_thr, int32_t n_classes, const double *ego_xyz,
+                            const float *pose_inv, double *box, int32_t *flags, cm3d_stream_t stream)
 {
     if (!centroid || !medoid_pos || !mask_off || !class_id || !score || !lane || !lane_off || !frame_lane || !lane_idx ||
-        !lane_dist || !prior_wlh || !is_vehicle || !nms_thr || !ego_xyz || !box || !flags)
+        !lane_dist || !prior_wlh || !is_vehicle || !nms_group || !nms_thr || (!ego_xyz && !pose_inv) || !box || !flags)
         return CM3D_ERR_ARG;
     if (n_frames <= 0 || n_masks <= 0 || n_classes <= 0) return CM3D_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_box_nms, dim3(n_frames), dim3(64), 0, st, centroid, medoid_pos, mask_off, class_id, score, lane,
-                       lane_off, frame_lane, lane_idx, lane_dist, prior_wlh, is_vehicle, nms_thr, n_classes, ego_xyz, box, flags);
+                       lane_off, frame_lane, lane_idx, lane_dist, prior_wlh, is_vehicle, nms_group, nms_thr, n_classes, ego_xyz, pose_inv, box, flags);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

@@ -55,7 +55,13 @@ class ClassTable:
     names: List[str]
     prior_wlh: np.ndarray      # (n,3) float64
     is_vehicle: np.ndarray     # (n,) int32
-    nms_thr: np.ndarray        # (n,) float64
+    nms_thr: np.ndarray        # (g,) float64, squared-distance threshold per NMS label
+    nms_group: Optional[np.ndarray] = None   # (n,) int32 NMS label of each class (default: the class itself)
+    out_names: Optional[List[str]] = None    # what the writer calls each class (Waymo: the Waymo type)
+
+    def __post_init__(self):
+        if self.nms_group is None:
+            self.nms_group = np.arange(len(self.names), dtype=np.int32)
 
     @staticmethod
     def nuscenes(shape_priors=None):
@@ -65,6 +71,20 @@ class ClassTable:
                           prior_wlh=np.array([pri[n] for n in names], np.float64),
                           is_vehicle=np.array([n in PUSHED_CLASSES for n in names], np.int32),
                           nms_thr=np.array([THRESHS_BY_LABEL[n] for n in names], np.float64))
+
+    @staticmethod
+    def waymo(shape_priors=None):
+        """Reference src/waymo: same priors and pushed classes, classes renamed through NUSC_TO_WAYMO
+        (cfg/prompt_cfg.py:286-297), NMS per Waymo type with the thresholds of 2d_to_3d.py:1147-1158."""
+        from . import waymo as wm
+        base = ClassTable.nuscenes(shape_priors)
+        types = [wm.WAYMO_TYPE.get(wm.NUSC_TO_WAYMO[n], -1) for n in base.names]
+        thr = np.zeros(5, np.float64)
+        for t, v in wm.THRESHS_BY_TYPE.items():
+            thr[t] = v
+        return ClassTable(names=base.names, prior_wlh=base.prior_wlh, is_vehicle=base.is_vehicle, nms_thr=thr,
+                          nms_group=np.array([max(t, 0) for t in types], np.int32),
+                          out_names=[wm.NUSC_TO_WAYMO[n] for n in base.names])
 
     def index(self, detection_name):
         return self.names.index(detection_name)   # ValueError for an unknown class, like the reference's KeyError
@@ -97,6 +117,9 @@ class HostBatch:
     height: int
     tokens: List[str]
     labels: List[List[str]]
+    pose_rt: Optional[np.ndarray] = None      # (F,12) float32, Waymo: vehicle -> global rotate/translate
+    pose_inv: Optional[np.ndarray] = None     # (F,16) float32, Waymo: inverse of the float32 frame pose
+    ego_box: bool = True                      # nuScenes drops the ego-box points (:442-445); Waymo does not
 
     @property
     def n_frames(self):
@@ -120,6 +143,7 @@ def pack_frames(frames: Sequence, lane_tables: Sequence[np.ndarray], frame_lane:
     raws, xfs, row_off, fso = [], [], [0], [0]
     cams, mask_off, mask_cam, mask_frame = [], [0], [], []
     cnts, rle_off, class_id, score, ego, tokens, labels = [], [0], [], [], [], [], []
+    pose_rt, pose_inv = [], []
     stride = frames[0].sweeps_raw[0].shape[1]
     for fi, fr in enumerate(frames):
         if fr.width != W or fr.height != H or fr.cams.shape[0] != n_cams:
@@ -147,11 +171,20 @@ def pack_frames(frames: Sequence, lane_tables: Sequence[np.ndarray], frame_lane:
         mask_off.append(mask_off[-1] + n)
         mask_cam.extend(int(c) for c in fr.cam_nums)
         mask_frame.extend([fi] * n)
-        class_id.extend(classes.index(get_detection_name(l)) for l in fr.labels)
+        for l in fr.labels:
+            ci = classes.index(get_detection_name(l))
+            if classes.out_names is not None and classes.out_names[ci] == "":
+                raise ValueError(f"label {l!r} has no output type")     # the reference raises ValueError (src/waymo/2d_to_3d.py:1054-1062)
+            class_id.append(ci)
         score.extend(float(s) for s in fr.scores)
         ego.append(np.asarray(fr.ego_xyz, np.float64))
         tokens.append(fr.token)
         labels.append(list(fr.labels))
+        if getattr(fr, "pose", None) is not None:
+            from . import waymo as wm
+            rt, inv = wm.pose_records(fr.pose)
+            pose_rt.append(rt)
+            pose_inv.append(inv)
     lane32 = [np.asarray(t, np.float64).astype(np.float32).reshape(-1, 3) for t in lane_tables]   # torch.Tensor(...) at :278
     lane_off = np.concatenate([[0], np.cumsum([t.shape[0] for t in lane32])]).astype(np.int32)
     i32 = lambda a: np.asarray(a, np.int32)
@@ -163,7 +196,10 @@ def pack_frames(frames: Sequence, lane_tables: Sequence[np.ndarray], frame_lane:
         rle_counts=np.concatenate(cnts).astype(np.uint32) if cnts else np.zeros(0, np.uint32), rle_off=i32(rle_off),
         class_id=i32(class_id), score=np.asarray(score, np.float64),
         lane=np.concatenate(lane32, 0), lane_off=lane_off, frame_lane=i32(frame_lane),
-        ego_xyz=np.stack(ego), width=W, height=H, tokens=tokens, labels=labels)
+        ego_xyz=np.stack(ego), width=W, height=H, tokens=tokens, labels=labels,
+        pose_rt=np.stack(pose_rt).astype(np.float32) if len(pose_rt) == len(frames) and frames else None,
+        pose_inv=np.stack(pose_inv).astype(np.float32) if len(pose_inv) == len(frames) and frames else None,
+        ego_box=not (len(pose_rt) == len(frames) and len(frames) > 0))
 
 
 # ---- device side ----------------------------------------------------------------
@@ -193,6 +229,7 @@ class LiftEngine:
         self.prior_wlh = torch.from_numpy(self.classes.prior_wlh).to(d)
         self.is_vehicle = torch.from_numpy(self.classes.is_vehicle).to(d)
         self.nms_thr = torch.from_numpy(self.classes.nms_thr).to(d)
+        self.nms_group = torch.from_numpy(np.ascontiguousarray(self.classes.nms_group, np.int32)).to(d)
 
     # -- upload + allocation
     def upload(self, hb: HostBatch, dense_masks: Optional[torch.Tensor] = None):
@@ -215,6 +252,9 @@ class LiftEngine:
         b.cams = t(hb.cams); b.mask_off = t(hb.mask_off); b.mask_cam = t(hb.mask_cam); b.mask_frame = t(hb.mask_frame)
         b.rle_counts = t(hb.rle_counts.view(np.int32)); b.rle_off = t(hb.rle_off)
         b.class_id = t(hb.class_id); b.score = t(hb.score)
+        b.pose_rt = t(hb.pose_rt) if hb.pose_rt is not None else None
+        b.pose_inv = t(hb.pose_inv) if hb.pose_inv is not None else None
+        b.halfw = self.halfw if hb.ego_box else 0.0
         b.lane = t(hb.lane); b.lane_off = t(hb.lane_off); b.frame_lane = t(hb.frame_lane); b.ego_xyz = t(hb.ego_xyz)
         b.pt_cap = hb.n_raw_rows
         b.max_pts = int(max(hb.sweep_row_off[hb.frame_sweep_off[1:]] - hb.sweep_row_off[hb.frame_sweep_off[:-1]]))
@@ -230,6 +270,7 @@ class LiftEngine:
         b.hit_count = e(M); b.hit_off = e(M + 1); b.tile_off = e(M + 1)
         b.hit_idx = e(b.idx_cap)
         b.medoid_pos = e(M); b.centroid = e(M, 3, dtype=torch.float32)
+        b.centroid_g = e(M, 3, dtype=torch.float32) if hb.pose_rt is not None else b.centroid
         b.colsum = e(b.idx_cap, dtype=torch.float32) if self.keep_colsum else None
         b.lane_idx = e(M); b.lane_dist = e(M, dtype=torch.float64)
         b.box = e(M, _lib.BOX_STRIDE, dtype=torch.float64); b.flags = e(M)
@@ -279,7 +320,7 @@ class LiftEngine:
     def stage_sweeps(self, st):
         b = self.b
         check(self.lib.cm3d_sweep_prep(_ptr(b.raw), b.hb.raw_stride, _ptr(b.sweep_row_off), b.S, b.hb.max_rows_per_sweep,
-                                       _ptr(b.sweep_xf), _ptr(b.frame_sweep_off), b.F, self.halfw, _ptr(b.points), b.pt_cap,
+                                       _ptr(b.sweep_xf), _ptr(b.frame_sweep_off), b.F, b.halfw, _ptr(b.points), b.pt_cap,
                                        _ptr(b.pt_off), _ptr(b.status), _ptr(b.ws), b.ws_bytes, st), "cm3d_sweep_prep")
 
     def stage_masks(self, st, masks="dense"):
@@ -323,16 +364,20 @@ class LiftEngine:
 
     def stage_lanes(self, st):
         b = self.b
-        check(self.lib.cm3d_lane_nn(_ptr(b.centroid), _ptr(b.medoid_pos), _ptr(b.mask_frame), b.M, _ptr(b.lane), _ptr(b.lane_off),
+        if b.pose_rt is not None:       # Waymo: the lane lookup happens in the global frame
+            check(self.lib.cm3d_centroid_transform(_ptr(b.centroid), _ptr(b.medoid_pos), _ptr(b.mask_frame), b.M, _ptr(b.pose_rt),
+                                                   _ptr(b.centroid_g), st), "cm3d_centroid_transform")
+        check(self.lib.cm3d_lane_nn(_ptr(b.centroid_g), _ptr(b.medoid_pos), _ptr(b.mask_frame), b.M, _ptr(b.lane), _ptr(b.lane_off),
                                     _ptr(b.frame_lane), b.n_tables, b.n_lane, _ptr(b.grid), _ptr(b.lane_idx),
                                     _ptr(b.lane_dist), _ptr(b.ws), b.ws_bytes, st), "cm3d_lane_nn")
 
     def stage_boxes(self, st):
         b = self.b
-        check(self.lib.cm3d_box_nms(_ptr(b.centroid), _ptr(b.medoid_pos), _ptr(b.mask_off), b.F, b.M, _ptr(b.class_id),
+        check(self.lib.cm3d_box_nms(_ptr(b.centroid_g), _ptr(b.medoid_pos), _ptr(b.mask_off), b.F, b.M, _ptr(b.class_id),
                                     _ptr(b.score), _ptr(b.lane), _ptr(b.lane_off), _ptr(b.frame_lane), _ptr(b.lane_idx),
-                                    _ptr(b.lane_dist), _ptr(self.prior_wlh), _ptr(self.is_vehicle), _ptr(self.nms_thr),
-                                    len(self.classes.names), _ptr(b.ego_xyz), _ptr(b.box), _ptr(b.flags), st), "cm3d_box_nms")
+                                    _ptr(b.lane_dist), _ptr(self.prior_wlh), _ptr(self.is_vehicle), _ptr(self.nms_group),
+                                    _ptr(self.nms_thr), len(self.classes.names), _ptr(b.ego_xyz), _ptr(b.pose_inv), _ptr(b.box),
+                                    _ptr(b.flags), st), "cm3d_box_nms")
 
     STAGES = ("sweeps", "masks", "project", "compact", "medoid", "lanes", "boxes")
 
@@ -370,7 +415,7 @@ class LiftEngine:
             pt_off=b.pt_off.cpu().numpy(), points=b.points[:n_pts].cpu().numpy(),
             hit_off=b.hit_off.cpu().numpy(), hit_idx=b.hit_idx[:n_idx].cpu().numpy(),
             bbox=b.bbox.cpu().numpy(), medoid_pos=b.medoid_pos.cpu().numpy(), centroid=b.centroid.cpu().numpy(),
-            lane_idx=b.lane_idx.cpu().numpy(), lane_dist=b.lane_dist.cpu().numpy(),
+            lane_idx=b.lane_idx.cpu().numpy(), lane_dist=b.lane_dist.cpu().numpy(), centroid_global=b.centroid_g.cpu().numpy(),
             box=b.box.cpu().numpy(), flags=b.flags.cpu().numpy())
         if b.colsum is not None:
             out["colsum"] = b.colsum[:n_idx].cpu().numpy()

@@ -184,12 +184,14 @@ def _box_nms(centroids, class_ids, scores, yaws, ego_xyz, classes, valid=None):
     d = dict(cent=_t(cent), med=_t(med), mask_off=_t(np.array([0, n], np.int32)), cls=_t(np.asarray(class_ids, np.int32)),
              score=_t(np.asarray(scores, np.float64)), lane=_t(lane), lane_off=_t(np.array([0, n], np.int32)),
              frame_lane=_t(np.array([0], np.int32)), lane_idx=_t(np.arange(n, dtype=np.int32)), lane_dist=_t(np.zeros(n, np.float64)),
-             prior=_t(classes.prior_wlh), veh=_t(classes.is_vehicle), thr=_t(classes.nms_thr), ego=_t(np.asarray(ego_xyz, np.float64).reshape(1, 3)))
+             prior=_t(classes.prior_wlh), veh=_t(classes.is_vehicle), thr=_t(classes.nms_thr),
+             grp=_t(np.ascontiguousarray(classes.nms_group, np.int32)), ego=_t(np.asarray(ego_xyz, np.float64).reshape(1, 3)))
     box, flags = _e(n, _lib.BOX_STRIDE, dtype=torch.float64), _e(n)
     check(L.cm3d_box_nms(d["cent"].data_ptr(), d["med"].data_ptr(), d["mask_off"].data_ptr(), 1, n, d["cls"].data_ptr(),
                          d["score"].data_ptr(), d["lane"].data_ptr(), d["lane_off"].data_ptr(), d["frame_lane"].data_ptr(),
                          d["lane_idx"].data_ptr(), d["lane_dist"].data_ptr(), d["prior"].data_ptr(), d["veh"].data_ptr(),
-                         d["thr"].data_ptr(), len(classes.names), d["ego"].data_ptr(), box.data_ptr(), flags.data_ptr(), _st()),
+                         d["grp"].data_ptr(), d["thr"].data_ptr(), len(classes.names), d["ego"].data_ptr(), 0, box.data_ptr(),
+                         flags.data_ptr(), _st()),
           "cm3d_box_nms")
     return box.cpu().numpy(), flags.cpu().numpy()
 

@@ -221,6 +221,39 @@ def make_frame(cfg: SyntheticConfig, index: int) -> Frame:
                  ego_xyz=ego_t.copy(), width=W, height=H, meta={"ego_yaw": ego_yaw})
 
 
+def make_waymo_frame(cfg: SyntheticConfig, index: int):
+    """A Waymo-shaped frame (reference src/waymo/2d_to_3d.py): one vehicle-frame cloud, cameras given as
+    4x4 extrinsics in Waymo's camera axes (x forward, y left, z up) + [fx, fy, cx, cy] intrinsics, a frame
+    pose (vehicle -> global).  Built on make_frame so masks and points stay consistent."""
+    from . import waymo as wm
+    fr = make_frame(cfg, index)
+    rng = np.random.default_rng(cfg.seed + 7919 * (index + 1))
+    xf = fr.sweep_xf[0].astype(np.float64)
+    R_l, t_l = xf[0:9].reshape(3, 3), xf[9:12]
+    pts_vehicle = (fr.sweeps_raw[0][:, :3].astype(np.float64) @ R_l.T + t_l).astype(np.float32)
+    S = np.array([[0, -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float64)      # :561-565
+    cams = []
+    for c in range(fr.cams.shape[0]):
+        rec = fr.cams[c].astype(np.float64)
+        T = np.eye(4)
+        T[:3, :3] = rec[15:24].reshape(3, 3).T          # optical camera -> vehicle
+        T[:3, 3] = -rec[12:15]
+        K = rec[24:33].reshape(3, 3) / cfg.ratio
+        cams.append(((T @ S).reshape(16), [K[0, 0], K[1, 1], K[0, 2], K[1, 2], 0, 0, 0, 0, 0]))
+    yaw = rng.uniform(-np.pi, np.pi)
+    P = np.eye(4)
+    P[:3, :3] = geo.rot_z(yaw) @ geo.quat_to_rotmat([1.0, rng.normal() * 0.01, rng.normal() * 0.01, 0.0])
+    P[:3, 3] = [5000.0 + rng.uniform(-300, 300), -3000.0 + rng.uniform(-300, 300), 20.0 + rng.uniform(-5, 5)]
+    ok = {"barrier": "car", "trafficcone": "human"}
+    labels = [ok.get(l, l) for l in fr.labels]
+    wf = wm.frame_from_extracted(f"waymo-{cfg.seed}-{index:06d}", pts_vehicle, cams, fr.rles, labels, fr.scores, fr.cam_nums,
+                                 P.reshape(16), fr.width, fr.height, timestamp_micros=1_550_000_000_000_000 + index * 100_000,
+                                 context_name=f"synthetic-context-{cfg.seed}")
+    # cam records must use this config's ratio (the reference hard-codes 1024/1920 for the real dataset)
+    wf.cams = np.stack([wm.cam_record(e, i, ratio=cfg.ratio) for e, i in cams])
+    return wf
+
+
 def make_lane_table(center_xy, n_points=50000, seed=0, extent=200.0):
     """Synthetic HD-map lane centre-lines discretised at 0.5 m as (x, y, yaw) rows
     (what nuscenes-devkit's discretize_lanes yields, reference 2d_to_3d.py:228-240)."""

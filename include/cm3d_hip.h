@@ -178,17 +178,27 @@ int cm3d_lane_nn(const float *centroid, const int32_t *medoid_pos, const int32_t
  * Replaces stage 2 (2d_to_3d.py:745-817: shape prior, lane-yaw rotation, push_centroid
  * :164-198) and circle_nms (:309-332 with the thresholds of :850-861).
  *  class_id int32[n_masks] index into the class tables; score double[n_masks]
- *  prior_wlh double[n_classes][3]; is_vehicle int32[n_classes]; nms_thr double[n_classes]
- *  ego_xyz double[F][3]   LIDAR_TOP ego_pose translation of each frame (:793-795)
- *  box   double[n_masks][CM3D_BOX_STRIDE] OUT: tx,ty,tz, qw,qz (rotation = [qw,0,0,qz]), lane yaw, lane dist,
- *        score, class id, flags -- the fixed-size record that the multi-GPU gather ships
+ *  prior_wlh double[n_classes][3]; is_vehicle int32[n_classes] (pushed classes, :763);
+ *  nms_group int32[n_classes] NMS label of each class (the class itself for nuScenes, the Waymo type
+ *  for Waymo, src/waymo/cfg/prompt_cfg.py:286-297); nms_thr double[] squared-distance threshold per NMS label
+ *  ego_xyz double[F][3]   LIDAR_TOP ego_pose translation of each frame (:793-795)            (nuScenes mode)
+ *  pose_inv float[F][16]  NULL for nuScenes.  Waymo mode (a17, src/waymo/2d_to_3d.py:812-816,978-1001):
+ *        inverse of the float32 frame pose; centroids are global, the kernel maps them back to the vehicle
+ *        frame in float64, pushes with ego_frame=True and emits the heading instead of a quaternion.
+ *  box   double[n_masks][CM3D_BOX_STRIDE] OUT: tx,ty,tz, qw,qz (rotation = [qw,0,0,qz]; Waymo: heading,0),
+ *        lane yaw, lane dist, score, class id, flags -- the fixed-size record that the multi-GPU gather ships
  *  flags int32[n_masks] OUT: bit0 box exists (mask had points), bit1 box survives NMS */
 int cm3d_box_nms(const float *centroid, const int32_t *medoid_pos, const int32_t *mask_off, int32_t n_frames,
                  int32_t n_masks, const int32_t *class_id, const double *score, const float *lane,
                  const int32_t *lane_off, const int32_t *frame_lane, const int32_t *lane_idx,
                  const double *lane_dist, const double *prior_wlh, const int32_t *is_vehicle,
-                 const double *nms_thr, int32_t n_classes, const double *ego_xyz, double *box, int32_t *flags,
-                 cm3d_stream_t stream);
+                 const int32_t *nms_group, const double *nms_thr, int32_t n_classes, const double *ego_xyz,
+                 const float *pose_inv, double *box, int32_t *flags, cm3d_stream_t stream);
+
+/* a17 (Waymo): medoid in the vehicle frame -> global frame, float32 rotate then translate
+ * (src/waymo/2d_to_3d.py:684-690).  pose_rt float[F][12]: [0..8] rotation row-major, [9..11] translation. */
+int cm3d_centroid_transform(const float *centroid_in, const int32_t *medoid_pos, const int32_t *mask_frame,
+                            int32_t n_masks, const float *pose_rt, float *centroid_out, cm3d_stream_t stream);
 
 /* circle_nms alone (2d_to_3d.py:309-332) on float64 centres: boxes [frame_off[f], frame_off[f+1]) form
  * one sample; keep[i] = 1 for the survivors.  Order: descending score, ties by descending index. */

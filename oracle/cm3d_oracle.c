@@ -414,3 +414,53 @@ ORC_API int orc_circle_nms(const double *x, const double *y, const double *score
     free(order); free(sup);
     return kept;
 }
+
+/* ------------------------------------------------------------------ */
+/* a17 Waymo deltas (reference src/waymo/2d_to_3d.py).
+ * orc_centroid_transform: medoid (vehicle frame) -> global, float32 rotate then translate (:684-690).
+ * orc_box_assemble_waymo: global float32 centroid -> vehicle frame with inv(float32 pose) in float64
+ * (:812-816), push_centroid(ego_frame=True) with the GLOBAL lane yaw (:995, :175-205), heading =
+ * as_euler('xyz')[2] of R_inv . Rz(yaw) (:978-1001); other classes: raw centroid, heading 0. */
+ORC_API void orc_centroid_transform(const float *c, const float *pose_rt, float *out)
+{
+    float o[3];
+    for (int r = 0; r < 3; ++r) {
+        float acc = pose_rt[3 * r] * c[0];
+        acc = fmaf(pose_rt[3 * r + 1], c[1], acc);
+        acc = fmaf(pose_rt[3 * r + 2], c[2], acc);
+        o[r] = acc;
+    }
+    for (int r = 0; r < 3; ++r) out[r] = o[r] + pose_rt[9 + r];
+}
+
+ORC_API void orc_box_assemble_waymo(const float *centroid_global, const float *pose_inv, const double *prior, float yaw,
+                                    int is_vehicle, double *out_t, double *out_heading)
+{
+    double g[3] = { (double)centroid_global[0], (double)centroid_global[1], (double)centroid_global[2] };
+    double c[3];
+    for (int r = 0; r < 3; ++r)
+        c[r] = (double)pose_inv[4 * r] * g[0] + (double)pose_inv[4 * r + 1] * g[1] + (double)pose_inv[4 * r + 2] * g[2] + (double)pose_inv[4 * r + 3];
+    if (!is_vehicle) { out_t[0] = c[0]; out_t[1] = c[1]; out_t[2] = c[2]; *out_heading = 0.0; return; }
+    double cs = (double)cosf(yaw), sn = (double)sinf(yaw);
+    double qw, qz;
+    if (cs < -cs) { double t = 1.0 - cs - cs + 1.0; double f = 0.5 / sqrt(t); qw = (sn + sn) * f; qz = t * f; }
+    else          { double t = 1.0 + cs + cs + 1.0; double f = 0.5 / sqrt(t); qw = t * f; qz = (sn + sn) * f; }
+    double phi = 2.0 * atan2(qw, qz);
+    if (phi > M_PI) phi -= 2.0 * M_PI;
+    if (phi <= -M_PI) phi += 2.0 * M_PI;
+    double theta = -phi;
+    if (theta != theta) theta = 0.5 * M_PI;
+    double ex = c[0], ey = c[1];
+    double alpha = atan(fabs(ey) / fabs(ex));
+    if (ex < 0) { if (ey < 0) alpha = -M_PI + alpha; else alpha = M_PI - alpha; }
+    else        { if (ey < 0) alpha = -alpha; }
+    double l = prior[0], w = prior[1];
+    double o1 = fabs(w / (2.0 * sin(theta - alpha)));
+    double o2 = fabs(l / (2.0 * cos(theta - alpha)));
+    double off = o1 < o2 ? o1 : o2;
+    if (o1 != o1 || o2 != o2) off = NAN;
+    out_t[0] = c[0] + off * cos(alpha);
+    out_t[1] = c[1] + off * sin(alpha);
+    out_t[2] = c[2];
+    *out_heading = atan2((double)pose_inv[4] * cs + (double)pose_inv[5] * sn, (double)pose_inv[0] * cs + (double)pose_inv[1] * sn);
+}

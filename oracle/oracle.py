@@ -52,6 +52,10 @@ def _load():
     lib.orc_lane_nn.argtypes = [p, i64, p, i64, p, p]
     lib.orc_box_assemble.restype = None
     lib.orc_box_assemble.argtypes = [p, p, f32, p, i32, p, p]
+    lib.orc_centroid_transform.restype = None
+    lib.orc_centroid_transform.argtypes = [p, p, p]
+    lib.orc_box_assemble_waymo.restype = None
+    lib.orc_box_assemble_waymo.argtypes = [p, p, p, f32, i32, p, p]
     lib.orc_circle_nms.restype = i32
     lib.orc_circle_nms.argtypes = [p, p, p, p, i32, p, p]
     return lib
@@ -261,3 +265,45 @@ def stage2_frame(centroids, med, class_id, scores, lane_pts, ego_xyz):
     if vi.size:
         keep[vi] = circle_nms(t[vi, 0], t[vi, 1], np.asarray(scores, np.float64)[vi], np.asarray(class_id, np.int32)[vi], NMS_THR)
     return dict(valid=valid, keep=keep, translation=t, rotation=q, lane_idx=lane_j, lane_dist=lane_d, yaw=yaw)
+
+
+# ---------------------------------------------------------------- a17 (Waymo)
+WAYMO_NMS_GROUP = np.array([1, 1, 1, 1, 1, 2, 1, 4, 0, 0], np.int32)      # NUSC_TO_WAYMO -> Label.Type, per CLASSES entry
+WAYMO_NMS_THR = np.array([1, 4, 0.175, 0.175, 0.85], np.float64)          # by Label.Type (src/waymo/2d_to_3d.py:1147-1158)
+
+
+def centroid_transform(c, pose_rt):
+    out = np.empty(3, np.float32)
+    lib().orc_centroid_transform(_ptr(_f32(c).reshape(3)), _ptr(_f32(pose_rt)), _ptr(out))
+    return out
+
+
+def box_assemble_waymo(centroid_global, pose_inv, prior, yaw, is_vehicle):
+    t = np.empty(3, np.float64)
+    h = np.empty(1, np.float64)
+    lib().orc_box_assemble_waymo(_ptr(_f32(centroid_global).reshape(3)), _ptr(_f32(pose_inv)), _ptr(np.ascontiguousarray(prior, np.float64)),
+                                 float(np.float32(yaw)), int(bool(is_vehicle)), _ptr(t), _ptr(h))
+    return t, float(h[0])
+
+
+def stage2_frame_waymo(centroids_vehicle, med, class_id, scores, lane_pts, pose_rt, pose_inv):
+    """Waymo stage 2 + NMS for one frame.  scores are the proto-float (float32) values."""
+    n = len(med)
+    valid = np.asarray(med) >= 0
+    t = np.zeros((n, 3)); heading = np.zeros(n)
+    lane_j = np.full(n, -1, np.int32); lane_d = np.full(n, np.nan); yaw = np.zeros(n, np.float32)
+    cg = np.zeros((n, 3), np.float32)
+    vi = np.flatnonzero(valid)
+    if vi.size:
+        for k in vi:
+            cg[k] = centroid_transform(centroids_vehicle[k], pose_rt)
+        j, d = lane_nn(cg[vi], lane_pts)
+        lane_j[vi], lane_d[vi] = j, d
+        lane32 = _f32(lane_pts).reshape(-1, 3)
+        yaw[vi] = lane32[j, 2]
+        for k in vi:
+            t[k], heading[k] = box_assemble_waymo(cg[k], pose_inv, PRIORS_WLH[class_id[k]], yaw[k], IS_VEHICLE[class_id[k]])
+    keep = np.zeros(n, bool)
+    if vi.size:
+        keep[vi] = circle_nms(t[vi, 0], t[vi, 1], np.asarray(scores, np.float64)[vi], WAYMO_NMS_GROUP[np.asarray(class_id)[vi]], WAYMO_NMS_THR)
+    return dict(valid=valid, keep=keep, translation=t, heading=heading, lane_idx=lane_j, lane_dist=lane_d, yaw=yaw, centroid_global=cg)

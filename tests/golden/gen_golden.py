@@ -76,6 +76,35 @@ def _load_reference():
     return pcd, ref
 
 
+def _load_waymo_reference():
+    """src/waymo/2d_to_3d.py with inert stand-ins for tensorflow / waymo_open_dataset / ... (never called by
+    the two helpers used here)."""
+    for name in ["tensorflow", "tensorflow.compat.v1", "waymo_open_dataset", "waymo_open_dataset.utils",
+                 "waymo_open_dataset.utils.range_image_utils", "waymo_open_dataset.utils.transform_utils",
+                 "waymo_open_dataset.utils.frame_utils", "waymo_open_dataset.dataset_pb2", "waymo_open_dataset.label_pb2",
+                 "waymo_open_dataset.protos", "waymo_open_dataset.protos.metrics_pb2", "pycocotools.mask", "open3d", "trimesh",
+                 "cfg", "cfg.prompt_cfg"]:
+        parts = name.split(".")
+        for i in range(1, len(parts) + 1):
+            n = ".".join(parts[:i])
+            if n not in sys.modules:
+                try:
+                    importlib.import_module(n)
+                except Exception:
+                    sys.modules[n] = _Stub(n)
+    wdir = "/root/reference/src/waymo"
+    spec = importlib.util.spec_from_file_location("utils.pcd", os.path.join(wdir, "utils/pcd.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["utils.pcd"] = m
+    spec.loader.exec_module(m)
+    sys.modules["utils"].pcd = m
+    spec = importlib.util.spec_from_file_location("ref_waymo_2d_to_3d", os.path.join(wdir, "2d_to_3d.py"))
+    w = importlib.util.module_from_spec(spec)
+    sys.modules["ref_waymo_2d_to_3d"] = w
+    spec.loader.exec_module(w)
+    return w
+
+
 def reference_mask_body(pcd, pts, cam, eroded_hw, min_dist=2.3):
     """2d_to_3d.py:543-617 on CPU tensors; cam = our float32 camera record (the tensors the
     reference builds at :570-577,:585-587).  Returns track_points (ascending point indices)."""
@@ -261,6 +290,31 @@ def main():
     report["G6 lane NN mismatches"] = int((lane32[j, 2] != yaws).sum() + (d != dists).sum())
     np.savez_compressed(os.path.join(HERE, "g6_lane_nn.npz"), lane=lane, centroids=cent, yaws=np.asarray(yaws), dists=np.asarray(dists),
                         coords=np.asarray(coords), oracle_idx=j)
+
+    # ---------------- G8: Waymo deltas (src/waymo/2d_to_3d.py: push_centroid(ego_frame=True), get_yaws_from_lane_coords)
+    wref = _load_waymo_reference()
+    g8 = {"push": [], "lanes": []}
+    worst8 = 0.0
+    for i in range(120):
+        cls = int(rng.integers(0, len(orc.CLASSES)))
+        yaw = np.float32(rng.uniform(-np.pi, np.pi))
+        d, a = rng.uniform(3, 60), rng.uniform(-np.pi, np.pi)
+        cen = np.array([d * np.cos(a), d * np.sin(a), rng.uniform(-1, 2)])
+        q = pyquaternion_from_rz(yaw)
+        pushed = wref.push_centroid(cen.copy(), list(priors[cls]), list(q), ego_frame=True)
+        # the oracle takes a global centroid and the inverse pose: identity pose makes them the same frame
+        t, _ = orc.box_assemble_waymo(cen.astype(np.float32), np.eye(4, dtype=np.float32).reshape(16), priors[cls], yaw, True)
+        pushed32 = wref.push_centroid(cen.astype(np.float32).astype(np.float64), list(priors[cls]), list(q), ego_frame=True)
+        worst8 = max(worst8, float(np.abs(t - pushed32).max()))
+        g8["push"].append({"centroid": [float(v) for v in cen.astype(np.float32)], "class": cls, "yaw": float(yaw),
+                           "pushed": [float(v) for v in pushed32]})
+    from types import SimpleNamespace as NS
+    for n in [1, 2, 5, 40]:
+        poly = np.cumsum(rng.normal(size=(n, 3)), 0) + [5000.0, -3000.0, 20.0]
+        out = wref.get_yaws_from_lane_coords([NS(x=float(p_[0]), y=float(p_[1]), z=float(p_[2])) for p_ in poly])
+        g8["lanes"].append({"polyline": poly.tolist(), "xyyaw": np.asarray(out).tolist()})
+    report["G8 waymo push_centroid max |oracle - reference|"] = worst8
+    json.dump(g8, open(os.path.join(HERE, "g8_waymo.json"), "w"))
 
     # ---------------- small helpers of the reference
     report["get_detection_name"] = {k: ref.get_detection_name(k) for k in ["trafficcone", "constructionvehicle", "human", "car"]}

@@ -9,7 +9,8 @@ def oracle_batch(orc, frames, lane_tables, frame_lane, hb):
     medoid_pos, centroid = [], []
     lane_idx, lane_dist, box, flags, bbox = [], [], [], [], []
     for fi, fr in enumerate(frames):
-        pts = np.concatenate([orc.sweep_prep(r, x[0:9], x[9:12], x[12:21], x[21:24])
+        halfw = orc.EGO_HALFW_F32 if hb.ego_box else np.float32(0.0)
+        pts = np.concatenate([orc.sweep_prep(r, x[0:9], x[9:12], x[12:21], x[21:24], halfw)
                               for r, x in zip(fr.sweeps_raw, fr.sweep_xf)], 0)
         pts_all.append(pts)
         pt_off.append(pt_off[-1] + pts.shape[0])
@@ -25,7 +26,14 @@ def oracle_batch(orc, frames, lane_tables, frame_lane, hb):
         medoid_pos.append(med)
         centroid.append(np.where(np.isnan(cent), 0, cent))
         m0, m1 = hb.mask_off[fi], hb.mask_off[fi + 1]
-        s2 = orc.stage2_frame(cent, med, hb.class_id[m0:m1], hb.score[m0:m1], lane_tables[frame_lane[fi]], fr.ego_xyz)
+        if hb.pose_rt is not None:      # Waymo (a17)
+            s2 = orc.stage2_frame_waymo(cent, med, hb.class_id[m0:m1], hb.score[m0:m1], lane_tables[frame_lane[fi]],
+                                        hb.pose_rt[fi], hb.pose_inv[fi])
+            s2["rotation"] = np.zeros((m1 - m0, 4))
+            s2["rotation"][:, 0] = s2["heading"]
+            s2["rotation"][~s2["valid"], 0] = 1.0
+        else:
+            s2 = orc.stage2_frame(cent, med, hb.class_id[m0:m1], hb.score[m0:m1], lane_tables[frame_lane[fi]], fr.ego_xyz)
         lane_idx.append(s2["lane_idx"]); lane_dist.append(s2["lane_dist"])
         b = np.zeros((m1 - m0, 10))
         b[:, 0:3] = np.where(s2["valid"][:, None], s2["translation"], 0.0)

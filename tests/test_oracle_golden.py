@@ -101,3 +101,30 @@ def test_rle_known_answers(oracle):
     s = oracle.rle_counts_to_string(cnts)
     assert s == b"61X13mN000`0"
     assert np.array_equal(oracle.rle_string_to_counts(s), cnts)
+
+
+def test_g8_waymo_helpers(oracle):
+    """Waymo deltas against the reference's src/waymo/2d_to_3d.py helpers: push_centroid(ego_frame=True)
+    and get_yaws_from_lane_coords (the host-side restatement in cm3d_amd.waymo)."""
+    from cm3d_amd import waymo as wm
+    g = json.load(open(os.path.join(G, "g8_waymo.json")))
+    eye = np.eye(4, dtype=np.float32).reshape(16)
+    for c in g["push"]:
+        t, _ = oracle.box_assemble_waymo(np.float32(c["centroid"]), eye, oracle.PRIORS_WLH[c["class"]], np.float32(c["yaw"]), True)
+        assert np.allclose(t, c["pushed"], rtol=0, atol=1e-5)
+    for c in g["lanes"]:
+        assert np.array_equal(wm.get_yaws_from_lane_coords(c["polyline"]), np.array(c["xyyaw"]).reshape(-1, 3))
+
+
+def test_waymo_class_table_and_writer():
+    from cm3d_amd import lifting, waymo as wm
+    ct = lifting.ClassTable.waymo()
+    assert ct.out_names[ct.index("bus")] == "vehicle" and ct.out_names[ct.index("bicycle")] == "cyclist"
+    assert ct.nms_group[ct.index("pedestrian")] == wm.WAYMO_TYPE["pedestrian"] and ct.nms_thr[1] == 4 and ct.nms_thr[4] == 0.85
+    o = wm.encode_object([1.0, 2.0, 3.0], 4.5, 1.8, 1.4, 0.25, 1, 0.5, "ctx", 1234567)
+    blob = wm.encode_objects([o, o])
+    # minimal wire-format parse: two length-delimited field-1 records
+    assert blob[0] == 0x0A and blob[1] == len(o) and blob[2 + len(o)] == 0x0A
+    assert np.frombuffer(o[6:14], np.float64)[0] == 1.0          # Box.center_x right after the nested headers
+    rt, inv = wm.pose_records(np.eye(4).reshape(16))
+    assert rt.shape == (12,) and inv.shape == (16,) and rt.dtype == np.float32
