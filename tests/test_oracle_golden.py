@@ -125,6 +125,6 @@ def test_waymo_class_table_and_writer():
     blob = wm.encode_objects([o, o])
     # minimal wire-format parse: two length-delimited field-1 records
     assert blob[0] == 0x0A and blob[1] == len(o) and blob[2 + len(o)] == 0x0A
-    assert np.frombuffer(o[6:14], np.float64)[0] == 1.0          # Box.center_x right after the nested headers
+    assert np.frombuffer(o[5:13], np.float64)[0] == 1.0           # Box.center_x: after Object.object, Label.box and field-1 headers
     rt, inv = wm.pose_records(np.eye(4).reshape(16))
     assert rt.shape == (12,) and inv.shape == (16,) and rt.dtype == np.float32
