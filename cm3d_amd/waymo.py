@@ -151,3 +151,42 @@ def objects_from_results(hb, res, classes, frame_meta):
                                      type_id=WAYMO_TYPE[classes.out_names[ci]], score=hb.score[m], context_name=ctx,
                                      timestamp_micros=ts))
     return out
+
+
+def decode_objects(blob):
+    """Inverse of encode_objects for the fields this writer emits (tests, debugging)."""
+    def rd_varint(b, i):
+        v, sh = 0, 0
+        while True:
+            c = b[i]; i += 1
+            v |= (c & 0x7F) << sh; sh += 7
+            if not c & 0x80:
+                return v, i
+
+    def fields(b):
+        i, out = 0, []
+        while i < len(b):
+            key, i = rd_varint(b, i)
+            f, w = key >> 3, key & 7
+            if w == 0:
+                v, i = rd_varint(b, i)
+            elif w == 1:
+                v = float(np.frombuffer(b[i:i + 8], np.float64)[0]); i += 8
+            elif w == 5:
+                v = float(np.frombuffer(b[i:i + 4], np.float32)[0]); i += 4
+            elif w == 2:
+                n, i = rd_varint(b, i)
+                v = bytes(b[i:i + n]); i += n
+            else:
+                raise ValueError("unsupported wire type")
+            out.append((f, v))
+        return out
+
+    objs = []
+    for f, payload in fields(blob):
+        o = dict(fields(payload))
+        label = dict(fields(o[1]))
+        box = dict(fields(label[1]))
+        objs.append(dict(center=[box[1], box[2], box[3]], width=box[4], length=box[5], height=box[6], heading=box[7],
+                         type=label[3], id=label[4].decode(), score=o[2], context_name=o[4].decode(), timestamp_micros=o[5]))
+    return objs

@@ -50,3 +50,55 @@ def test_nuscenes_entry_point_end_to_end(tmp_path, oracle):
     assert n_boxes > 10
     last = tables.samples_of_scene(tables.scene_by_name(names[1]))[2]["token"]
     assert got["results"][last] == []
+
+
+def test_waymo_entry_point(tmp_path, oracle):
+    """src/waymo/2d_to_3d.py on extracted-frame files, against the oracle on the same files."""
+    import pickle
+    from cm3d_amd import lifting, pipeline_waymo as pw, synthetic as syn, waymo as wm
+    from tests.helpers import oracle_batch
+    cfg = syn.config("tiny", n_cams=5)
+    scene = "segment-synthetic-0"
+    fdir, mdir = tmp_path / "frames" / scene, tmp_path / "masks" / scene
+    os.makedirs(fdir); os.makedirs(mdir)
+    rng = np.random.default_rng(3)
+    centre = None
+    for i in range(3):
+        fr = syn.make_waymo_frame(cfg, i)
+        P = np.asarray(fr.pose).reshape(4, 4)
+        centre = P[:2, 3] if centre is None else centre
+        # recover the raw calibration the frame was built from (the generator keeps it in the record only)
+        S = np.array([[0, -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float64)
+        base = syn.make_frame(cfg, i)
+        ext, intr = [], []
+        for c in range(base.cams.shape[0]):
+            rec = base.cams[c].astype(np.float64)
+            T = np.eye(4); T[:3, :3] = rec[15:24].reshape(3, 3).T; T[:3, 3] = -rec[12:15]
+            K = rec[24:33].reshape(3, 3) / cfg.ratio
+            ext.append((T @ S).reshape(16)); intr.append([K[0, 0], K[1, 1], K[0, 2], K[1, 2], 0, 0, 0, 0, 0])
+        rec = dict(points=fr.sweeps_raw[0][:, :3], extrinsics=np.array(ext), intrinsics=np.array(intr), pose=P.reshape(16),
+                   timestamp_micros=np.int64(fr.timestamp_micros), context_name=np.str_(fr.context_name))
+        if i == 0:
+            polys = [np.cumsum(np.concatenate([[[centre[0] - 200 + 40 * k, centre[1] - 200, 0.0]], np.tile([[0.0, 0.5, 0.0]], (800, 1))]), 0) for k in range(10)]
+            rec["lanes"] = np.vstack(polys); rec["lane_off"] = np.concatenate([[0], np.cumsum([len(p) for p in polys])])
+        np.savez_compressed(fdir / f"{i}_frame.npz", **rec)
+        pickle.dump(fr.rles, open(mdir / f"{i}_masks.pkl", "wb"))
+        json.dump({"labels": fr.labels, "detection_scores": fr.scores, "cam_nums": fr.cam_nums}, open(mdir / f"{i}_data.json", "w"))
+    out = tmp_path / "out" / "pred.bin"
+    r = subprocess.run([sys.executable, "2d_to_3d.py", "--frames-dir", str(tmp_path / "frames"), "--mask-dir", str(tmp_path / "masks"),
+                        "--output", str(out)], cwd=os.path.join(ROOT, "src", "waymo"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blob = open(out, "rb").read()
+    # expectation: the oracle over the frames as the entry point loads them (ratio = 1024/1920 like the reference)
+    frames, lanes = pw.load_scene(str(tmp_path / "frames"), str(tmp_path / "masks"), scene)
+    classes = lifting.ClassTable.waymo()
+    hb = lifting.pack_frames(frames, [lanes], [0] * len(frames), classes)
+    exp = oracle_batch(oracle, frames, [lanes], [0] * len(frames), hb)
+    exp_objs = wm.objects_from_results(hb, exp, classes, [(f.context_name, f.timestamp_micros) for f in frames])
+    assert f"wrote {len(exp_objs)} objects" in r.stdout
+    got, want = wm.decode_objects(blob), wm.decode_objects(wm.encode_objects(exp_objs))
+    assert len(got) == len(want) > 5
+    for a, b in zip(got, want):
+        assert (a["type"], a["id"], a["context_name"], a["timestamp_micros"], a["score"]) == (b["type"], b["id"], b["context_name"], b["timestamp_micros"], b["score"])
+        assert (a["width"], a["length"], a["height"]) == (b["width"], b["length"], b["height"])
+        assert np.allclose(a["center"] + [a["heading"]], b["center"] + [b["heading"]], rtol=0, atol=1e-4)
