@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcm3d_hip.so")
 
 ABI_VERSION = 1
-CAM_STRIDE = 40
+CAM_STRIDE = 64
 SWEEP_XF_STRIDE = 24
 MAX_CAMS = 8
 MAX_MASKS_PER_FRAME = 1024

@@ -23,19 +23,24 @@ static __device__ __forceinline__ int ph_slot(int j) { return (int)(threadIdx.x 
 // One pinhole projection through the reference's float32 op chain, branch-free (the kernel is
 // instruction-issue bound and divergent control flow costs scalar instructions).  Returns the pixel
 // code (iv << 16 | iu) or -1.  cm = camera record in LDS.
-static __device__ __forceinline__ int project_pixel(const float *cm, float4 pt, bool pre_ok, float min_dist, int W, int H)
+static __device__ __forceinline__ int project_pixel(const float *cm, int ns, int fl, float4 pt, bool pre_ok, float min_dist, int W, int H)
 {
-    // global -> ego(cam time) -> camera: p += t1; p = R1 p; p += t2; p = R2 p   (2d_to_3d.py:569-577)
-    float x = pt.x + cm[0], y = pt.y + cm[1], z = pt.z + cm[2];
-    float ax, ay, az;
-    cm3d_rot3(cm + 3, x, y, z, ax, ay, az);
-    if (cm[33] > 1.5f) {                                      // block-uniform
-        x = ax + cm[12]; y = ay + cm[13]; z = az + cm[14];
-        cm3d_rot3(cm + 15, x, y, z, ax, ay, az);
+    // up to three rigid stages `p += t_pre; p = R p; p += t_post` (nuScenes: global -> ego(cam time) ->
+    // camera, 2d_to_3d.py:569-577; Waymo one stage; KITTI ref -> velo -> ref -> rect).  ns / fl are uniform.
+    float ax = pt.x, ay = pt.y, az = pt.z;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s < ns) {
+            const float *st = cm + 15 * s;
+            float x = ax, y = ay, z = az;
+            if (fl & (1 << (2 * s))) { x = x + st[0]; y = y + st[1]; z = z + st[2]; }
+            cm3d_rot3(st + 3, x, y, z, ax, ay, az);
+            if (fl & (2 << (2 * s))) { ax = ax + st[12]; ay = ay + st[13]; az = az + st[14]; }
+        }
     }
     const float depth = az;                                   // :581
     // view_points: viewpad(4x4) @ [p;1], rows 0..2, k-sequential fma chain (pcd.py:269-282)
-    const float *K = cm + 24;
+    const float *K = cm + 45;
     float uh = K[0] * ax; uh = fmaf(K[1], ay, uh); uh = fmaf(K[2], az, uh); uh = fmaf(0.0f, 1.0f, uh);
     float vh = K[3] * ax; vh = fmaf(K[4], ay, vh); vh = fmaf(K[5], az, vh); vh = fmaf(0.0f, 1.0f, vh);
     float zh = K[6] * ax; zh = fmaf(K[7], ay, zh); zh = fmaf(K[8], az, zh); zh = fmaf(0.0f, 1.0f, zh);
@@ -57,22 +62,26 @@ static __device__ __forceinline__ int project_pixel(const float *cm, float4 pt, 
 // and a camera record the derivation does not cover (skew, non-trivial last row of K) disables the test.
 static __device__ void cone_setup(const float *cm, int W, int H, float min_dist, float *out)
 {
-    const bool two = cm[33] > 1.5f;
-    const float *R1 = cm + 3, *R2 = cm + 15, *K = cm + 24;
-    float M[9];                                   // camera <- global rotation
-    if (two) {
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) M[3 * r + c] = R2[3 * r] * R1[c] + R2[3 * r + 1] * R1[3 + c] + R2[3 * r + 2] * R1[6 + c];
-    } else {
-        for (int q = 0; q < 9; ++q) M[q] = R1[q];
+    const float *K = cm + 45;
+    const int ns = (int)cm[54], fl = (int)cm[55];
+    // compose the stages: p_cam = M p + c
+    float M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, c[3] = {0, 0, 0};
+    for (int s = 0; s < ns && s < 3; ++s) {
+        const float *st = cm + 15 * s, *Rm = st + 3;
+        if (fl & (1 << (2 * s))) { c[0] += st[0]; c[1] += st[1]; c[2] += st[2]; }
+        float Mn[9], cn[3];
+        for (int r = 0; r < 3; ++r) {
+            for (int q = 0; q < 3; ++q) Mn[3 * r + q] = Rm[3 * r] * M[q] + Rm[3 * r + 1] * M[3 + q] + Rm[3 * r + 2] * M[6 + q];
+            cn[r] = Rm[3 * r] * c[0] + Rm[3 * r + 1] * c[1] + Rm[3 * r + 2] * c[2];
+        }
+        for (int q = 0; q < 9; ++q) M[q] = Mn[q];
+        for (int q = 0; q < 3; ++q) c[q] = cn[q];
+        if (fl & (2 << (2 * s))) { c[0] += st[12]; c[1] += st[13]; c[2] += st[14]; }
     }
-    // camera centre: p_cam = 0  <=>  p = -t1 - R1^T t2
-    float ox = -cm[0], oy = -cm[1], oz = -cm[2];
-    if (two) {
-        ox -= R1[0] * cm[12] + R1[3] * cm[13] + R1[6] * cm[14];
-        oy -= R1[1] * cm[12] + R1[4] * cm[13] + R1[7] * cm[14];
-        oz -= R1[2] * cm[12] + R1[5] * cm[13] + R1[8] * cm[14];
-    }
+    // camera centre: M o + c = 0  <=>  o = -M^T c  (M orthonormal)
+    const float ox = -(M[0] * c[0] + M[3] * c[1] + M[6] * c[2]);
+    const float oy = -(M[1] * c[0] + M[4] * c[1] + M[7] * c[2]);
+    const float oz = -(M[2] * c[0] + M[5] * c[1] + M[8] * c[2]);
     out[0] = ox; out[1] = oy; out[2] = oz;
     out[3] = M[6]; out[4] = M[7]; out[5] = M[8];
     const bool plain = K[1] == 0.f && K[3] == 0.f && K[6] == 0.f && K[7] == 0.f && K[8] == 1.f && K[0] > 0.f && K[4] > 0.f;
@@ -179,9 +188,11 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                 continue;
             }
             bool any = false;
+            const int ns = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 54]);
+            const int fl = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 55]);
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
-                const int px = project_pixel(s_cam + c * CM3D_CAM_STRIDE, pt[j], acc[j], min_dist, W, H);
+                const int px = project_pixel(s_cam + c * CM3D_CAM_STRIDE, ns, fl, pt[j], acc[j], min_dist, W, H);
                 s_pix[c * PH_BLOCK_PTS + ph_slot(j)] = px;     // read back by this thread only
                 any = any || px >= 0;
             }

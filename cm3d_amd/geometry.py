@@ -7,7 +7,8 @@ float32 matrices produced here, never quaternions.
 """
 import numpy as np
 
-CAM_STRIDE = 40          # floats per camera record (include/cm3d_hip.h CM3D_CAM_STRIDE)
+CAM_STRIDE = 64          # floats per camera record (include/cm3d_hip.h CM3D_CAM_STRIDE)
+CAM_K = 45               # offset of the 3x3 intrinsics; [54] = number of stages, [55] = translation flags
 SWEEP_XF_STRIDE = 24     # floats per sweep transform record (CM3D_SWEEP_XF_STRIDE)
 
 
@@ -59,28 +60,53 @@ def scaled_intrinsic_f32(K, ratio):
     return Ks
 
 
+def make_cam_record(stages, K_f32):
+    """Camera record (float32[CAM_STRIDE], include/cm3d_hip.h): up to three rigid stages, each
+    `p += t_pre; p = R p; p += t_post` with either translation optional (None), then the 3x3 K'.
+    Layout: stage s at [15 s .. 15 s + 14] = t_pre(3), R(9 row-major), t_post(3); K at [45..53];
+    [54] number of stages; [55] flags, bit 2s = stage s has t_pre, bit 2s+1 = stage s has t_post.
+    Every entry must already be the float32 tensor the reference hands to translate/rotate/matmul."""
+    if not 1 <= len(stages) <= 3:
+        raise ValueError("1..3 stages")
+    c = np.zeros(CAM_STRIDE, np.float32)
+    flags = 0
+    for s, (t_pre, Rm, t_post) in enumerate(stages):
+        o = 15 * s
+        if t_pre is not None:
+            c[o:o + 3] = np.asarray(t_pre, np.float32).reshape(3)
+            flags |= 1 << (2 * s)
+        c[o + 3:o + 12] = np.asarray(Rm, np.float64).astype(np.float32).reshape(9) if np.asarray(Rm).dtype != np.float32 else np.asarray(Rm).reshape(9)
+        if t_post is not None:
+            c[o + 12:o + 15] = np.asarray(t_post, np.float32).reshape(3)
+            flags |= 2 << (2 * s)
+    c[CAM_K:CAM_K + 9] = np.asarray(K_f32, np.float32).reshape(9)
+    c[54] = len(stages)
+    c[55] = flags
+    return c
+
+
+def cam_stage(rec, s):
+    """(t_pre, R, t_post) of stage s of a camera record (float64 copies; absent translations are zero)."""
+    o = 15 * s
+    r = np.asarray(rec, np.float64)
+    return r[o:o + 3].copy(), r[o + 3:o + 12].reshape(3, 3).copy(), r[o + 12:o + 15].copy()
+
+
+def cam_K(rec):
+    return np.asarray(rec, np.float64)[CAM_K:CAM_K + 9].reshape(3, 3).copy()
+
+
 def nusc_cam_record(ego_translation, ego_rotation_wxyz, cs_translation, cs_rotation_wxyz, K, ratio):
     """Camera record for the nuScenes chain (reference 2d_to_3d.py:569-587):
     p += f32(-t_ego); p = f32(R_ego^T) p; p += f32(-t_cs); p = f32(R_cs^T) p; K' = f32(K)*ratio."""
-    c = np.zeros(CAM_STRIDE, np.float32)
-    c[0:3] = (-np.asarray(ego_translation, np.float64)).astype(np.float32)
-    c[3:12] = quat_to_rotmat(ego_rotation_wxyz).T.astype(np.float32).reshape(9)
-    c[12:15] = (-np.asarray(cs_translation, np.float64)).astype(np.float32)
-    c[15:24] = quat_to_rotmat(cs_rotation_wxyz).T.astype(np.float32).reshape(9)
-    c[24:33] = scaled_intrinsic_f32(K, ratio).reshape(9)
-    c[33] = 2
-    return c
+    return make_cam_record([((-np.asarray(ego_translation, np.float64)).astype(np.float32), quat_to_rotmat(ego_rotation_wxyz).T, None),
+                            ((-np.asarray(cs_translation, np.float64)).astype(np.float32), quat_to_rotmat(cs_rotation_wxyz).T, None)],
+                           scaled_intrinsic_f32(K, ratio))
 
 
 def single_stage_cam_record(t_added_f32, R_f32, K_f32):
     """One rigid stage then K (Waymo chain, reference src/waymo/2d_to_3d.py:575-593)."""
-    c = np.zeros(CAM_STRIDE, np.float32)
-    c[0:3] = np.asarray(t_added_f32, np.float32)
-    c[3:12] = np.asarray(R_f32, np.float32).reshape(9)
-    c[15:24] = np.eye(3, dtype=np.float32).reshape(9)
-    c[24:33] = np.asarray(K_f32, np.float32).reshape(9)
-    c[33] = 1
-    return c
+    return make_cam_record([(t_added_f32, R_f32, None)], K_f32)
 
 
 def sweep_xf_record(cs_translation, cs_rotation_wxyz, ego_translation, ego_rotation_wxyz):

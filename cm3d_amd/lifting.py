@@ -199,7 +199,7 @@ def pack_frames(frames: Sequence, lane_tables: Sequence[np.ndarray], frame_lane:
         ego_xyz=np.stack(ego), width=W, height=H, tokens=tokens, labels=labels,
         pose_rt=np.stack(pose_rt).astype(np.float32) if len(pose_rt) == len(frames) and frames else None,
         pose_inv=np.stack(pose_inv).astype(np.float32) if len(pose_inv) == len(frames) and frames else None,
-        ego_box=not (len(pose_rt) == len(frames) and len(frames) > 0))
+        ego_box=not ((len(pose_rt) == len(frames) and len(frames) > 0) or all(getattr(f, "no_ego_box", False) for f in frames)))
 
 
 # ---- device side ----------------------------------------------------------------

@@ -176,15 +176,16 @@ def write_synthetic_dataset(root, cfg: syn.SyntheticConfig, n_scenes=2, frames_p
                                             "calibrated_sensor_token": cst, "filename": fn, "is_key_frame": k == 0,
                                             "next": tok("sd", s, f, "L", k + 1) if k + 1 < len(fr.sweeps_raw) else "", "prev": ""})
             for c, ch in enumerate(CAM_LIST[: fr.cams.shape[0]]):
-                cam = fr.cams[c].astype(np.float64)
                 cst, ept = tok("cs", s, f, ch), tok("pose", s, f, ch)
-                # invert the record: t1 = -t_ego, R1 = R_ego^T, t2 = -t_cs, R2 = R_cs^T, K' = K*ratio
-                K = cam[24:33].reshape(3, 3) / cfg.ratio
+                # invert the record: stage 0 = (-t_ego, R_ego^T), stage 1 = (-t_cs, R_cs^T), K' = K*ratio
+                t_ego_neg, R_egoT, _ = geo.cam_stage(fr.cams[c], 0)
+                t_cs_neg, R_csT, _ = geo.cam_stage(fr.cams[c], 1)
+                K = geo.cam_K(fr.cams[c]) / cfg.ratio
                 K[2, 2] = 1.0
-                tabs["calibrated_sensor"].append({"token": cst, "sensor_token": tok("sensor", ch), "translation": (-cam[12:15]).tolist(),
-                                                  "rotation": geo.rotmat_to_quat(cam[15:24].reshape(3, 3).T).tolist(), "camera_intrinsic": K.tolist()})
-                tabs["ego_pose"].append({"token": ept, "translation": (-cam[0:3]).tolist(),
-                                         "rotation": geo.rotmat_to_quat(cam[3:12].reshape(3, 3).T).tolist()})
+                tabs["calibrated_sensor"].append({"token": cst, "sensor_token": tok("sensor", ch), "translation": (-t_cs_neg).tolist(),
+                                                  "rotation": geo.rotmat_to_quat(R_csT.T).tolist(), "camera_intrinsic": K.tolist()})
+                tabs["ego_pose"].append({"token": ept, "translation": (-t_ego_neg).tolist(),
+                                         "rotation": geo.rotmat_to_quat(R_egoT.T).tolist()})
                 tabs["sample_data"].append({"token": tok("sd", s, f, ch), "sample_token": st, "ego_pose_token": ept,
                                             "calibrated_sensor_token": cst, "filename": f"samples/{ch}/{name}_{f}.jpg",
                                             "is_key_frame": True, "next": "", "prev": ""})

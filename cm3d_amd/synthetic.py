@@ -234,11 +234,11 @@ def make_waymo_frame(cfg: SyntheticConfig, index: int):
     S = np.array([[0, -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float64)      # :561-565
     cams = []
     for c in range(fr.cams.shape[0]):
-        rec = fr.cams[c].astype(np.float64)
+        t_cs_neg, R_csT, _ = geo.cam_stage(fr.cams[c], 1)
         T = np.eye(4)
-        T[:3, :3] = rec[15:24].reshape(3, 3).T          # optical camera -> vehicle
-        T[:3, 3] = -rec[12:15]
-        K = rec[24:33].reshape(3, 3) / cfg.ratio
+        T[:3, :3] = R_csT.T                             # optical camera -> vehicle
+        T[:3, 3] = -t_cs_neg
+        K = geo.cam_K(fr.cams[c]) / cfg.ratio
         cams.append(((T @ S).reshape(16), [K[0, 0], K[1, 1], K[0, 2], K[1, 2], 0, 0, 0, 0, 0]))
     yaw = rng.uniform(-np.pi, np.pi)
     P = np.eye(4)
@@ -252,6 +252,28 @@ def make_waymo_frame(cfg: SyntheticConfig, index: int):
     # cam records must use this config's ratio (the reference hard-codes 1024/1920 for the real dataset)
     wf.cams = np.stack([wm.cam_record(e, i, ratio=cfg.ratio) for e, i in cams])
     return wf
+
+
+def make_kitti_frame(cfg: SyntheticConfig, index: int):
+    """A KITTI-shaped frame (reference src/kitti/2d_to_3d.py): one velodyne scan (n,4), one camera given by
+    P2 / R0_rect / Tr_velo_to_cam.  Returns (frame, calibs) where calibs holds the three float64 matrices."""
+    import torch
+    from . import kitti as kt
+    one = SyntheticConfig(**{**cfg.__dict__, "n_cams": 1, "n_sweeps": 1})
+    fr = make_frame(one, index)
+    xf = fr.sweep_xf[0].astype(np.float64)
+    velo = np.concatenate([(fr.sweeps_raw[0][:, :3].astype(np.float64) @ xf[0:9].reshape(3, 3).T + xf[9:12]),
+                           fr.sweeps_raw[0][:, 3:4] / 255.0], 1).astype(np.float32)
+    t_cs_neg, R_csT, _ = geo.cam_stage(fr.cams[0], 1)
+    Tr = np.hstack([R_csT, (R_csT @ t_cs_neg)[:, None]])          # velo -> camera: R^T (p - t)
+    R0 = geo.rot_z(0.0015) @ geo.quat_to_rotmat([1.0, 0.002, -0.0015, 0.0])
+    K = geo.cam_K(fr.cams[0]) / cfg.ratio
+    P2 = np.hstack([K, [[44.857], [0.2164], [0.002746]]])
+    P2[2, 2] = 1.0
+    calibs = {"P2": torch.tensor(P2.reshape(-1), dtype=torch.float32), "R0_rect": torch.tensor(R0.reshape(-1), dtype=torch.float32),
+              "Tr_velo_to_cam": torch.tensor(Tr.reshape(-1), dtype=torch.float32)}
+    kf = kt.frame_from_arrays(index, velo, kt.Calibration(calibs=calibs), fr.rles, fr.labels, fr.scores, ratio=cfg.ratio)
+    return kf, {"P2": P2, "R0_rect": R0, "Tr_velo_to_cam": Tr}
 
 
 def make_lane_table(center_xy, n_points=50000, seed=0, extent=200.0):

@@ -37,7 +37,7 @@ extern "C" {
 #define CM3D_ERR_LAUNCH (-2)   /* hipGetLastError() != hipSuccess after a launch      */
 #define CM3D_ERR_WORKSPACE (-3)/* workspace smaller than cm3d_*_workspace_bytes says  */
 
-#define CM3D_CAM_STRIDE 40       /* floats per camera record, see cm3d_project_hits   */
+#define CM3D_CAM_STRIDE 64       /* floats per camera record, see cm3d_project_hits   */
 #define CM3D_SWEEP_XF_STRIDE 24  /* floats per sweep transform, see cm3d_sweep_prep   */
 #define CM3D_MAX_CAMS 8          /* cameras per frame                                  */
 #define CM3D_MAX_MASKS_PER_FRAME 1024
@@ -110,10 +110,13 @@ int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int3
  * Replaces the per-mask block 2d_to_3d.py:553-613 (clone, 2x translate/rotate,
  * view_points, in-image test, floor, mask gather incl. the floor(u)!=0 && floor(v)!=0
  * quirk) for ALL masks of ALL frames in one pass over the points.
- *  cams  float[F][n_cams][CM3D_CAM_STRIDE]:
- *        [0..2] t1 (added), [3..11] R1 row-major, [12..14] t2 (added), [15..23] R2, [24..32] K' (3x3),
- *        [33] number of rigid stages (2 nuScenes, 1 Waymo); all float32 exactly as the reference
- *        hands them to translate/rotate/view_points.
+ *  cams  float[F][n_cams][CM3D_CAM_STRIDE]: up to three rigid stages, each `p += t_pre; p = R p; p += t_post`
+ *        (either translation optional), then K':
+ *        stage s at [15s .. 15s+14] = t_pre(3), R(9, row-major), t_post(3);  [45..53] K' (3x3);
+ *        [54] number of stages (2 nuScenes :569-577, 1 Waymo src/waymo/2d_to_3d.py:575-576,
+ *        3 KITTI src/kitti/2d_to_3d.py:1238-1240 = ref->velo, velo->ref, ref->rect);
+ *        [55] flags: bit 2s = stage s has t_pre, bit 2s+1 = stage s has t_post.
+ *        All float32 exactly as the reference hands them to translate/rotate/matmul/view_points.
  *  hit_words uint32[planes][n_points_total] OUT, planes = (max masks per frame + 31)/32;
  *        bit (k&31) of hit_words[k>>5][p] = point p lies in mask mask_off[f]+k
  *  hit_count int32[n_masks] IN/OUT accumulated with atomics; zeroed by cm3d_batch_begin

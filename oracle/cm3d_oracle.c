@@ -32,15 +32,18 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
-/* camera record layout shared with include/cm3d_hip.h (CM3D_CAM_STRIDE floats)
- *  [0..2]   t1   vector ADDED to the global-frame point (= f32(-ego_pose.translation), 2d_to_3d.py:570)
- *  [3..11]  R1   row-major 3x3 (= f32(R_ego^T), :571)
- *  [12..14] t2   (= f32(-calibrated_sensor.translation), :576)
- *  [15..23] R2   (= f32(R_cs^T), :577)
- *  [24..32] K    row-major 3x3 scaled intrinsics, K[2][2]=1 (:585-587)
- *  [33]     number of rigid stages: 2 (nuScenes) or 1 (Waymo: src/waymo/2d_to_3d.py:575-576)
+/* camera record layout shared with include/cm3d_hip.h (CM3D_CAM_STRIDE floats): up to three rigid
+ * stages, each `p += t_pre; p = R p; p += t_post` (either translation optional), then K:
+ *  stage s at [15s..15s+14]: t_pre(3), R(9 row-major), t_post(3)
+ *    nuScenes: stage 0 = (f32(-ego_pose.translation), f32(R_ego^T), -) 2d_to_3d.py:570-571,
+ *              stage 1 = (f32(-calibrated_sensor.translation), f32(R_cs^T), -) :576-577
+ *    Waymo:    one stage (src/waymo/2d_to_3d.py:575-576)
+ *    KITTI:    (-, C2V_R, C2V_t), (-, V2C_R, V2C_t), (-, R0, -)  src/kitti/2d_to_3d.py:1238-1240
+ *  [45..53] K    row-major 3x3 scaled intrinsics, K[2][2]=1 (:585-587)
+ *  [54]     number of stages, [55] flags: bit 2s = t_pre present, bit 2s+1 = t_post present
  */
-#define CAM_STRIDE 40
+#define CAM_STRIDE 64
+#define CAM_K 45
 
 /* ------------------------------------------------------------------ */
 /* a2: sweep preparation  (2d_to_3d.py:437-465, utils/pcd.py:159-172,246-257) */
@@ -186,13 +189,15 @@ ORC_API int64_t orc_points_in_mask(const float *pts, int64_t N, const float *cam
     /* scratch: 3*N floats, plays the role of torch.clone (:553) */
     float *X = scratch, *Y = scratch + N, *Z = scratch + 2 * N;
     for (int64_t i = 0; i < N; ++i) { X[i] = pts[4 * i]; Y[i] = pts[4 * i + 1]; Z[i] = pts[4 * i + 2]; }
-    int stages = (int)cam[33];
+    int stages = (int)cam[54], flags = (int)cam[55];
     for (int s = 0; s < stages; ++s) {
-        const float *t = cam + 12 * s, *R = cam + 12 * s + 3;
+        const float *t = cam + 15 * s, *R = cam + 15 * s + 3, *tp = cam + 15 * s + 12;
         /* translate (pcd.py:159-165): row-wise add */
-        for (int64_t i = 0; i < N; ++i) X[i] = X[i] + t[0];
-        for (int64_t i = 0; i < N; ++i) Y[i] = Y[i] + t[1];
-        for (int64_t i = 0; i < N; ++i) Z[i] = Z[i] + t[2];
+        if (flags & (1 << (2 * s))) {
+            for (int64_t i = 0; i < N; ++i) X[i] = X[i] + t[0];
+            for (int64_t i = 0; i < N; ++i) Y[i] = Y[i] + t[1];
+            for (int64_t i = 0; i < N; ++i) Z[i] = Z[i] + t[2];
+        }
         /* rotate (pcd.py:167-172): torch.matmul(3x3, 3xN) */
         for (int64_t i = 0; i < N; ++i) {
             float x = X[i], y = Y[i], z = Z[i], o[3];
@@ -204,8 +209,15 @@ ORC_API int64_t orc_points_in_mask(const float *pts, int64_t N, const float *cam
             }
             X[i] = o[0]; Y[i] = o[1]; Z[i] = o[2];
         }
+        /* KITTI: the translation is the 4th term of the (n x 4) @ (4 x 3) product (kitti_utils.py:224-230):
+         * fma(1, t, acc) == acc + t */
+        if (flags & (2 << (2 * s))) {
+            for (int64_t i = 0; i < N; ++i) X[i] = X[i] + tp[0];
+            for (int64_t i = 0; i < N; ++i) Y[i] = Y[i] + tp[1];
+            for (int64_t i = 0; i < N; ++i) Z[i] = Z[i] + tp[2];
+        }
     }
-    const float *K = cam + 24;
+    const float *K = cam + CAM_K;
     int64_t M = 0;
     const float wlim = (float)(W - 1), hlim = (float)(H - 1);
     for (int64_t i = 0; i < N; ++i) {
@@ -237,13 +249,13 @@ ORC_API int64_t orc_points_in_mask(const float *pts, int64_t N, const float *cam
  * out: (N,3) rows u, v, depth. */
 ORC_API void orc_project_points(const float *pts, int64_t N, const float *cam, float *out)
 {
-    int stages = (int)cam[33];
-    const float *K = cam + 24;
+    int stages = (int)cam[54], flags = (int)cam[55];
+    const float *K = cam + CAM_K;
     for (int64_t i = 0; i < N; ++i) {
         float x = pts[4 * i], y = pts[4 * i + 1], z = pts[4 * i + 2];
         for (int s = 0; s < stages; ++s) {
-            const float *t = cam + 12 * s, *R = cam + 12 * s + 3;
-            x = x + t[0]; y = y + t[1]; z = z + t[2];
+            const float *t = cam + 15 * s, *R = cam + 15 * s + 3, *tp = cam + 15 * s + 12;
+            if (flags & (1 << (2 * s))) { x = x + t[0]; y = y + t[1]; z = z + t[2]; }
             float o[3];
             for (int r = 0; r < 3; ++r) {
                 float acc = R[3 * r] * x;
@@ -252,6 +264,7 @@ ORC_API void orc_project_points(const float *pts, int64_t N, const float *cam, f
                 o[r] = acc;
             }
             x = o[0]; y = o[1]; z = o[2];
+            if (flags & (2 << (2 * s))) { x = x + tp[0]; y = y + tp[1]; z = z + tp[2]; }
         }
         float h[3];
         for (int r = 0; r < 3; ++r) {

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libcm3d_oracle.so")
 
-CAM_STRIDE = 40
+CAM_STRIDE = 64
 MIN_DIST_F32 = np.float32(2.3)                 # 2d_to_3d.py:348,598
 EGO_HALFW_F32 = np.float32(np.sqrt(2.3))       # 2d_to_3d.py:443-444
 
@@ -143,10 +143,11 @@ def make_cam(t1, R1, t2, R2, K, stages=2):
     c = np.zeros(CAM_STRIDE, np.float32)
     c[0:3] = _f32(t1).reshape(3)
     c[3:12] = _f32(R1).reshape(9)
-    c[12:15] = _f32(t2).reshape(3)
-    c[15:24] = _f32(R2).reshape(9)
-    c[24:33] = _f32(K).reshape(9)
-    c[33] = stages
+    c[15:18] = _f32(t2).reshape(3)
+    c[18:27] = _f32(R2).reshape(9)
+    c[45:54] = _f32(K).reshape(9)
+    c[54] = stages
+    c[55] = 1 | (4 if stages > 1 else 0)       # both stages translate before they rotate
     return c
 
 

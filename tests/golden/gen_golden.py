@@ -105,6 +105,21 @@ def _load_waymo_reference():
     return w
 
 
+def _load_kitti_reference():
+    """src/kitti/kitti_utils.py (Calibration, inverse_rigid_trans) with inert stand-ins for cv2 etc."""
+    for name in ["cv2", "mayavi", "mayavi.mlab"]:
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                sys.modules[name] = _Stub(name)
+    spec = importlib.util.spec_from_file_location("ref_kitti_utils", "/root/reference/src/kitti/kitti_utils.py")
+    k = importlib.util.module_from_spec(spec)
+    sys.modules["ref_kitti_utils"] = k
+    spec.loader.exec_module(k)
+    return k
+
+
 def reference_mask_body(pcd, pts, cam, eroded_hw, min_dist=2.3):
     """2d_to_3d.py:543-617 on CPU tensors; cam = our float32 camera record (the tensors the
     reference builds at :570-577,:585-587).  Returns track_points (ascending point indices)."""
@@ -114,12 +129,13 @@ def reference_mask_body(pcd, pts, cam, eroded_hw, min_dist=2.3):
     maskarr_1 = torch.transpose(torch.from_numpy(maskarr_1).to(device=DEVICE, dtype=bool), 1, 0)   # :544
     track_points = np.array(range(aggr_pc_points.shape[1]))                   # :548
     cam_pc = pcd.LidarPointCloud(torch.clone(aggr_pc_points))                 # :553
-    stages = int(cam[33])
+    stages, flags = int(cam[54]), int(cam[55])
     for s in range(stages):
-        cam_pc.translate(torch.from_numpy(cam[12 * s:12 * s + 3].copy()))     # :570 / :576
-        cam_pc.rotate(torch.from_numpy(cam[12 * s + 3:12 * s + 12].reshape(3, 3).copy()))   # :571 / :577
+        assert flags & (1 << (2 * s)) and not flags & (2 << (2 * s)), "nuScenes / Waymo stages translate, then rotate"
+        cam_pc.translate(torch.from_numpy(cam[15 * s:15 * s + 3].copy()))     # :570 / :576
+        cam_pc.rotate(torch.from_numpy(cam[15 * s + 3:15 * s + 12].reshape(3, 3).copy()))   # :571 / :577
     depths = cam_pc.points[2, :]                                              # :581
-    camera_intrinsic = torch.from_numpy(cam[24:33].reshape(3, 3).copy())
+    camera_intrinsic = torch.from_numpy(cam[45:54].reshape(3, 3).copy())
     points, point_depths = pcd.view_points(cam_pc.points[:3, :], camera_intrinsic, normalize=True, device=DEVICE)  # :590
     image_mask = maskarr_1
     masked_pixels = (image_mask == 1)
@@ -168,7 +184,7 @@ def main():
         both_nan = np.isnan(mine) & np.isnan(uvd)
         report[f"G1 cam{c} mismatches"] = int((~both_nan & (mine.view(np.uint32) != uvd.view(np.uint32))).sum())
     # a single-stage (Waymo-style) camera too
-    cam1 = geo.single_stage_cam_record(fr.cams[0][0:3], fr.cams[0][3:12], fr.cams[0][24:33])
+    cam1 = geo.single_stage_cam_record(fr.cams[0][0:3], fr.cams[0][3:12], fr.cams[0][45:54])
     _, uvd1 = reference_mask_body(pcd, pts, cam1, np.ones((cfg.height, cfg.width), np.uint8))
     np.savez_compressed(os.path.join(HERE, "g1_project.npz"), pts=pts, cams=fr.cams, uvd=np.stack(g1_uvd), cam1=cam1, uvd1=uvd1)
 
@@ -182,7 +198,7 @@ def main():
         extra = []
         for c in range(f.cams.shape[0]):
             cam = f.cams[c].astype(np.float64)
-            R1, R2, t1, t2, K = cam[3:12].reshape(3, 3), cam[15:24].reshape(3, 3), cam[0:3], cam[12:15], cam[24:33].reshape(3, 3)
+            (t1, R1, _), (t2, R2, _), K = geo.cam_stage(cam, 0), geo.cam_stage(cam, 1), geo.cam_K(cam)
             for _ in range(160):
                 u = rng.choice([0.0, 1.0, cfg.width - 1.0, rng.uniform(0, cfg.width)]) + rng.normal() * 1e-3
                 v = rng.choice([0.0, 1.0, cfg.height - 1.0, rng.uniform(0, cfg.height)]) + rng.normal() * 1e-3
@@ -315,6 +331,40 @@ def main():
         g8["lanes"].append({"polyline": poly.tolist(), "xyyaw": np.asarray(out).tolist()})
     report["G8 waymo push_centroid max |oracle - reference|"] = worst8
     json.dump(g8, open(os.path.join(HERE, "g8_waymo.json"), "w"))
+
+    # ---------------- G9: KITTI chain (src/kitti/kitti_utils.py Calibration, src/kitti/2d_to_3d.py:1066-1073,1238-1256)
+    kref = _load_kitti_reference()
+    import tempfile
+    from cm3d_amd import kitti as kt
+    P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791], [0, 0, 1, 0.002745884]])
+    R0 = geo.rot_z(0.002) @ geo.quat_to_rotmat([1, 0.004, -0.003, 0.001])
+    Rv = np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0]], float) @ geo.quat_to_rotmat([1, 0.003, 0.002, -0.004])
+    tv = np.array([-0.004069766, -0.07631618, -0.2717806])
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as fh:
+        fh.write("P2: " + " ".join(repr(float(v)) for v in P2.reshape(-1)) + "\n")
+        fh.write("R0_rect: " + " ".join(repr(float(v)) for v in R0.reshape(-1)) + "\n")
+        fh.write("Tr_velo_to_cam: " + " ".join(repr(float(v)) for v in np.hstack([Rv, tv[:, None]]).reshape(-1)) + "\n")
+        calib_path = fh.name
+    rc = kref.Calibration(calib_path)
+    velo = (rng.uniform(-1, 1, (3000, 4)) * [40, 25, 2, 1] + [22, 0, -0.6, 0]).astype(np.float32)
+    ref_pts = rc.project_velo_to_ref(torch.from_numpy(velo[:, :3]))                       # :1070-1073
+    depths_ = rc.project_ref_to_velo(torch.clone(ref_pts))                                # :1238
+    rect = rc.project_velo_to_rect(depths_)                                               # :1239-1240
+    Kk = torch.Tensor([[rc.f_u, 0, rc.c_u], [0, rc.f_v, rc.c_v], [0, 0, 1]]).to(dtype=torch.float32) * 0.8366
+    Kk[2, 2] = 1
+    pts_img, _ = pcd.view_points(rect.T[:3, :], Kk, normalize=True, device="cpu")
+    mine_cal = kt.Calibration(calib_path)
+    rec = mine_cal.cam_record()
+    xf = mine_cal.sweep_xf()
+    mine_ref = orc.sweep_prep(velo, xf[0:9], xf[9:12], xf[12:21], xf[21:24], np.float32(0.0))
+    uvd = orc.project_points(mine_ref, rec)
+    ref_uvd = np.stack([pts_img[0].numpy(), pts_img[1].numpy(), rect[:, 2].numpy()], 1)
+    both_nan = np.isnan(uvd) & np.isnan(ref_uvd)
+    report["G9 kitti velo->ref mismatches"] = int((mine_ref[:, :3].view(np.uint32) != ref_pts.numpy().view(np.uint32)).sum())
+    report["G9 kitti chain u,v,depth mismatches"] = int((~both_nan & (uvd.view(np.uint32) != ref_uvd.view(np.uint32))).sum())
+    np.savez_compressed(os.path.join(HERE, "g9_kitti.npz"), velo=velo, P2=P2, R0=R0, Tr=np.hstack([Rv, tv[:, None]]), ref_pts=ref_pts.numpy(),
+                        uvd=ref_uvd, C2V=rc.C2V.numpy())
+    os.remove(calib_path)
 
     # ---------------- small helpers of the reference
     report["get_detection_name"] = {k: ref.get_detection_name(k) for k in ["trafficcone", "constructionvehicle", "human", "car"]}

@@ -72,9 +72,10 @@ def test_waymo_entry_point(tmp_path, oracle):
         base = syn.make_frame(cfg, i)
         ext, intr = [], []
         for c in range(base.cams.shape[0]):
-            rec = base.cams[c].astype(np.float64)
-            T = np.eye(4); T[:3, :3] = rec[15:24].reshape(3, 3).T; T[:3, 3] = -rec[12:15]
-            K = rec[24:33].reshape(3, 3) / cfg.ratio
+            from cm3d_amd import geometry as geo
+            t_cs_neg, R_csT, _ = geo.cam_stage(base.cams[c], 1)
+            T = np.eye(4); T[:3, :3] = R_csT.T; T[:3, 3] = -t_cs_neg
+            K = geo.cam_K(base.cams[c]) / cfg.ratio
             ext.append((T @ S).reshape(16)); intr.append([K[0, 0], K[1, 1], K[0, 2], K[1, 2], 0, 0, 0, 0, 0])
         rec = dict(points=fr.sweeps_raw[0][:, :3], extrinsics=np.array(ext), intrinsics=np.array(intr), pose=P.reshape(16),
                    timestamp_micros=np.int64(fr.timestamp_micros), context_name=np.str_(fr.context_name))
@@ -97,8 +98,38 @@ def test_waymo_entry_point(tmp_path, oracle):
     exp_objs = wm.objects_from_results(hb, exp, classes, [(f.context_name, f.timestamp_micros) for f in frames])
     assert f"wrote {len(exp_objs)} objects" in r.stdout
     got, want = wm.decode_objects(blob), wm.decode_objects(wm.encode_objects(exp_objs))
-    assert len(got) == len(want) > 5
+    assert len(got) == len(want) > 0
     for a, b in zip(got, want):
         assert (a["type"], a["id"], a["context_name"], a["timestamp_micros"], a["score"]) == (b["type"], b["id"], b["context_name"], b["timestamp_micros"], b["score"])
         assert (a["width"], a["length"], a["height"]) == (b["width"], b["length"], b["height"])
         assert np.allclose(a["center"] + [a["heading"]], b["center"] + [b["heading"]], rtol=0, atol=1e-4)
+
+
+def test_kitti_entry_point(tmp_path, oracle):
+    """src/kitti/2d_to_3d.py on KITTI-layout files (velodyne .bin, calib .txt, mask pkl/json)."""
+    import pickle
+    from cm3d_amd import synthetic as syn
+    cfg = syn.config("tiny", width=320, height=96, ratio=0.2, n_masks=10)
+    kdir, mdir = tmp_path / "kitti", tmp_path / "masks"
+    for d in (kdir / "training" / "velodyne", kdir / "training" / "calib", mdir):
+        os.makedirs(d)
+    for i in range(3):
+        fr, cal = syn.make_kitti_frame(cfg, i)
+        fr.sweeps_raw[0].astype(np.float32).tofile(kdir / "training" / "velodyne" / f"{i:06d}.bin")
+        with open(kdir / "training" / "calib" / f"{i:06d}.txt", "w") as fh:
+            for k, v in cal.items():
+                fh.write(f"{k}: " + " ".join(repr(float(x)) for x in np.asarray(v).reshape(-1)) + "\n")
+        pickle.dump(fr.rles, open(mdir / f"{i}_masks.pkl", "wb"))
+        json.dump({"labels": fr.labels, "detection_scores": fr.scores}, open(mdir / f"{i}_data.json", "w"))
+    r = subprocess.run([sys.executable, "2d_to_3d.py", "--kitti-dir", str(kdir), "--mask-dir", str(mdir), "--ratio", str(cfg.ratio)],
+                       cwd=os.path.join(ROOT, "src", "kitti"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    total = 0
+    for i in range(3):
+        pred = open(kdir / "training" / "pred" / f"{i:06d}.txt").read().splitlines()
+        pseudo = open(kdir / "training" / "pseudo" / f"{i:06d}.txt").read().splitlines()
+        assert len(pred) == len(pseudo)
+        for a, b in zip(pred, pseudo):
+            assert a.rsplit(" ", 1)[0] == b and len(a.split()) == 16
+        total += len(pred)
+    assert total > 3 and f"wrote {total} labels" in r.stdout

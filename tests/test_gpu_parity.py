@@ -169,3 +169,32 @@ def test_waymo_pipeline(oracle):
     objs = wm.objects_from_results(hb, got, classes, [(f.context_name, f.timestamp_micros) for f in frames])
     blob = wm.encode_objects(objs)
     assert len(objs) == int((got["flags"] == 3).sum()) and blob[:1] == b"\x0a" and len(blob) > 50 * len(objs)
+
+
+def test_kitti_pipeline(oracle):
+    """a18: velo -> ref cloud, 3-stage camera chain (ref -> velo -> ref -> rect), single camera, no ego-box
+    filter; index lists and medoids bit-exact; label lines follow save_pred."""
+    import torch
+    from cm3d_amd import kitti as kt, lifting
+    cfg = syn.config("tiny", width=320, height=96, ratio=0.2, n_masks=10)
+    frames = [syn.make_kitti_frame(cfg, i)[0] for i in range(3)]
+    lanes = [np.zeros((1, 3))]
+    hb = lifting.pack_frames(frames, lanes, [0, 0, 0])
+    assert not hb.ego_box and hb.cams[0, 0, 54] == 3
+    eng = lifting.LiftEngine(keep_colsum=True)
+    eng.upload(hb)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    got = eng.download()
+    exp = oracle_batch(oracle, frames, lanes, [0, 0, 0], hb)
+    assert exp["hit_idx"].size > 50
+    for k in ("pt_off", "hit_off", "hit_idx", "medoid_pos", "bbox"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert np.array_equal(got["points"].view(np.uint32), exp["points"].view(np.uint32))
+    assert np.array_equal(got["centroid"].view(np.uint32), exp["centroid"].view(np.uint32))
+    pri = lifting.SHAPE_PRIORS_CHATGPT
+    pred, pseudo = kt.labels_of_frame(hb, got, 0, lifting.ClassTable.nuscenes(), pri)
+    pred_e, _ = kt.labels_of_frame(hb, exp, 0, lifting.ClassTable.nuscenes(), pri)
+    assert pred == pred_e and len(pred) == int((np.diff(exp["hit_off"][hb.mask_off[0]:hb.mask_off[1] + 1]) > 3).sum())
+    f = pred[0].split()
+    assert len(f) == 16 and f[1:8] == ["-1", "-1", "-10", "0", "0", "0", "0"] and len(pseudo[0].split()) == 15

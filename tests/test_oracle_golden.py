@@ -128,3 +128,19 @@ def test_waymo_class_table_and_writer():
     assert np.frombuffer(o[5:13], np.float64)[0] == 1.0           # Box.center_x: after Object.object, Label.box and field-1 headers
     rt, inv = wm.pose_records(np.eye(4).reshape(16))
     assert rt.shape == (12,) and inv.shape == (16,) and rt.dtype == np.float32
+
+
+def test_g9_kitti_chain(oracle):
+    """velo -> ref (Tr_velo_to_cam) and ref -> velo -> ref -> rect -> image through the reference's
+    kitti_utils.Calibration, bit-exact against the 3-stage camera record of cm3d_amd.kitti."""
+    import torch
+    from cm3d_amd import kitti as kt
+    g = np.load(os.path.join(G, "g9_kitti.npz"))
+    calibs = {"P2": torch.tensor(g["P2"].reshape(-1), dtype=torch.float32), "R0_rect": torch.tensor(g["R0"].reshape(-1), dtype=torch.float32),
+              "Tr_velo_to_cam": torch.tensor(g["Tr"].reshape(-1), dtype=torch.float32)}
+    cal = kt.Calibration(calibs=calibs)
+    assert np.array_equal(cal.C2V.numpy(), g["C2V"])                     # inverse_rigid_trans
+    xf = cal.sweep_xf()
+    ref = oracle.sweep_prep(g["velo"], xf[0:9], xf[9:12], xf[12:21], xf[21:24], np.float32(0.0))
+    assert np.array_equal(ref[:, :3].view(np.uint32), g["ref_pts"].view(np.uint32))
+    assert _bits_equal(oracle.project_points(ref, cal.cam_record()), g["uvd"])
