@@ -132,12 +132,12 @@ def main():
         stages = list(eng.STAGES)
         ev = {s: [] for s in stages}
         st = torch.cuda.current_stream(dev).cuda_stream
-        def lanes(s):
+        def lanes_after_grid(s):
             eng.wait_lane_grid()        # the lane-grid build runs on the engine's side stream since stage_begin
             eng.stage_lanes(s)
 
         calls = {"sweeps": eng.stage_sweeps, "masks": lambda s: eng.stage_masks(s, mode), "project": eng.stage_project,
-                 "compact": eng.stage_compact, "medoid": eng.stage_medoid, "lanes": lanes, "boxes": eng.stage_boxes}
+                 "compact": eng.stage_compact, "medoid": eng.stage_medoid, "lanes": lanes_after_grid, "boxes": eng.stage_boxes}
         for _ in range(args.warmup):
             eng.run(masks=mode)
         if world > 1 and mode == modes[0]:

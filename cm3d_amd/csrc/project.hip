@@ -23,8 +23,12 @@ static __device__ __forceinline__ int ph_slot(int j) { return (int)(threadIdx.x 
 // One pinhole projection through the reference's float32 op chain, branch-free (the kernel is
 // instruction-issue bound and divergent control flow costs scalar instructions).  Returns the pixel
 // code (iv << 16 | iu) or -1.  cm = camera record in LDS.
-static __device__ __forceinline__ int project_pixel(const float *cm, int ns, int fl, float4 pt, bool pre_ok, float min_dist, int W, int H)
+// NS / FL >= 0: compile-time stage count and translation flags (the three dataset layouts get their own
+// straight-line code); NS < 0: read both from the record.
+template <int NS, int FL>
+static __device__ __forceinline__ int project_pixel(const float *cm, int ns_rt, int fl_rt, float4 pt, bool pre_ok, float min_dist, int W, int H)
 {
+    const int ns = NS >= 0 ? NS : ns_rt, fl = NS >= 0 ? FL : fl_rt;
     // up to three rigid stages `p += t_pre; p = R p; p += t_post` (nuScenes: global -> ego(cam time) ->
     // camera, 2d_to_3d.py:569-577; Waymo one stage; KITTI ref -> velo -> ref -> rect).  ns / fl are uniform.
     float ax = pt.x, ay = pt.y, az = pt.z;
@@ -190,11 +194,25 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             bool any = false;
             const int ns = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 54]);
             const int fl = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 55]);
+            const float *cm = s_cam + c * CM3D_CAM_STRIDE;
+            int px[PH_PT];
+            if (ns == 2 && fl == 5) {                  // nuScenes: two stages, translate then rotate
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j) px[j] = project_pixel<2, 5>(cm, ns, fl, pt[j], acc[j], min_dist, W, H);
+            } else if (ns == 1 && fl == 1) {           // Waymo
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j) px[j] = project_pixel<1, 1>(cm, ns, fl, pt[j], acc[j], min_dist, W, H);
+            } else if (ns == 3 && fl == 10) {          // KITTI: rotate then translate twice, then R0
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j) px[j] = project_pixel<3, 10>(cm, ns, fl, pt[j], acc[j], min_dist, W, H);
+            } else {
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j) px[j] = project_pixel<-1, 0>(cm, ns, fl, pt[j], acc[j], min_dist, W, H);
+            }
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
-                const int px = project_pixel(s_cam + c * CM3D_CAM_STRIDE, ns, fl, pt[j], acc[j], min_dist, W, H);
-                s_pix[c * PH_BLOCK_PTS + ph_slot(j)] = px;     // read back by this thread only
-                any = any || px >= 0;
+                s_pix[c * PH_BLOCK_PTS + ph_slot(j)] = px[j];     // read back by this thread only
+                any = any || px[j] >= 0;
             }
             if (__ballot(any)) cam_any |= 1u << c;
         }

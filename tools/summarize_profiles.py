@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""gpurun_out/<tag>/ (written by tools/collect_profiles.sh) -> profiles/<tag>_*  and profiles/traffic.json.
+
+HBM traffic per launch follows MI355X_MICROARCH.md 'HBM': separate --pmc passes for FETCH_SIZE and
+WRITE_SIZE (KiB); on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced (16 B/lane)
+streaming read, so kernels whose reads are such streams are doubled (listed in STREAM_READERS);
+WRITE_SIZE is taken as is."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+STREAM_READERS = {"k_project_hits", "k_erode_pack"}        # float4 / uint4 coalesced point and mask streams
+
+
+def main(tag):
+    src = os.path.join("gpurun_out", tag)
+    os.makedirs("profiles", exist_ok=True)
+    shutil.copy(os.path.join(src, "kt", "k_kernel_stats.csv"), f"profiles/{tag}_c2_rle_kernel_stats.csv")
+    shutil.copy(os.path.join(src, "bench_profiled.json"), f"profiles/{tag}_c2_rle_bench_profiled.json")
+    shutil.copy(os.path.join(src, "bench_default.json"), f"profiles/{tag}_bench_default.json")
+    tr = collections.defaultdict(dict)
+    for d, c in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv"))):
+            if r["Counter_Name"] == c:
+                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            if k.startswith("k_"):
+                tr[k][c + "_KiB_per_launch"] = sum(v) / len(v)
+    out = {}
+    for k, v in sorted(tr.items()):
+        f, w = v.get("FETCH_SIZE_KiB_per_launch", 0.0), v.get("WRITE_SIZE_KiB_per_launch", 0.0)
+        corr = 2.0 if k in STREAM_READERS else 1.0
+        v["fetch_correction"] = corr
+        v["hbm_bytes_per_launch"] = int((f * corr + w) * 1024)
+        out[k] = v
+    json.dump(out, open(f"profiles/{tag}_c2_rle_pmc_traffic.json", "w"), indent=1)
+    traffic = {"c2_rle": {k: v["hbm_bytes_per_launch"] for k, v in out.items()}, "source": f"profiles/{tag}_c2_rle_pmc_traffic.json"}
+    json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
+    rows = list(csv.DictReader(open(f"profiles/{tag}_c2_rle_kernel_stats.csv")))
+    print(f"{'kernel':42s} {'calls':>5s} {'avg_us':>9s} {'%':>6s} {'HBM MB/launch':>14s}")
+    for r in rows[:24]:
+        name = r["Name"].split("(")[0]
+        mb = out.get(name, {}).get("hbm_bytes_per_launch")
+        print(f"{name[:42]:42s} {r['Calls']:>5s} {float(r['AverageNs']) / 1e3:9.1f} {float(r['Percentage']):6.2f} {'' if mb is None else f'{mb / 1e6:14.1f}'}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
