@@ -186,7 +186,7 @@ def main():
         stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) for s in stages}
         status = eng.check_status()
         results[mode] = dict(dt=dt, stage_ms=stage_ms, sum_hits=int(status[2]), n_points=int(status[1]),
-                             n_boxes=int((eng.b.flags == 3).sum().item()),
+                             n_boxes=int((eng.b.flags == 3).sum().item()), max_hits=int(eng.b.hit_count.max().item()),
                              n_gathered=None if gathered is None else int(sum(g.shape[0] for g in gathered)))
 
     if rank != 0:
@@ -233,7 +233,7 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
         "frame_alg_bytes": int(alg["frame_total"] // hb.n_frames),
-        "boxes_per_step": r["n_boxes"], "in_mask_points_per_step": r["sum_hits"],
+        "boxes_per_step": r["n_boxes"], "in_mask_points_per_step": r["sum_hits"], "max_points_in_a_mask": r["max_hits"],
         "gen_seconds": round(t_gen, 1),
     }
     for mode in modes[1:]:

@@ -35,8 +35,11 @@ static __device__ __forceinline__ void erode_tile_store(const uint32_t *s_rows, 
     const uint32_t tail_mask = (W & 31) ? ((1u << (W & 31)) - 1u) : 0xFFFFFFFFu;
     int minx = 0x7FFFFFFF, miny = 0x7FFFFFFF, maxx = -1, maxy = -1;
     const int nwords = rows * wc;
-    for (int q = threadIdx.x; q < nwords; q += EP_THREADS) {
-        const int r = q / wc, c = q - r * wc;        // output row ya + 1 + r, word xw0 + c
+    // (r, c) = (q / wc, q % wc) kept incrementally: one division per thread, none in the loop
+    int r = (int)threadIdx.x / wc, c = (int)threadIdx.x - r * wc;
+    const int dr_step = EP_THREADS / wc, dc_step = EP_THREADS - dr_step * wc;
+    for (int q = threadIdx.x; q < nwords; q += EP_THREADS, r += dr_step, c += dc_step) {
+        if (c >= wc) { c -= wc; ++r; }               // output row ya + 1 + r, word xw0 + c
         uint32_t e = 0xFFFFFFFFu;
 #pragma unroll
         for (int dr = 0; dr < 3; ++dr) {
@@ -287,13 +290,17 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
     const int ya = y0 - 1;                                      // image row of LDS row 0
     // initial tile: ones outside the image, zeros inside; pad bits of a row's last word are ones
     const uint32_t pad = (W & 31) ? ~((1u << (W & 31)) - 1u) : 0u;
-    for (int q = threadIdx.x; q < lrows * lw; q += EP_THREADS) {
-        const int r = q / lw, c = q - r * lw;
+    {
+    int r = (int)threadIdx.x / lw, c = (int)threadIdx.x - r * lw;
+    const int dr_step = EP_THREADS / lw, dc_step = EP_THREADS - dr_step * lw;
+    for (int q = threadIdx.x; q < lrows * lw; q += EP_THREADS, r += dr_step, c += dc_step) {
+        if (c >= lw) { c -= lw; ++r; }
         const int y = ya + r, xw = xw0 - 1 + c;
         uint32_t v = 0u;
         if (y < 0 || y >= H || xw < 0 || xw >= Wp) v = 0xFFFFFFFFu;
         else if (xw == Wp - 1) v = pad;
         s_rows[q] = v;
+    }
     }
     if (threadIdx.x < 2) s_range[threadIdx.x] = 0;
     __syncthreads();

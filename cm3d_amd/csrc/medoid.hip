@@ -15,6 +15,21 @@
 #define MD_WAVES 4                       // waves per workgroup, one tile each
 #define MD_THREADS (MD_WAVES * 64)
 
+// Correctly rounded float32 square root = sqrtf(), without the denormal pre-scaling hipcc emits around
+// v_sqrt_f32: v_sqrt_f32 is within 1 ulp, the two fma residuals pick the right neighbour (0 maps to 0).
+// Valid for x == 0 or 1e-30 <= x < 1e30; md_sqrt_ok() tells whether a value is in that domain, and the
+// caller falls back to sqrtf() for the whole wave when any lane is not (never on real coordinates).
+static __device__ __forceinline__ float md_sqrt_core(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float s_lo = __int_as_float(__float_as_int(s) - 1), s_hi = __int_as_float(__float_as_int(s) + 1);
+    const float r_lo = fmaf(-s_lo, s, x), r_hi = fmaf(-s_hi, s, x);
+    s = r_lo <= 0.0f ? s_lo : s;
+    s = r_hi > 0.0f ? s_hi : s;
+    return s;
+}
+static __device__ __forceinline__ bool md_sqrt_ok(float x) { return (x < 1.0e30f) & ((x >= 1.0e-30f) | (x == 0.0f)); }
+
 struct TileBest { float s; int j; };
 struct TileDesc { int m, off, M, jt; };  // mask, start in hit_idx, list length, tile index inside the mask
 
@@ -61,39 +76,75 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
         }
         float s = 0.f;
         const bool direct = M <= 25;
+        // rows are gathered one 64-row chunk ahead: the loads of chunk k+1 fly while chunk k is summed
+        float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < M) nxt = P[hit_idx[off + lane]];
         for (int i0 = 0; i0 < M; i0 += 64) {
             __builtin_amdgcn_wave_barrier();
-            const int i = i0 + lane;
-            if (i < M) {
-                float4 r = P[hit_idx[off + i]];
+            if (i0 + lane < M) {
+                float4 r = nxt;
                 r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
+                // the expansion branch only ever needs -2x, -2y, -2z of a row (exact products)
+                if (!direct) { r.x = -2.0f * r.x; r.y = -2.0f * r.y; r.z = -2.0f * r.z; }
                 s_row[lane] = r;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (i0 + 64 + lane < M) nxt = P[hit_idx[off + i0 + 64 + lane]];
             const int cnt = min(64, M - i0);
-            if (direct) {
-                for (int ii = 0; ii < cnt; ++ii) {
-                    const float4 r = s_row[ii];
+            // 4 rows per step: the four distance chains are independent (ILP), only the final adds into s
+            // are sequential -- and they stay in ascending row order, which is what fixes the float32 sum.
+            int ii = 0;
+            for (; ii + 4 <= cnt; ii += 4) {
+                float d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 r = s_row[ii + u];
+                    if (direct) {
+                        float dd = fabsf(r.x - qx);
+                        float agg = fmaf(dd, dd, 0.0f);
+                        dd = fabsf(r.y - qy); agg = fmaf(dd, dd, agg);
+                        dd = fabsf(r.z - qz); agg = fmaf(dd, dd, agg);
+                        d[u] = agg;
+                    } else {
+                        float acc = r.x * qx;                     // (-2 x_i) * x_j
+                        acc = fmaf(r.y, qy, acc);
+                        acc = fmaf(r.z, qz, acc);
+                        acc = fmaf(r.w, 1.0f, acc);
+                        acc = fmaf(1.0f, qn, acc);
+                        // clamp_min_(0); the in-image test only lets finite points into a mask, so acc is never NaN
+                        d[u] = fmaxf(acc, 0.0f);
+                    }
+                }
+                const bool bad = !(md_sqrt_ok(d[0]) & md_sqrt_ok(d[1]) & md_sqrt_ok(d[2]) & md_sqrt_ok(d[3]));
+                if (__ballot(bad)) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) d[u] = sqrtf(d[u]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) d[u] = md_sqrt_core(d[u]);
+                }
+                s = s + d[0]; s = s + d[1]; s = s + d[2]; s = s + d[3];
+            }
+            for (; ii < cnt; ++ii) {
+                const float4 r = s_row[ii];
+                float v;
+                if (direct) {
                     float dd = fabsf(r.x - qx);
                     float agg = fmaf(dd, dd, 0.0f);
                     dd = fabsf(r.y - qy); agg = fmaf(dd, dd, agg);
                     dd = fabsf(r.z - qz); agg = fmaf(dd, dd, agg);
-                    s = s + sqrtf(agg);
-                }
-            } else {
-#pragma unroll 4
-                for (int ii = 0; ii < cnt; ++ii) {
-                    const float4 r = s_row[ii];
-                    float acc = (-2.0f * r.x) * qx;
-                    acc = fmaf(-2.0f * r.y, qy, acc);
-                    acc = fmaf(-2.0f * r.z, qz, acc);
+                    v = agg;
+                } else {
+                    float acc = r.x * qx;
+                    acc = fmaf(r.y, qy, acc);
+                    acc = fmaf(r.z, qz, acc);
                     acc = fmaf(r.w, 1.0f, acc);
                     acc = fmaf(1.0f, qn, acc);
-                    acc = acc > 0.0f ? acc : (acc != acc ? acc : 0.0f);   // clamp_min_(0)
-                    s = s + sqrtf(acc);
+                    v = fmaxf(acc, 0.0f);
                 }
+                s = s + (__ballot(!md_sqrt_ok(v)) ? sqrtf(v) : md_sqrt_core(v));
             }
         }
         if (act && colsum_opt) colsum_opt[off + j] = s;
