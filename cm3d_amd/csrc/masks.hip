@@ -281,12 +281,13 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
     int br = RLE_LDS_WORDS / lw - 2;                            // output rows per tile
     const int need = rc.y - rc.x + 1;
     if (br > need) br = need;
-    const int y0 = rc.x + (int)blockIdx.x * br;                 // first output row of this tile
-    if (y0 > rc.y) return;
-    const int rows = min(br, rc.y - y0 + 1);
-    const int lrows = rows + 2;
     const int o = rle_off[m], n = rle_off[m + 1] - o;
     const uint32_t *ends = ends_all + o;
+    // most masks fit one tile; the few that do not are walked by the mask's workgroups in a strided loop
+    for (int y0 = rc.x + (int)blockIdx.x * br; y0 <= rc.y; y0 += (int)gridDim.x * br) {
+    __syncthreads();                                            // the previous tile's readers are done
+    const int rows = min(br, rc.y - y0 + 1);
+    const int lrows = rows + 2;
     const int ya = y0 - 1;                                      // image row of LDS row 0
     // initial tile: ones outside the image, zeros inside; pad bits of a row's last word are ones
     const uint32_t pad = (W & 31) ? ~((1u << (W & 31)) - 1u) : 0u;
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
     }
     __syncthreads();
     erode_tile_store(s_rows, lw, wc, xw0, ya, rows, W, Wp, packed + (size_t)m * H * Wp, bbox + 4 * m);
+    }
 }
 
 static inline size_t rle_align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -386,7 +388,8 @@ extern "C" int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rl
     const int Wp = (W + 31) / 32;
     const int min_rows = RLE_LDS_WORDS / (Wp + 2) - 2;          // tile height of a full-width mask
     if (min_rows < 1) return CM3D_ERR_ARG;
-    const int max_bands = (H + min_rows - 1) / min_rows;
+    int max_bands = (H + min_rows - 1) / min_rows;
+    if (max_bands > 2) max_bands = 2;                           // workgroups per mask; each walks its tiles in a strided loop
     hipLaunchKernelGGL(k_rle_ends, dim3(n_masks), dim3(RE_THREADS), 0, st, rle_counts, rle_off, W, ends, mrect, bbox);
     CM3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_rle_erode_pack, dim3(max_bands, n_masks), dim3(EP_THREADS), (size_t)RLE_LDS_WORDS * 4, st, ends, rle_off, mrect,
