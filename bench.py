@@ -148,16 +148,19 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
+            # same order as LiftEngine.run()
             eng.stage_begin(st)
-            for s in stages:
-                if s == "project":      # HIP events around the roofline kernel only, on the launch stream
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    calls[s](st)
-                    b.record()
-                    ev[s].append((a, b))
-                else:
-                    calls[s](st)
+            eng.stage_sweeps(st)
+            eng.stage_masks(st, mode)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()                  # HIP events around the roofline kernel only, on its launch stream
+            eng.stage_project(st)
+            b.record()
+            ev["project"].append((a, b))
+            eng.stage_compact(st)
+            eng.stage_medoid(st)
+            lanes_after_grid(st)
+            eng.stage_boxes(st)
         gathered = None
         if mode == modes[0]:
             # the single end-of-job exchange: fixed-size box records -> rank 0 (RCCL gather)

@@ -11,6 +11,7 @@
 // staged through LDS 64 at a time and read back as wave-wide broadcasts.  VALU-bound
 // (about 20 ops per pair incl. the IEEE sqrt); nothing M x M ever touches HBM.
 #include "common.h"
+#include <stdlib.h>
 
 #define MD_WAVES 4                       // waves per workgroup, one tile each
 #define MD_THREADS (MD_WAVES * 64)
@@ -223,7 +224,9 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     hipLaunchKernelGGL(k_medoid_desc, dim3((n_masks + 255) / 256), dim3(256), 0, st, n_masks, hit_off, tile_off, idx_cap, tile_cap, desc);
     CM3D_CHECK_LAUNCH();
     int grid = (tile_cap + MD_WAVES - 1) / MD_WAVES;
-    if (grid > 4096) grid = 4096;
+    int gmax = 4096;
+    if (const char *e = getenv("CM3D_MD_GRID")) gmax = atoi(e);
+    if (grid > gmax) grid = gmax;
     hipLaunchKernelGGL(k_medoid_tiles, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
                        tile_off, hit_idx, desc, best, tile_cap, colsum_opt);
     CM3D_CHECK_LAUNCH();

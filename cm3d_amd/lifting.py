@@ -226,6 +226,8 @@ class LiftEngine:
         d = self.dev
         self.side = torch.cuda.Stream(device=d)              # lane-grid build overlaps the point/mask stages
         self.grid_done = torch.cuda.Event()
+        self.mask_stream = torch.cuda.Stream(device=d)       # mask expansion/erosion overlaps the sweep preparation
+        self.masks_done = torch.cuda.Event()
         self.prior_wlh = torch.from_numpy(self.classes.prior_wlh).to(d)
         self.is_vehicle = torch.from_numpy(self.classes.is_vehicle).to(d)
         self.nms_thr = torch.from_numpy(self.classes.nms_thr).to(d)
@@ -316,6 +318,19 @@ class LiftEngine:
 
     def wait_lane_grid(self):
         torch.cuda.current_stream(self.dev).wait_event(self.grid_done)
+
+    def stage_masks_async(self, masks="dense"):
+        """Mask expansion + erosion on the mask stream (optional).  Measured on MI355X: the two stages do run
+        concurrently, but the HBM-bound sweep kernels then lose the occupancy they need and stretch by the
+        same amount (profiles/README: k_sweep_count 37 -> 89 us), so `run` keeps the stages serial."""
+        main = torch.cuda.current_stream(self.dev)
+        self.mask_stream.wait_stream(main)       # after batch_begin and after the previous pass's readers of `packed`
+        with torch.cuda.stream(self.mask_stream):
+            self.stage_masks(self.mask_stream.cuda_stream, masks)
+            self.masks_done.record(self.mask_stream)
+
+    def wait_masks(self):
+        torch.cuda.current_stream(self.dev).wait_event(self.masks_done)
 
     def stage_sweeps(self, st):
         b = self.b
