@@ -68,19 +68,20 @@ class NuscTables:
 
 
 def load_lane_points(dataroot, location):
-    """(L,3) float64 rows x, y, yaw of all lanes + lane connectors, discretised at 0.5 m."""
+    """(L,3) float64 rows x, y, yaw of all lanes + lane connectors, discretised at 0.5 m.
+    A pre-discretised `<dataroot>/lanes/<location>.npy` wins when present; otherwise nuscenes-devkit is used."""
+    path = os.path.join(dataroot, "lanes", location + ".npy")
+    if os.path.exists(path):
+        return np.load(path).astype(np.float64).reshape(-1, 3)
     try:
         from nuscenes.map_expansion.map_api import NuScenesMap   # third-party, optional
-        nusc_map = NuScenesMap(dataroot=dataroot, map_name=location)
-        records = nusc_map.lane + nusc_map.lane_connector
-        poses = nusc_map.discretize_lanes([r["token"] for r in records], 0.5)
-        pts = [p for lane in poses.values() for p in lane]
-        return np.asarray(pts, np.float64).reshape(-1, 3)
     except ImportError:
-        path = os.path.join(dataroot, "lanes", location + ".npy")
-        if not os.path.exists(path):
-            raise FileNotFoundError(f"nuscenes-devkit is not installed and {path} does not exist")
-        return np.load(path).astype(np.float64).reshape(-1, 3)
+        raise FileNotFoundError(f"nuscenes-devkit is not installed and {path} does not exist")
+    nusc_map = NuScenesMap(dataroot=dataroot, map_name=location)
+    records = nusc_map.lane + nusc_map.lane_connector
+    poses = nusc_map.discretize_lanes([r["token"] for r in records], 0.5)
+    pts = [p for lane in poses.values() for p in lane]
+    return np.asarray(pts, np.float64).reshape(-1, 3)
 
 
 def frames_of_scene(tables: NuscTables, scene, mask_dir, n_sweeps=3, ratio=0.64, missing_ok=False):

@@ -366,6 +366,22 @@ def main():
                         uvd=ref_uvd, C2V=rc.C2V.numpy())
     os.remove(calib_path)
 
+    # ---------------- G7: end-to-end tiny scene -> final detection JSON (oracle pipeline over on-disk inputs)
+    import tempfile as _tf
+    from cm3d_amd import nusc_io
+    from tests.helpers import oracle_results
+    with _tf.TemporaryDirectory() as td:
+        tiny = syn.config("tiny")
+        dataroot, mask_dir, names = nusc_io.write_synthetic_dataset(td, tiny, n_scenes=1, frames_per_scene=2)
+        tables = nusc_io.NuscTables("v1.0-synth", dataroot)
+        scene = tables.scene_by_name(names[0])
+        frames = nusc_io.frames_of_scene(tables, scene, mask_dir, n_sweeps=3, ratio=tiny.ratio)
+        lanes7 = [nusc_io.load_lane_points(dataroot, tables.location(scene))]
+        res7 = oracle_results(orc, frames, lanes7, [0] * len(frames))
+    g7 = {"meta": {"use_camera": True, "use_lidar": False, "use_radar": False, "use_map": True, "use_external": False}, "results": res7}
+    json.dump(g7, open(os.path.join(HERE, "g7_tiny_scene.json"), "w"))
+    report["G7 boxes in the tiny scene"] = int(sum(len(v) for v in res7.values()))
+
     # ---------------- small helpers of the reference
     report["get_detection_name"] = {k: ref.get_detection_name(k) for k in ["trafficcone", "constructionvehicle", "human", "car"]}
     json.dump(report, open(os.path.join(HERE, "gen_report.json"), "w"), indent=1)

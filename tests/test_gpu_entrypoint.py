@@ -133,3 +133,27 @@ def test_kitti_entry_point(tmp_path, oracle):
             assert a.rsplit(" ", 1)[0] == b and len(a.split()) == 16
         total += len(pred)
     assert total > 3 and f"wrote {total} labels" in r.stdout
+
+
+def test_g7_tiny_scene_json(tmp_path):
+    """G7: the committed end-to-end fixture (a 1-scene, 2-frame synthetic dataset through the oracle pipeline)
+    against the entry point's output on the regenerated dataset."""
+    from cm3d_amd import nusc_io, synthetic as syn
+    cfg = syn.config("tiny")
+    dataroot, mask_dir, names = nusc_io.write_synthetic_dataset(str(tmp_path), cfg, n_scenes=1, frames_per_scene=2)
+    out_dir = tmp_path / "outputs"
+    env = dict(os.environ, CM3D_VER_NAME="v1.0-synth", CM3D_INPUT_PATH=dataroot, CM3D_INPUT_DIR=mask_dir, CM3D_OUTPUT_DIR=str(out_dir))
+    r = subprocess.run([sys.executable, "2d_to_3d.py", "--ratio", str(cfg.ratio)], cwd=os.path.join(ROOT, "src", "nuscenes"), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.load(open(out_dir / "pseudolabels_minival.json"))
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "g7_tiny_scene.json")))
+    assert got["meta"] == want["meta"] and list(got["results"]) == list(want["results"])
+    n = 0
+    for tok in want["results"]:
+        assert len(got["results"][tok]) == len(want["results"][tok])
+        for a, b in zip(got["results"][tok], want["results"][tok]):
+            assert {k: a[k] for k in a if k not in ("translation", "rotation")} == {k: b[k] for k in b if k not in ("translation", "rotation")}
+            assert np.allclose(a["translation"], b["translation"], rtol=0, atol=1e-4) and np.allclose(a["rotation"], b["rotation"], rtol=0, atol=1e-4)
+            n += 1
+    assert n > 5

@@ -144,3 +144,17 @@ def test_g9_kitti_chain(oracle):
     ref = oracle.sweep_prep(g["velo"], xf[0:9], xf[9:12], xf[12:21], xf[21:24], np.float32(0.0))
     assert np.array_equal(ref[:, :3].view(np.uint32), g["ref_pts"].view(np.uint32))
     assert _bits_equal(oracle.project_points(ref, cal.cam_record()), g["uvd"])
+
+
+def test_g7_tiny_scene_fixture_is_reproducible(oracle, tmp_path):
+    """The G7 fixture regenerates bit-for-bit from the synthetic dataset writer + the oracle (CPU only)."""
+    from cm3d_amd import nusc_io, synthetic as syn
+    from tests.helpers import oracle_results
+    cfg = syn.config("tiny")
+    dataroot, mask_dir, names = nusc_io.write_synthetic_dataset(str(tmp_path), cfg, n_scenes=1, frames_per_scene=2)
+    tables = nusc_io.NuscTables("v1.0-synth", dataroot)
+    scene = tables.scene_by_name(names[0])
+    frames = nusc_io.frames_of_scene(tables, scene, mask_dir, n_sweeps=3, ratio=cfg.ratio)
+    res = oracle_results(oracle, frames, [nusc_io.load_lane_points(dataroot, tables.location(scene))], [0] * len(frames))
+    want = json.load(open(os.path.join(G, "g7_tiny_scene.json")))
+    assert json.loads(json.dumps(res)) == want["results"]
