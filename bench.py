@@ -44,7 +44,7 @@ def algorithmic_bytes(hb, sum_hits, mode):
         "k_project_hits": 16 * n_pts + packed + 4 * n_pts,
         "k_erode_pack": M * W * H + packed,
         "k_rle_erode_pack": 4 * int(hb.rle_counts.size) + packed,
-        "k_sweep": 2 * 4 * hb.raw_stride * n_raw + 16 * n_pts,
+        "k_sweep": 4 * hb.raw_stride * n_raw + 16 * n_pts,
     }
     masks_in = M * W * H if mode == "dense" else 4 * int(hb.rle_counts.size)
     alg["frame_total"] = alg["project_gather"] + masks_in + packed + 16 * sum_hits + 64 * M
@@ -221,7 +221,7 @@ def main():
     mask_kernel = "k_erode_pack" if main_mode == "dense" else "k_rle_erode_pack"
     kernels = {
         "masks": roof(mask_kernel, "masks", r, mask_kernel, "HBM streaming"),
-        "sweeps": roof("k_sweep", "sweeps", r, "k_sweep_count+k_scan_i32+k_sweep_scatter", "HBM streaming, 4 launches"),
+        "sweeps": roof("k_sweep", "sweeps", r, "k_sweep_xform", "HBM streaming, one pass"),
         "stage_ms": {k: round(v, 4) for k, v in r["stage_ms"].items()},
     }
     out = {

@@ -24,9 +24,8 @@ _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "cm3d_abi_version": (_i32, []),
     "cm3d_error_string": (C.c_char_p, [_i32]),
-    "cm3d_batch_begin": (_i32, [_p, _p, _i32, _p]),
-    "cm3d_sweep_prep_workspace_bytes": (_i64, [_i32, _i32]),
-    "cm3d_sweep_prep": (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _f32, _p, _i32, _p, _p, _p, _i64, _p]),
+    "cm3d_batch_begin": (_i32, [_p, _p, _i32, _p, _i32, _p]),
+    "cm3d_sweep_prep": (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _f32, _p, _i32, _p, _p, _p, _p, _p]),
     "cm3d_rle_workspace_bytes": (_i64, [_i32]),
     "cm3d_rle_to_dense": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p]),
     "cm3d_erode_pack": (_i32, [_p, _i32, _i32, _i32, _p, _p, _p]),
@@ -34,7 +33,7 @@ SIGNATURES = {
     "cm3d_project_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "cm3d_project_hits": (_i32, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32,
                                  _p, _p, _p, _p, _i64, _p]),
-    "cm3d_compact_hits": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i32, _p, _p, _i64, _p]),
+    "cm3d_compact_hits": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i64, _p]),
     "cm3d_medoid_workspace_bytes": (_i64, [_i32, _i32]),
     "cm3d_medoid": (_i32, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _i64, _p]),
     "cm3d_lane_grid_bytes": (_i64, [_i32, _i32]),

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
                                                               const int32_t *__restrict__ pt_off,
                                                               const int32_t *__restrict__ mask_frame, int n_masks,
                                                               const int32_t *__restrict__ tile_off,
-                                                              const int32_t *__restrict__ hit_idx,
+                                                              const int32_t *__restrict__ hit_row,
                                                               const TileDesc *__restrict__ desc,
                                                               TileBest *__restrict__ tile_best, int tile_cap,
                                                               float *__restrict__ colsum_opt)
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
         const bool act = j < M;
         float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
         if (act) {
-            const float4 q = P[hit_idx[off + j]];
+            const float4 q = P[hit_row[off + j]];
             qx = q.x; qy = q.y; qz = q.z;
             qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
         }
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
         const bool direct = M <= 25;
         // rows are gathered one 64-row chunk ahead: the loads of chunk k+1 fly while chunk k is summed
         float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < M) nxt = P[hit_idx[off + lane]];
+        if (lane < M) nxt = P[hit_row[off + lane]];
         for (int i0 = 0; i0 < M; i0 += 64) {
             __builtin_amdgcn_wave_barrier();
             if (i0 + lane < M) {
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (i0 + 64 + lane < M) nxt = P[hit_idx[off + i0 + 64 + lane]];
+            if (i0 + 64 + lane < M) nxt = P[hit_row[off + i0 + 64 + lane]];
             const int cnt = min(64, M - i0);
             // 4 rows per step: the four distance chains are independent (ILP), only the final adds into s
             // are sequential -- and they stay in ascending row order, which is what fixes the float32 sum.
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
                                                        const int32_t *__restrict__ mask_frame, int n_masks,
                                                        const int32_t *__restrict__ hit_off,
                                                        const int32_t *__restrict__ tile_off,
-                                                       const int32_t *__restrict__ hit_idx, int idx_cap,
+                                                       const int32_t *__restrict__ hit_row, int idx_cap,
                                                        const TileBest *__restrict__ tile_best, int tile_cap,
                                                        int32_t *__restrict__ medoid_pos, float *__restrict__ centroid)
 {
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
     medoid_pos[m] = bj;
     float cx = 0.f, cy = 0.f, cz = 0.f;
     if (bj >= 0 && hit_off[m] + bj < idx_cap) {
-        const float4 p = points[pt_off[mask_frame[m]] + hit_idx[hit_off[m] + bj]];
+        const float4 p = points[pt_off[mask_frame[m]] + hit_row[hit_off[m] + bj]];
         cx = p.x; cy = p.y; cz = p.z;
     }
     centroid[3 * m + 0] = cx; centroid[3 * m + 1] = cy; centroid[3 * m + 2] = cz;
@@ -208,11 +208,11 @@ extern "C" int64_t cm3d_medoid_workspace_bytes(int32_t n_masks, int32_t idx_cap)
 }
 
 extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_frame, int32_t n_masks,
-                           const int32_t *hit_off, const int32_t *tile_off, const int32_t *hit_idx, int32_t idx_cap,
+                           const int32_t *hit_off, const int32_t *tile_off, const int32_t *hit_row, int32_t idx_cap,
                            int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
                            int64_t workspace_bytes, cm3d_stream_t stream)
 {
-    if (!points || !pt_off || !mask_frame || !hit_off || !tile_off || !hit_idx || !medoid_pos || !centroid || !workspace)
+    if (!points || !pt_off || !mask_frame || !hit_off || !tile_off || !hit_row || !medoid_pos || !centroid || !workspace)
         return CM3D_ERR_ARG;
     if (n_masks <= 0 || idx_cap <= 0) return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_medoid_workspace_bytes(n_masks, idx_cap)) return CM3D_ERR_WORKSPACE;
@@ -228,10 +228,10 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     if (const char *e = getenv("CM3D_MD_GRID")) gmax = atoi(e);
     if (grid > gmax) grid = gmax;
     hipLaunchKernelGGL(k_medoid_tiles, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
-                       tile_off, hit_idx, desc, best, tile_cap, colsum_opt);
+                       tile_off, hit_row, desc, best, tile_cap, colsum_opt);
     CM3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_medoid_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, (const float4 *)points, pt_off, mask_frame,
-                       n_masks, hit_off, tile_off, hit_idx, idx_cap, best, tile_cap, medoid_pos, centroid);
+                       n_masks, hit_off, tile_off, hit_row, idx_cap, best, tile_cap, medoid_pos, centroid);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

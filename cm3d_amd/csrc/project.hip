@@ -328,12 +328,40 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
                                                              const int32_t *__restrict__ pt_off,
                                                              const int32_t *__restrict__ mask_off, int nm_cap, int nblk_max,
                                                              const int32_t *__restrict__ blk_base,
-                                                             int32_t *__restrict__ hit_idx, int idx_cap)
+                                                             const int32_t *__restrict__ removed_cnt,
+                                                             const int32_t *__restrict__ removed_idx,
+                                                             int32_t *__restrict__ hit_idx, int32_t *__restrict__ hit_row, int idx_cap)
 {
     const int f = blockIdx.y, chunk = blockIdx.x;
     const int p0 = pt_off[f], n = pt_off[f + 1] - p0;
     const int base = chunk * PH_BLOCK_PTS;
     if (base >= n) return;
+    // rows the sweep preparation dropped (ego box): the emitted index of a point is its row index minus the
+    // number of dropped rows before it, i.e. its index in the reference's compacted cloud
+    __shared__ uint32_t s_rm[PH_BLOCK_PTS / 32];      // dropped rows of this block, one bit per row
+    __shared__ int s_rm_before;                       // dropped rows of the frame before this block
+    __shared__ int s_rm_pre[PH_BLOCK_PTS / 32];
+    const int n_rm = removed_cnt ? removed_cnt[f] : 0;
+    if (n_rm > 0) {
+        if (threadIdx.x < PH_BLOCK_PTS / 32) s_rm[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) s_rm_before = 0;
+        __syncthreads();
+        int before = 0;
+        for (int q = threadIdx.x; q < n_rm; q += PH_THREADS) {
+            const int r = removed_idx[p0 + q];
+            if (r < base) ++before;
+            else if (r < base + PH_BLOCK_PTS) atomicOr(&s_rm[(r - base) >> 5], 1u << ((r - base) & 31));
+        }
+        before = cm3d_wave_sum(before);
+        if (cm3d_lane() == 0 && before) atomicAdd(&s_rm_before, before);
+        __syncthreads();
+        if (threadIdx.x < PH_BLOCK_PTS / 32) {       // exclusive prefix over the bitmap words
+            int pre = 0;
+            for (int wq = 0; wq < (int)threadIdx.x; ++wq) pre += __popc(s_rm[wq]);
+            s_rm_pre[threadIdx.x] = pre;
+        }
+        __syncthreads();
+    }
     const int m0 = mask_off[f];
     const int nm = min(mask_off[f + 1] - m0, nm_cap);
     const int planes = (nm + 31) >> 5;
@@ -377,7 +405,16 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
                     const int basepos = __builtin_amdgcn_readlane(run, b);
                     if (mine) {
                         const int pos = basepos + cm3d_mbcnt(mk);
-                        if (pos >= 0 && pos < idx_cap) hit_idx[pos] = idx[j];
+                        if (pos >= 0 && pos < idx_cap) {
+                            int dropped = 0;
+                            if (n_rm > 0) {
+                                const int loc = idx[j] - base;
+                                dropped = s_rm_before + s_rm_pre[loc >> 5] +
+                                          __popc(s_rm[loc >> 5] & ((1u << (loc & 31)) - 1u));
+                            }
+                            hit_idx[pos] = idx[j] - dropped;
+                            hit_row[pos] = idx[j];
+                        }
                     }
                     if (lane == b) run += __popcll(mk);
                 }
@@ -386,17 +423,22 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
     }
 }
 
-__global__ void k_batch_begin(int32_t *__restrict__ status, int32_t *__restrict__ hit_count, int n_masks)
+__global__ void k_batch_begin(int32_t *__restrict__ status, int32_t *__restrict__ hit_count, int n_masks,
+                              int32_t *__restrict__ removed_cnt, int n_frames)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < CM3D_STATUS_WORDS) status[i] = 0;
     if (i < n_masks) hit_count[i] = 0;
+    if (removed_cnt && i < n_frames) removed_cnt[i] = 0;
 }
 
-extern "C" int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, cm3d_stream_t stream)
+extern "C" int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, int32_t *removed_cnt, int32_t n_frames,
+                                cm3d_stream_t stream)
 {
-    if (!status || !hit_count || n_masks <= 0) return CM3D_ERR_ARG;
-    hipLaunchKernelGGL(k_batch_begin, dim3((n_masks + 255) / 256), dim3(256), 0, (hipStream_t)stream, status, hit_count, n_masks);
+    if (!status || !hit_count || n_masks <= 0 || (removed_cnt && n_frames <= 0)) return CM3D_ERR_ARG;
+    const int n = n_masks > n_frames ? n_masks : n_frames;
+    hipLaunchKernelGGL(k_batch_begin, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, status, hit_count, n_masks, removed_cnt,
+                       removed_cnt ? n_frames : 0);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }
@@ -448,12 +490,13 @@ extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int
 
 extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, const int32_t *pt_off, int32_t n_frames,
                                  int32_t max_pts_per_frame, int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
-                                 const int32_t *hit_count, int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx,
-                                 int32_t idx_cap, int32_t *status, void *workspace, int64_t workspace_bytes,
-                                 cm3d_stream_t stream)
+                                 const int32_t *hit_count, const int32_t *removed_cnt, const int32_t *removed_idx,
+                                 int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx, int32_t *hit_row, int32_t idx_cap,
+                                 int32_t *status, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream)
 {
-    if (!hit_words || !pt_off || !mask_off || !hit_count || !hit_off || !tile_off || !hit_idx || !status || !workspace)
+    if (!hit_words || !pt_off || !mask_off || !hit_count || !hit_off || !tile_off || !hit_idx || !hit_row || !status || !workspace)
         return CM3D_ERR_ARG;
+    if ((removed_cnt == nullptr) != (removed_idx == nullptr)) return CM3D_ERR_ARG;
     if (planes <= 0 || n_frames <= 0 || max_pts_per_frame <= 0 || n_points_total <= 0 || n_masks <= 0 || idx_cap <= 0)
         return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_project_workspace_bytes(n_frames, max_pts_per_frame, planes)) return CM3D_ERR_WORKSPACE;
@@ -466,7 +509,7 @@ extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, cons
                        nblk_max, (int32_t *)workspace);
     CM3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_compact_hits, dim3(nblk_max, n_frames), dim3(PH_THREADS), 0, st, hit_words, n_points_total, pt_off, mask_off,
-                       nm_cap, nblk_max, (const int32_t *)workspace, hit_idx, idx_cap);
+                       nm_cap, nblk_max, (const int32_t *)workspace, removed_cnt, removed_idx, hit_idx, hit_row, idx_cap);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

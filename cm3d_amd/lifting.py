@@ -270,14 +270,15 @@ class LiftEngine:
         b.bbox = e(M, 4)
         b.hit_words = e(b.planes, b.pt_cap)
         b.hit_count = e(M); b.hit_off = e(M + 1); b.tile_off = e(M + 1)
-        b.hit_idx = e(b.idx_cap)
+        b.hit_idx = e(b.idx_cap); b.hit_row = e(b.idx_cap)
+        b.removed_cnt = e(F); b.removed_idx = e(b.pt_cap)
         b.medoid_pos = e(M); b.centroid = e(M, 3, dtype=torch.float32)
         b.centroid_g = e(M, 3, dtype=torch.float32) if hb.pose_rt is not None else b.centroid
         b.colsum = e(b.idx_cap, dtype=torch.float32) if self.keep_colsum else None
         b.lane_idx = e(M); b.lane_dist = e(M, dtype=torch.float64)
         b.box = e(M, _lib.BOX_STRIDE, dtype=torch.float64); b.flags = e(M)
         L = self.lib
-        ws = max(L.cm3d_sweep_prep_workspace_bytes(S, hb.max_rows_per_sweep), L.cm3d_rle_workspace_bytes(max(1, hb.rle_counts.size)),
+        ws = max(L.cm3d_rle_workspace_bytes(max(1, hb.rle_counts.size)),
                  L.cm3d_medoid_workspace_bytes(M, b.idx_cap),
                  L.cm3d_lane_nn_workspace_bytes(M))
         b.ws_bytes = int(ws)
@@ -309,7 +310,7 @@ class LiftEngine:
     def stage_begin(self, st):
         """Resets the per-pass state and starts the lane-grid build on the side stream."""
         b = self.b
-        check(self.lib.cm3d_batch_begin(_ptr(b.status), _ptr(b.hit_count), b.M, st), "cm3d_batch_begin")
+        check(self.lib.cm3d_batch_begin(_ptr(b.status), _ptr(b.hit_count), b.M, _ptr(b.removed_cnt), b.F, st), "cm3d_batch_begin")
         main = torch.cuda.current_stream(self.dev)
         self.side.wait_stream(main)          # the previous pass's lane queries have been issued before this point
         with torch.cuda.stream(self.side):
@@ -336,7 +337,7 @@ class LiftEngine:
         b = self.b
         check(self.lib.cm3d_sweep_prep(_ptr(b.raw), b.hb.raw_stride, _ptr(b.sweep_row_off), b.S, b.hb.max_rows_per_sweep,
                                        _ptr(b.sweep_xf), _ptr(b.frame_sweep_off), b.F, b.halfw, _ptr(b.points), b.pt_cap,
-                                       _ptr(b.pt_off), _ptr(b.status), _ptr(b.ws), b.ws_bytes, st), "cm3d_sweep_prep")
+                                       _ptr(b.pt_off), _ptr(b.removed_cnt), _ptr(b.removed_idx), _ptr(b.status), st), "cm3d_sweep_prep")
 
     def stage_masks(self, st, masks="dense"):
         b = self.b
@@ -361,13 +362,14 @@ class LiftEngine:
     def stage_compact(self, st):
         b = self.b
         check(self.lib.cm3d_compact_hits(_ptr(b.hit_words), b.planes, _ptr(b.pt_off), b.F, b.max_pts, b.pt_cap, _ptr(b.mask_off),
-                                         b.M, _ptr(b.hit_count), _ptr(b.hit_off), _ptr(b.tile_off), _ptr(b.hit_idx), b.idx_cap,
-                                         _ptr(b.status), _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_compact_hits")
+                                         b.M, _ptr(b.hit_count), _ptr(b.removed_cnt), _ptr(b.removed_idx), _ptr(b.hit_off),
+                                         _ptr(b.tile_off), _ptr(b.hit_idx), _ptr(b.hit_row), b.idx_cap, _ptr(b.status), _ptr(b.pg_ws),
+                                         b.pg_ws_bytes, st), "cm3d_compact_hits")
 
     def stage_medoid(self, st):
         b = self.b
         check(self.lib.cm3d_medoid(_ptr(b.points), _ptr(b.pt_off), _ptr(b.mask_frame), b.M, _ptr(b.hit_off), _ptr(b.tile_off),
-                                   _ptr(b.hit_idx), b.idx_cap, _ptr(b.medoid_pos), _ptr(b.centroid), _ptr(b.colsum),
+                                   _ptr(b.hit_row), b.idx_cap, _ptr(b.medoid_pos), _ptr(b.centroid), _ptr(b.colsum),
                                    _ptr(b.ws), b.ws_bytes, st), "cm3d_medoid")
 
     def stage_lane_grid(self, st):
@@ -422,12 +424,24 @@ class LiftEngine:
         return s
 
     def download(self):
-        """Synchronises, checks the status word and returns numpy results."""
+        """Synchronises, checks the status word and returns numpy results.  `points` / `pt_off` are returned in
+        the reference's form (the aggregated cloud without the ego-box rows, :445-465); on the device the cloud
+        keeps those rows as NaN placeholders (see cm3d_sweep_prep)."""
         b = self.b
         s = self.check_status()
-        n_pts, n_idx = int(s[1]), int(s[2])
+        n_rows, n_idx = int(s[1]), int(s[2])
+        pt_off_rows = b.pt_off.cpu().numpy()
+        pts_rows = b.points[:n_rows].cpu().numpy()
+        rm_cnt = b.removed_cnt.cpu().numpy()
+        rm_idx = b.removed_idx[:n_rows].cpu().numpy()
+        keep = np.ones(n_rows, bool)
+        for f in range(b.F):
+            if rm_cnt[f]:
+                keep[pt_off_rows[f] + rm_idx[pt_off_rows[f]:pt_off_rows[f] + rm_cnt[f]]] = False
+        kept_per_frame = np.add.reduceat(keep.astype(np.int64), pt_off_rows[:-1]) if n_rows else np.zeros(b.F, np.int64)
+        kept_per_frame = np.where(np.diff(pt_off_rows) > 0, kept_per_frame, 0)
         out = dict(
-            pt_off=b.pt_off.cpu().numpy(), points=b.points[:n_pts].cpu().numpy(),
+            pt_off=np.concatenate([[0], np.cumsum(kept_per_frame)]).astype(np.int32), points=pts_rows[keep],
             hit_off=b.hit_off.cpu().numpy(), hit_idx=b.hit_idx[:n_idx].cpu().numpy(),
             bbox=b.bbox.cpu().numpy(), medoid_pos=b.medoid_pos.cpu().numpy(), centroid=b.centroid.cpu().numpy(),
             lane_idx=b.lane_idx.cpu().numpy(), lane_dist=b.lane_dist.cpu().numpy(), centroid_global=b.centroid_g.cpu().numpy(),

@@ -107,17 +107,17 @@ def points_in_masks(points, cams, packed, bbox, cam_nums, W, H, min_dist=2.3):
     status = _e(_lib.STATUS_WORDS)
     hit_off, tile_off = _e(n + 1), _e(n + 1)
     cap = max(1024, N * 8)
-    hit_idx = _e(cap)
+    hit_idx, hit_row = _e(cap), _e(cap)
     st = _st()
     ws = _ws(L.cm3d_project_workspace_bytes(1, N, planes))
-    check(L.cm3d_batch_begin(status.data_ptr(), hit_count.data_ptr(), n, st), "cm3d_batch_begin")
+    check(L.cm3d_batch_begin(status.data_ptr(), hit_count.data_ptr(), n, 0, 0, st), "cm3d_batch_begin")
     check(L.cm3d_project_hits(pts.data_ptr(), pt_off.data_ptr(), 1, N, N, d_cams.data_ptr(), d_cams.shape[0], mask_off.data_ptr(),
                               mask_cam.data_ptr(), bbox.data_ptr(), packed.data_ptr(), n, W, H, float(np.float32(min_dist)), planes,
                               hit_words.data_ptr(), hit_count.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), st),
           "cm3d_project_hits")
     check(L.cm3d_compact_hits(hit_words.data_ptr(), planes, pt_off.data_ptr(), 1, N, N, mask_off.data_ptr(), n, hit_count.data_ptr(),
-                              hit_off.data_ptr(), tile_off.data_ptr(), hit_idx.data_ptr(), cap, status.data_ptr(), ws.data_ptr(),
-                              ws.numel(), st), "cm3d_compact_hits")
+                              0, 0, hit_off.data_ptr(), tile_off.data_ptr(), hit_idx.data_ptr(), hit_row.data_ptr(), cap,
+                              status.data_ptr(), ws.data_ptr(), ws.numel(), st), "cm3d_compact_hits")
     s = status.cpu().numpy()
     if s[0]:
         raise _lib.Cm3dError(f"status {s}")

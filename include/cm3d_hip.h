@@ -57,27 +57,32 @@ typedef void *cm3d_stream_t;
 int cm3d_abi_version(void);
 const char *cm3d_error_string(int code);
 
-/* Resets the per-pass device state: the status word and hit_count[n_masks].  First call of
- * every pass over a batch. */
-int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, cm3d_stream_t stream);
+/* Resets the per-pass device state: the status word, hit_count[n_masks] and (when not NULL)
+ * removed_cnt[n_frames].  First call of every pass over a batch. */
+int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, int32_t *removed_cnt, int32_t n_frames,
+                     cm3d_stream_t stream);
 
 /* ---- a2: sweep preparation -------------------------------------------------
- * Replaces 2d_to_3d.py:437-465 + utils/pcd.py:159-172,246-257: strip a raw sweep to
- * 4 columns, drop |x|<halfw && |y|<halfw (halfw = f32(sqrt(2.3))), sensor->ego->global
- * (rotate then translate, twice), concatenate sweeps in order.
+ * Replaces 2d_to_3d.py:437-465 + utils/pcd.py:159-172,246-257: strip a raw sweep to 4 columns,
+ * sensor->ego->global (rotate then translate, twice), sweeps of a frame back to back; one streaming pass.
+ * The ego-box rows (|x|<halfw && |y|<halfw, halfw = f32(sqrt(2.3)), :442-445) are NOT compacted away:
+ * they are written as NaN points (inert downstream) and listed per frame, and cm3d_compact_hits turns row
+ * indices into indices of the reference's compacted cloud.  So point p of frame f sits at row pt_off[f]+p
+ * of its raw rows.
  *  raw          float[rows][raw_stride]   all sweeps of the batch, back to back
  *  sweep_row_off int32[S+1]               row offsets of the sweeps into raw
  *  sweep_xf     float[S][24]              [0..8] R_cs, [9..11] t_cs, [12..20] R_ego, [21..23] t_ego (float32,
  *                                         exactly the tensors the reference passes to rotate/translate)
  *  frame_sweep_off int32[F+1]
- *  points       float[pt_cap][4]  OUT     x,y,z,intensity in the global frame, input order preserved
- *  pt_off       int32[F+1]        OUT
- *  workspace: cm3d_sweep_prep_workspace_bytes(S, max_rows_per_sweep) */
-int64_t cm3d_sweep_prep_workspace_bytes(int32_t n_sweeps, int32_t max_rows_per_sweep);
+ *  points       float[pt_cap][4]  OUT     x,y,z,intensity in the global frame at the raw row index (pt_cap >= rows)
+ *  pt_off       int32[F+1]        OUT     first row of each frame (= sweep_row_off[frame_sweep_off[f]])
+ *  removed_cnt  int32[F]          IN/OUT  number of dropped rows per frame; must be zero on entry (cm3d_batch_begin)
+ *  removed_idx  int32[pt_cap]     OUT     frame-local row indices of the dropped rows of frame f at
+ *                                         [pt_off[f], pt_off[f] + removed_cnt[f]), in no particular order */
 int cm3d_sweep_prep(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
                     int32_t max_rows_per_sweep, const float *sweep_xf, const int32_t *frame_sweep_off,
                     int32_t n_frames, float halfw, float *points, int32_t pt_cap, int32_t *pt_off,
-                    int32_t *status, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream);
+                    int32_t *removed_cnt, int32_t *removed_idx, int32_t *status, cm3d_stream_t stream);
 
 /* ---- a1: COCO-RLE expansion ------------------------------------------------
  * Replaces pycocotools.mask.decode at 2d_to_3d.py:425 (+ the transpose at :428): run
@@ -132,25 +137,30 @@ int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_fram
 
 /* ---- a7-a8: ordered compaction of the hits ----------------------------------
  * Replaces torch.where + the two .cpu() index-tracking steps at 2d_to_3d.py:606,613-617.
+ *  removed_cnt / removed_idx  from cm3d_sweep_prep (both NULL when the points were not produced by it)
  *  hit_off  int32[n_masks+1] OUT exclusive scan of hit_count
  *  tile_off int32[n_masks+1] OUT exclusive scan of ceil(hit_count/CM3D_MEDOID_TILE)
- *  hit_idx  int32[idx_cap]   OUT ascending frame-local point indices of mask m at [hit_off[m], hit_off[m+1]) */
+ *  hit_idx  int32[idx_cap]   OUT ascending point indices of mask m at [hit_off[m], hit_off[m+1]): indices into the
+ *                                frame's cloud WITHOUT the dropped rows, i.e. the reference's track_points
+ *  hit_row  int32[idx_cap]   OUT the same points as frame-local row indices into `points` (for gathers)
+ *  workspace: the buffer cm3d_project_hits filled */
 int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, const int32_t *pt_off, int32_t n_frames,
                       int32_t max_pts_per_frame, int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
-                      const int32_t *hit_count, int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx,
-                      int32_t idx_cap, int32_t *status, void *workspace, int64_t workspace_bytes,
-                      cm3d_stream_t stream);
+                      const int32_t *hit_count, const int32_t *removed_cnt, const int32_t *removed_idx,
+                      int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx, int32_t *hit_row, int32_t idx_cap,
+                      int32_t *status, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream);
 
 /* ---- a9: medoid --------------------------------------------------------------
  * Replaces get_medoid (2d_to_3d.py:116-119) + the gather at :620,645-647:
  * argmin_j sum_i cdist(P,P)[i][j] with torch.cdist's float32 arithmetic (direct form
  * for <=25 points, matmul expansion otherwise), rows summed in ascending i, first minimum.
+ *  hit_row    the row-index list of cm3d_compact_hits (gathers go through it)
  *  medoid_pos int32[n_masks]    OUT position in the mask's index list (-1 if the list is empty)
  *  centroid   float[n_masks][3] OUT global-frame xyz of the medoid point
  *  workspace: cm3d_medoid_workspace_bytes(n_masks, idx_cap) */
 int64_t cm3d_medoid_workspace_bytes(int32_t n_masks, int32_t idx_cap);
 int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_frame, int32_t n_masks,
-                const int32_t *hit_off, const int32_t *tile_off, const int32_t *hit_idx, int32_t idx_cap,
+                const int32_t *hit_off, const int32_t *tile_off, const int32_t *hit_row, int32_t idx_cap,
                 int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
                 int64_t workspace_bytes, cm3d_stream_t stream);
 

@@ -38,9 +38,8 @@ def test_argument_validation_never_launches():
     from cm3d_amd import _lib
     L = _lib.lib()
     assert L.cm3d_erode_pack(0, 1, 64, 64, 0, 0, 0) == -1                 # null pointers
-    assert L.cm3d_batch_begin(0, 0, 0, 0) == -1
+    assert L.cm3d_batch_begin(0, 0, 0, 0, 0, 0) == -1
     assert L.cm3d_rle_workspace_bytes(100) == 400 + 1600
-    assert L.cm3d_sweep_prep_workspace_bytes(3, 2048) == (2 * 3 * 2 + 2) * 4
     assert L.cm3d_medoid_workspace_bytes(10, 1000) > 0 and L.cm3d_lane_nn_workspace_bytes(10) > 0 and L.cm3d_lane_grid_bytes(1, 1000) > 0
 
 

@@ -122,6 +122,31 @@ def test_ragged_batch(oracle):
     assert (got["flags"][m0:] == 0).all() and (got["medoid_pos"][m0:] == -1).all()
 
 
+def test_heavy_ego_box_drop(oracle):
+    """A third of the rows of every sweep fall inside the ego box (:442-445), scattered over all workgroups of the
+    frame: the index lists must still be the indices of the reference's compacted cloud."""
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config("c1")
+    frames = [syn.make_frame(cfg, i) for i in range(2)]
+    rng = np.random.default_rng(5)
+    for fr in frames:
+        for sw in fr.sweeps_raw:
+            sel = rng.random(sw.shape[0]) < 0.33
+            sw[sel, 0] = rng.uniform(-1.5, 1.5, int(sel.sum())).astype(np.float32)
+            sw[sel, 1] = rng.uniform(-1.5, 1.5, int(sel.sum())).astype(np.float32)
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 2000, seed=1)]
+    hb = lifting.pack_frames(frames, lanes, [0, 0])
+    eng = lifting.LiftEngine(keep_colsum=True)
+    eng.upload(hb)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    got = eng.download()
+    exp = oracle_batch(oracle, frames, lanes, [0, 0], hb)
+    assert exp["pt_off"][-1] < 0.75 * hb.n_raw_rows and exp["hit_idx"].size > 500
+    _compare(hb, got, exp)
+
+
 def test_second_pass_is_identical(oracle):
     """Running the resident batch twice gives bit-identical outputs (no state leaks between passes,
     no order-dependent atomics on anything that is an output)."""
