@@ -48,6 +48,58 @@ __global__ __launch_bounds__(256) void k_medoid_desc(int n_masks, const int32_t 
     for (int t = t0; t < t1; ++t) desc[t] = TileDesc{m, off, M, t - t0};
 }
 
+// squared distance of one staged row to this lane's column
+template <bool DIRECT>
+static __device__ __forceinline__ float md_pair(const float4 r, float qx, float qy, float qz, float qn)
+{
+    if (DIRECT) {
+        float dd = fabsf(r.x - qx);
+        float agg = fmaf(dd, dd, 0.0f);
+        dd = fabsf(r.y - qy); agg = fmaf(dd, dd, agg);
+        dd = fabsf(r.z - qz); agg = fmaf(dd, dd, agg);
+        return agg;
+    }
+    float acc = r.x * qx;                     // (-2 x_i) * x_j
+    acc = fmaf(r.y, qy, acc);
+    acc = fmaf(r.z, qz, acc);
+    acc = fmaf(r.w, 1.0f, acc);
+    acc = fmaf(1.0f, qn, acc);
+    // clamp_min_(0); the in-image test only lets finite points into a mask, so acc is never NaN
+    return fmaxf(acc, 0.0f);
+}
+
+// adds the distances of `cnt` staged rows to s, in ascending row order.  8 rows per step: the distance chains
+// are independent (ILP, and the LDS reads of a step are issued together), only the adds into s are sequential
+// -- which is what fixes the float32 sum.
+template <bool DIRECT>
+static __device__ __forceinline__ float md_rows(const float4 *s_row, int cnt, float qx, float qy, float qz, float qn, float s)
+{
+    constexpr int U = 8;
+    int ii = 0;
+    for (; ii + U <= cnt; ii += U) {
+        float d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = md_pair<DIRECT>(s_row[ii + u], qx, qy, qz, qn);
+        // md_sqrt_core's domain, tested on the extremes (a 0 on the diagonal sends its step to sqrtf)
+        const float lo = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+        const float hi = fmaxf(fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3])), fmaxf(fmaxf(d[4], d[5]), fmaxf(d[6], d[7])));
+        if (__ballot(!(lo >= 1.0e-30f && hi < 1.0e30f))) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = sqrtf(d[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = md_sqrt_core(d[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) s = s + d[u];
+    }
+    for (; ii < cnt; ++ii) {
+        const float v = md_pair<DIRECT>(s_row[ii], qx, qy, qz, qn);
+        s = s + (__ballot(!md_sqrt_ok(v)) ? sqrtf(v) : md_sqrt_core(v));
+    }
+    return s;
+}
+
 // One wave = one tile = 64 columns of one mask; rows are staged 64 at a time through the wave's own
 // LDS slice and read back as broadcasts.  No workgroup barrier: waves of a block are independent.
 __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__restrict__ points,
@@ -65,9 +117,12 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
     const int ntiles = min(tile_off[n_masks], tile_cap);
     for (int t = blockIdx.x * MD_WAVES + wave; t < ntiles; t += gridDim.x * MD_WAVES) {
         const TileDesc d = desc[t];
-        const int off = d.off, M = d.M;
-        const float4 *P = points + pt_off[mask_frame[d.m]];
-        const int j = d.jt * 64 + lane;
+        // the descriptor is the same in every lane: keep it in scalar registers so that the loops below are
+        // uniform control flow
+        const int off = __builtin_amdgcn_readfirstlane(d.off), M = __builtin_amdgcn_readfirstlane(d.M);
+        const int jt = __builtin_amdgcn_readfirstlane(d.jt);
+        const float4 *P = points + pt_off[mask_frame[__builtin_amdgcn_readfirstlane(d.m)]];
+        const int j = jt * 64 + lane;
         const bool act = j < M;
         float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
         if (act) {
@@ -94,59 +149,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (i0 + 64 + lane < M) nxt = P[hit_row[off + i0 + 64 + lane]];
             const int cnt = min(64, M - i0);
-            // 4 rows per step: the four distance chains are independent (ILP), only the final adds into s
-            // are sequential -- and they stay in ascending row order, which is what fixes the float32 sum.
-            int ii = 0;
-            for (; ii + 4 <= cnt; ii += 4) {
-                float d[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 r = s_row[ii + u];
-                    if (direct) {
-                        float dd = fabsf(r.x - qx);
-                        float agg = fmaf(dd, dd, 0.0f);
-                        dd = fabsf(r.y - qy); agg = fmaf(dd, dd, agg);
-                        dd = fabsf(r.z - qz); agg = fmaf(dd, dd, agg);
-                        d[u] = agg;
-                    } else {
-                        float acc = r.x * qx;                     // (-2 x_i) * x_j
-                        acc = fmaf(r.y, qy, acc);
-                        acc = fmaf(r.z, qz, acc);
-                        acc = fmaf(r.w, 1.0f, acc);
-                        acc = fmaf(1.0f, qn, acc);
-                        // clamp_min_(0); the in-image test only lets finite points into a mask, so acc is never NaN
-                        d[u] = fmaxf(acc, 0.0f);
-                    }
-                }
-                const bool bad = !(md_sqrt_ok(d[0]) & md_sqrt_ok(d[1]) & md_sqrt_ok(d[2]) & md_sqrt_ok(d[3]));
-                if (__ballot(bad)) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) d[u] = sqrtf(d[u]);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) d[u] = md_sqrt_core(d[u]);
-                }
-                s = s + d[0]; s = s + d[1]; s = s + d[2]; s = s + d[3];
-            }
-            for (; ii < cnt; ++ii) {
-                const float4 r = s_row[ii];
-                float v;
-                if (direct) {
-                    float dd = fabsf(r.x - qx);
-                    float agg = fmaf(dd, dd, 0.0f);
-                    dd = fabsf(r.y - qy); agg = fmaf(dd, dd, agg);
-                    dd = fabsf(r.z - qz); agg = fmaf(dd, dd, agg);
-                    v = agg;
-                } else {
-                    float acc = r.x * qx;
-                    acc = fmaf(r.y, qy, acc);
-                    acc = fmaf(r.z, qz, acc);
-                    acc = fmaf(r.w, 1.0f, acc);
-                    acc = fmaf(1.0f, qn, acc);
-                    v = fmaxf(acc, 0.0f);
-                }
-                s = s + (__ballot(!md_sqrt_ok(v)) ? sqrtf(v) : md_sqrt_core(v));
-            }
+            s = direct ? md_rows<true>(s_row, cnt, qx, qy, qz, qn, s) : md_rows<false>(s_row, cnt, qx, qy, qz, qn, s);
         }
         if (act && colsum_opt) colsum_opt[off + j] = s;
         // first minimum over the tile's columns (torch.argmin: NaN counts as minimal, first wins)
