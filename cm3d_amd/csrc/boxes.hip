@@ -134,7 +134,6 @@ __global__ __launch_bounds__(256) void k_lane_nn_grid(const float *__restrict__ 
                                                       const int32_t *__restrict__ lane_off, const int32_t *__restrict__ frame_lane,
                                                       const LaneGrid *__restrict__ grids, const int32_t *__restrict__ cell_start,
                                                       const LanePt *__restrict__ sorted, int max_rings,
-                                                      int32_t *__restrict__ unres, int32_t *__restrict__ n_unres,
                                                       int32_t *__restrict__ lane_idx, double *__restrict__ lane_dist)
 {
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -184,9 +183,17 @@ __global__ __launch_bounds__(256) void k_lane_nn_grid(const float *__restrict__ 
             if (qi - r <= 0 && qi + r >= g.gw - 1 && qj - r <= 0 && qj + r >= g.gh - 1) { resolved = true; break; }   // whole grid seen
         }
     }
-    if (!resolved) {            // far from every lane: hand over to the exact brute-force kernel
-        if (lane == 0) unres[atomicAdd(n_unres, 1)] = k;
-        return;
+    if (!resolved) {
+        // far from every lane point (the ring search gave up): exact scan of the whole table, 64 points per step.
+        // The cell-sorted copy holds every non-NaN point with its original index; lg_consider keeps the
+        // (distance, index) order whatever the visiting order.
+        const int32_t *cs = cell_start + g.cell_base;
+        const int a = cs[0], b = cs[g.gw * g.gh];
+        for (int q = a + lane; q < b; q += 64) {
+            const LanePt p = sorted[q];
+            const double dx = cx - (double)p.x, dy = cy - (double)p.y;
+            lg_consider(dx * dx + dy * dy, p.idx, d2cut, sbest, jbest);
+        }
     }
     // lexicographic (distance, index) minimum over the lanes
 #pragma unroll
@@ -200,134 +207,6 @@ __global__ __launch_bounds__(256) void k_lane_nn_grid(const float *__restrict__ 
         lane_idx[k] = jbest;
         lane_dist[k] = sbest;
     }
-}
-
-#define LN_THREADS 256
-#define LN_SLICES 64
-#define LN_TILE 512
-
-// Reference: d = sqrt(dx*dx+dy*dy) per pair, first minimum of d (np.argmin).
-// Exact slow form: sqrt is monotone, so a candidate with d2 >= d2cut (the d2 of the current best)
-// cannot have a strictly smaller sqrt and is skipped without evaluating it.
-static __device__ __forceinline__ void ln_update(double d2, int j, double &d2cut, double &sbest, int &jbest)
-{
-    if (d2 < d2cut) {
-        const double s = sqrt(d2);
-        if (s < sbest) { sbest = s; jbest = j; d2cut = d2; }
-    }
-}
-
-// Fast form used in the inner loop: compare squared distances only (branch-free selects) and
-// remember whether a NEAR-TIE was seen, i.e. a later candidate whose d2 is smaller than the
-// running best by less than 1e-15 relative -- the only situation in which sqrt() could round both
-// to the same double and the reference would keep the earlier index.  Such a (centroid, slice)
-// is redone with the exact form.  (d2 smaller by more than 1e-15 relative => sqrt differs by
-// more than 2 ulp => strictly smaller; d2 >= best => sqrt >= best: no switch either way.)
-#define LN_NEAR (1.0 - 1e-15)
-
-// Exact brute force for the centroids the ring search gave up on (far from every lane).
-// grid (ceil(n_masks/256), LN_SLICES): thread = one unresolved centroid, block.y = one slice of its table.
-__global__ __launch_bounds__(LN_THREADS) void k_lane_nn_brute(const float *__restrict__ centroid,
-                                                               const int32_t *__restrict__ unres, const int32_t *__restrict__ n_unres,
-                                                               const int32_t *__restrict__ mask_frame, int n_masks,
-                                                               const float *__restrict__ lane, const int32_t *__restrict__ lane_off,
-                                                               const int32_t *__restrict__ frame_lane,
-                                                               double *__restrict__ part_s, int32_t *__restrict__ part_j)
-{
-    __shared__ double2 s_lane[LN_TILE];
-    __shared__ int s_tb, s_uni;
-    const int U = *n_unres;
-    if ((int)blockIdx.x * LN_THREADS >= U) return;
-    const int u = blockIdx.x * LN_THREADS + threadIdx.x;
-    const int slice = blockIdx.y;
-    const bool act = u < U;
-    const int k = act ? unres[u] : 0;
-    const int tb = act ? frame_lane[mask_frame[k]] : -1;
-    if (threadIdx.x == 0) { s_tb = -2; s_uni = 1; }
-    __syncthreads();
-    if (act) {
-        const int old = atomicCAS(&s_tb, -2, tb);
-        if (old != -2 && old != tb) s_uni = 0;
-    }
-    __syncthreads();
-    if (s_tb == -2) return;                      // no centroid in this block
-    double cx = 0.0, cy = 0.0;
-    if (act) { cx = (double)centroid[3 * k]; cy = (double)centroid[3 * k + 1]; }
-    double sbest = INFINITY;
-    int jbest = 0;
-    if (s_uni) {
-        // every centroid of the block uses the same table: stage it through LDS
-        const int tbu = s_tb;
-        const int lo = lane_off[tbu], L = lane_off[tbu + 1] - lo;
-        const int chunk = (L + LN_SLICES - 1) / LN_SLICES;
-        const int j0 = slice * chunk, j1 = min(L, j0 + chunk);
-        double d2best = INFINITY, near_thr = INFINITY;
-        bool amb = false;
-        for (int t0 = j0; t0 < j1; t0 += LN_TILE) {
-            __syncthreads();
-            for (int q = threadIdx.x; q < LN_TILE && t0 + q < j1; q += LN_THREADS) {
-                const float *lp = lane + (size_t)(lo + t0 + q) * 3;
-                s_lane[q] = make_double2((double)lp[0], (double)lp[1]);
-            }
-            __syncthreads();
-            const int cnt = min(LN_TILE, j1 - t0);
-#pragma unroll 8
-            for (int q = 0; q < cnt; ++q) {
-                const double2 lp = s_lane[q];
-                const double dx = cx - lp.x, dy = cy - lp.y;
-                const double d2 = dx * dx + dy * dy;
-                const bool better = d2 < d2best;
-                amb = amb || (better && d2 > near_thr);
-                near_thr = better ? d2 * LN_NEAR : near_thr;
-                jbest = better ? t0 + q : jbest;
-                d2best = better ? d2 : d2best;
-            }
-        }
-        sbest = sqrt(d2best);
-        if (amb && act) {           // near-tie seen: redo this slice exactly (practically never taken)
-            double d2cut = INFINITY;
-            sbest = INFINITY; jbest = 0;
-            for (int j = j0; j < j1; ++j) {
-                const float *lp = lane + (size_t)(lo + j) * 3;
-                const double dx = cx - (double)lp[0], dy = cy - (double)lp[1];
-                ln_update(dx * dx + dy * dy, j, d2cut, sbest, jbest);
-            }
-        }
-        if (j1 <= j0) { sbest = INFINITY; jbest = 0; }
-    } else if (act) {
-        const int lo = lane_off[tb], L = lane_off[tb + 1] - lo;
-        const int chunk = (L + LN_SLICES - 1) / LN_SLICES;
-        const int j0 = slice * chunk, j1 = min(L, j0 + chunk);
-        double d2cut = INFINITY;
-        for (int j = j0; j < j1; ++j) {
-            const float *lp = lane + (size_t)(lo + j) * 3;
-            const double dx = cx - (double)lp[0], dy = cy - (double)lp[1];
-            ln_update(dx * dx + dy * dy, j, d2cut, sbest, jbest);
-        }
-    }
-    if (act) {
-        part_s[(size_t)slice * n_masks + u] = sbest;
-        part_j[(size_t)slice * n_masks + u] = jbest;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_lane_nn_brute_reduce(const int32_t *__restrict__ unres, const int32_t *__restrict__ n_unres,
-                                                              int n_masks, const double *__restrict__ part_s,
-                                                              const int32_t *__restrict__ part_j, int32_t *__restrict__ lane_idx,
-                                                              double *__restrict__ lane_dist)
-{
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= *n_unres) return;
-    double sb = INFINITY; int jb = 0;
-    for (int s = 0; s < LN_SLICES; ++s) {
-        const double v = part_s[(size_t)s * n_masks + u];
-        const int j = part_j[(size_t)s * n_masks + u];
-        // slices cover ascending j ranges, so a strict < keeps the first minimum
-        if (v < sb) { sb = v; jb = j; }
-    }
-    const int k = unres[u];
-    lane_idx[k] = jb;
-    lane_dist[k] = sb;
 }
 
 static inline size_t lg_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -373,8 +252,7 @@ extern "C" int cm3d_lane_grid_build(const float *lane, const int32_t *lane_off, 
 extern "C" int64_t cm3d_lane_nn_workspace_bytes(int32_t n_masks)
 {
     if (n_masks <= 0) return 0;
-    return (int64_t)(lg_align(sizeof(int32_t) * ((size_t)n_masks + 64)) +
-                     lg_align((sizeof(double) + sizeof(int32_t)) * (size_t)n_masks * LN_SLICES));
+    return 256;                 // reserved: the search needs no scratch memory in this version
 }
 
 extern "C" int cm3d_lane_nn(const float *centroid, const int32_t *medoid_pos, const int32_t *mask_frame, int32_t n_masks,
@@ -386,23 +264,9 @@ extern "C" int cm3d_lane_nn(const float *centroid, const int32_t *medoid_pos, co
         return CM3D_ERR_ARG;
     if (n_masks <= 0 || n_tables <= 0 || n_lane_points <= 0) return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_lane_nn_workspace_bytes(n_masks)) return CM3D_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
     const LgLayout l = lg_layout(const_cast<void *>(grid), n_tables, n_lane_points);
-    char *w = (char *)workspace;
-    int32_t *n_unres = (int32_t *)w;                    // counter, then the list
-    int32_t *unres = n_unres + 64;                      w += lg_align(sizeof(int32_t) * ((size_t)n_masks + 64));
-    double *part_s = (double *)w;
-    int32_t *part_j = (int32_t *)(part_s + (size_t)n_masks * LN_SLICES);
-    if (hipMemsetAsync(n_unres, 0, sizeof(int32_t), st) != hipSuccess) return CM3D_ERR_LAUNCH;
-    hipLaunchKernelGGL(k_lane_nn_grid, dim3((n_masks + 3) / 4), dim3(256), 0, st, centroid, medoid_pos, mask_frame, n_masks, lane_off,
-                       frame_lane, l.grids, l.cell_start, l.sorted, LG_MAX_RINGS, unres, n_unres, lane_idx, lane_dist);
-    CM3D_CHECK_LAUNCH();
-    // exact brute force for whatever the ring search left unresolved (blocks beyond the count exit at once)
-    hipLaunchKernelGGL(k_lane_nn_brute, dim3((n_masks + LN_THREADS - 1) / LN_THREADS, LN_SLICES), dim3(LN_THREADS), 0, st, centroid,
-                       unres, n_unres, mask_frame, n_masks, lane, lane_off, frame_lane, part_s, part_j);
-    CM3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_lane_nn_brute_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, unres, n_unres, n_masks, part_s, part_j,
-                       lane_idx, lane_dist);
+    hipLaunchKernelGGL(k_lane_nn_grid, dim3((n_masks + 3) / 4), dim3(256), 0, (hipStream_t)stream, centroid, medoid_pos, mask_frame,
+                       n_masks, lane_off, frame_lane, l.grids, l.cell_start, l.sorted, LG_MAX_RINGS, lane_idx, lane_dist);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

@@ -175,7 +175,8 @@ int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_
  *  Exactly the brute-force result (first minimum of the float64 distance); internally the lane points are
  *  binned into a uniform grid per table (cm3d_lane_grid_build) and searched in growing rings, one wave per
  *  centroid; centroids farther than ~10 cells from every lane fall back to a brute-force kernel.
- *  grid: the buffer cm3d_lane_grid_build filled; workspace: cm3d_lane_nn_workspace_bytes(n_masks) */
+ *  grid: the buffer cm3d_lane_grid_build filled; workspace: cm3d_lane_nn_workspace_bytes(n_masks) bytes, reserved
+ *  (centroids the grid search cannot settle are scanned against their whole table by the same wave) */
 /* Spatial index of the lane tables (uniform grid per table, points in cell order): built by one
  * workgroup per table; depends only on the lane tables, so a driver may build it on a side stream. */
 int64_t cm3d_lane_grid_bytes(int32_t n_tables, int32_t n_lane_points);
