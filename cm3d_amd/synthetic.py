@@ -44,6 +44,10 @@ class SyntheticConfig:
     seed: int = 1234
     empty_mask_prob: float = 0.1   # masks dropped on sky/empty regions
     duplicate_prob: float = 0.2    # masks that re-detect an object of an earlier mask
+    point_order: str = "ring"      # row order of a sweep: "ring" = beam by beam, each a full turn (KITTI / Waymo range
+                                   # image rows); "firing" = azimuth step by azimuth step, all beams of one firing
+                                   # together (how the HDL-32E packets of a nuScenes LIDAR_TOP .pcd.bin are laid out,
+                                   # the ring index in column 4 cycling 0..31)
 
 
 @dataclass
@@ -97,6 +101,10 @@ def _lidar_sweep(rng, cfg: SyntheticConfig, objects):
     y = r * np.cos(el) * np.sin(az)
     z = r * np.sin(el)
     pts = np.stack([x, y, z, rng.uniform(0, 255, size=az.size), np.repeat(np.arange(nb), per).astype(np.float64)], 1)
+    if cfg.point_order == "firing":
+        pts = np.ascontiguousarray(pts.reshape(nb, per, 5).transpose(1, 0, 2)).reshape(nb * per, 5)
+    elif cfg.point_order != "ring":
+        raise ValueError(f"unknown point_order {cfg.point_order!r}")
     extra = n - pts.shape[0]
     if extra > 0:      # a few returns inside the ego box so that the a2 filter has work to do
         e = np.stack([rng.uniform(-1.4, 1.4, extra), rng.uniform(-1.4, 1.4, extra), rng.uniform(-1.5, 0.5, extra),
@@ -301,11 +309,11 @@ def make_lane_table(center_xy, n_points=50000, seed=0, extent=200.0):
 # named configurations of BASELINE.md section 3
 def config(name: str, **over) -> SyntheticConfig:
     base = {
-        "c1": dict(n_points=34700, n_sweeps=3, n_masks=20, n_cams=6, width=1024, height=576, ratio=0.64),
-        "c2": dict(n_points=35000, n_sweeps=1, n_masks=20, n_cams=6, width=1600, height=900, ratio=1.0),
+        "c1": dict(n_points=34700, n_sweeps=3, n_masks=20, n_cams=6, width=1024, height=576, ratio=0.64, point_order="firing"),
+        "c2": dict(n_points=35000, n_sweeps=1, n_masks=20, n_cams=6, width=1600, height=900, ratio=1.0, point_order="firing"),
         "c4": dict(n_points=180000, n_sweeps=1, n_masks=20, n_cams=5, width=1920, height=1280, ratio=1.0,
                    n_beams=64, focal=2060.0, full_width=1920, full_height=1280),
-        "c5": dict(n_points=35000, n_sweeps=10, n_masks=80, n_cams=6, width=1600, height=900, ratio=1.0),
+        "c5": dict(n_points=35000, n_sweeps=10, n_masks=80, n_cams=6, width=1600, height=900, ratio=1.0, point_order="firing"),
         "tiny": dict(n_points=3000, n_sweeps=2, n_masks=8, n_cams=6, width=256, height=144, ratio=0.16,
                      min_area=30.0, max_area=3000.0),
     }[name]
