@@ -20,42 +20,97 @@
 // the 64 lanes read 64 consecutive points (1 KiB, coalesced).  Order inside a block = (wave, j, lane).
 static __device__ __forceinline__ int ph_slot(int j) { return (int)(threadIdx.x >> 6) * (64 * PH_PT) + j * 64 + (int)(threadIdx.x & 63); }
 
-// One pinhole projection through the reference's float32 op chain, branch-free (the kernel is
-// instruction-issue bound and divergent control flow costs scalar instructions).  Returns the pixel
-// code (iv << 16 | iu) or -1.  cm = camera record in LDS.
+typedef float f2 __attribute__((ext_vector_type(2)));     // two points side by side: v_pk_{add,mul,fma}_f32
+#define PK_FMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
+
+// k-sequential fma chain of a row-major 3x3 times two vectors (cm3d_rot3 for a pair of points)
+static __device__ __forceinline__ void rot3_2(const float *R, f2 x, f2 y, f2 z, f2 &ox, f2 &oy, f2 &oz)
+{
+    f2 a = R[0] * x; a = PK_FMA((f2)(R[1]), y, a); a = PK_FMA((f2)(R[2]), z, a);
+    f2 b = R[3] * x; b = PK_FMA((f2)(R[4]), y, b); b = PK_FMA((f2)(R[5]), z, b);
+    f2 c = R[6] * x; c = PK_FMA((f2)(R[7]), y, c); c = PK_FMA((f2)(R[8]), z, c);
+    ox = a; oy = b; oz = c;
+}
+
+// Pinhole projection of TWO points through the reference's float32 op chain, branch-free and in packed
+// float32 (the kernel is instruction-issue bound).  Returns the pixel codes (iv << 16 | iu) or -1.
+// cm = camera record in LDS.
 // NS / FL >= 0: compile-time stage count and translation flags (the three dataset layouts get their own
 // straight-line code); NS < 0: read both from the record.
-template <int NS, int FL>
-static __device__ __forceinline__ int project_pixel(const float *cm, int ns_rt, int fl_rt, float4 pt, bool pre_ok, float min_dist, int W, int H)
+// FASTDIV: u = uh/zh and v = vh/zh through the same rcp + fma sequence hipcc emits for an IEEE division, but
+// without v_div_scale / v_div_fixup and with the refined reciprocal shared by both quotients.  For zh in
+// [1e-30, 1e30) the scaling steps are the identity unless the quotient is < 2^-100 or > 2^96 in magnitude
+// (rejected by the range test either way), so accepted pixels are bit-identical; `redo` is set when a
+// lane that passes the depth test has zh outside that range, and the caller repeats the camera with the
+// true division.
+template <int NS, int FL, bool FASTDIV>
+static __device__ __forceinline__ void project_pair(const float *cm, int ns_rt, int fl_rt, f2 px_, f2 py_, f2 pz_, float min_dist,
+                                                    int W, int H, int &out0, int &out1, bool &redo)
 {
     const int ns = NS >= 0 ? NS : ns_rt, fl = NS >= 0 ? FL : fl_rt;
     // up to three rigid stages `p += t_pre; p = R p; p += t_post` (nuScenes: global -> ego(cam time) ->
     // camera, 2d_to_3d.py:569-577; Waymo one stage; KITTI ref -> velo -> ref -> rect).  ns / fl are uniform.
-    float ax = pt.x, ay = pt.y, az = pt.z;
+    f2 ax = px_, ay = py_, az = pz_;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         if (s < ns) {
             const float *st = cm + 15 * s;
-            float x = ax, y = ay, z = az;
+            f2 x = ax, y = ay, z = az;
             if (fl & (1 << (2 * s))) { x = x + st[0]; y = y + st[1]; z = z + st[2]; }
-            cm3d_rot3(st + 3, x, y, z, ax, ay, az);
+            rot3_2(st + 3, x, y, z, ax, ay, az);
             if (fl & (2 << (2 * s))) { ax = ax + st[12]; ay = ay + st[13]; az = az + st[14]; }
         }
     }
-    const float depth = az;                                   // :581
-    // view_points: viewpad(4x4) @ [p;1], rows 0..2, k-sequential fma chain (pcd.py:269-282)
+    const f2 depth = az;                                      // :581
+    // view_points: viewpad(4x4) @ [p;1], rows 0..2, k-sequential fma chain (pcd.py:269-282).  The chain's last
+    // term, fma(0, 1, .), only turns -0 into +0, which cannot change an accepted pixel (|u| < 1 is rejected).
     const float *K = cm + 45;
-    float uh = K[0] * ax; uh = fmaf(K[1], ay, uh); uh = fmaf(K[2], az, uh); uh = fmaf(0.0f, 1.0f, uh);
-    float vh = K[3] * ax; vh = fmaf(K[4], ay, vh); vh = fmaf(K[5], az, vh); vh = fmaf(0.0f, 1.0f, vh);
-    float zh = K[6] * ax; zh = fmaf(K[7], ay, zh); zh = fmaf(K[8], az, zh); zh = fmaf(0.0f, 1.0f, zh);
-    const float u = uh / zh, v = vh / zh;                     // IEEE division, any operand
+    f2 uh = K[0] * ax; uh = PK_FMA((f2)(K[1]), ay, uh); uh = PK_FMA((f2)(K[2]), az, uh);
+    f2 vh = K[3] * ax; vh = PK_FMA((f2)(K[4]), ay, vh); vh = PK_FMA((f2)(K[5]), az, vh);
+    f2 zh = K[6] * ax; zh = PK_FMA((f2)(K[7]), ay, zh); zh = PK_FMA((f2)(K[8]), az, zh);
+    f2 u, v;
+    if (FASTDIV) {
+        f2 r = {__builtin_amdgcn_rcpf(zh.x), __builtin_amdgcn_rcpf(zh.y)};
+        const f2 e = PK_FMA(-zh, r, (f2)(1.0f));
+        r = PK_FMA(e, r, r);
+        f2 q = uh * r;
+        f2 t = PK_FMA(-zh, q, uh); q = PK_FMA(t, r, q);
+        t = PK_FMA(-zh, q, uh);    u = PK_FMA(t, r, q);
+        q = vh * r;
+        t = PK_FMA(-zh, q, vh);    q = PK_FMA(t, r, q);
+        t = PK_FMA(-zh, q, vh);    v = PK_FMA(t, r, q);
+    } else {
+        u = uh / zh; v = vh / zh;                             // IEEE division, any operand
+    }
     // :597-603 in-image test, :605 floor, :608-613 truthiness quirk, folded into integer range checks:
     //   u > 0 && u < W-1 && floor(u) != 0   <=>   1 <= floor(u) <= W-2      (u = W-1 gives floor W-1;
     //   NaN converts to 0 and +-inf saturates, all outside the range).  The third row of the quirk,
     //   floor(zh/zh) != 0, holds whenever u is finite and non-zero (then zh/zh == 1 exactly).
-    const int iu = (int)floorf(u), iv = (int)floorf(v);
-    const bool ok = pre_ok & (depth > min_dist) & ((unsigned)(iu - 1) <= (unsigned)(W - 3)) & ((unsigned)(iv - 1) <= (unsigned)(H - 3));
-    return ok ? ((iv << 16) | iu) : -1;
+    const int iu0 = (int)floorf(u.x), iv0 = (int)floorf(v.x), iu1 = (int)floorf(u.y), iv1 = (int)floorf(v.y);
+    const bool d0 = depth.x > min_dist, d1 = depth.y > min_dist;
+    const bool ok0 = d0 & ((unsigned)(iu0 - 1) <= (unsigned)(W - 3)) & ((unsigned)(iv0 - 1) <= (unsigned)(H - 3));
+    const bool ok1 = d1 & ((unsigned)(iu1 - 1) <= (unsigned)(W - 3)) & ((unsigned)(iv1 - 1) <= (unsigned)(H - 3));
+    out0 = ok0 ? ((iv0 << 16) | iu0) : -1;
+    out1 = ok1 ? ((iv1 << 16) | iu1) : -1;
+    if (FASTDIV) {
+        const float hi = 9.99999e29f;
+        redo = (d0 & !(zh.x >= 1.0e-30f && zh.x <= hi)) | (d1 & !(zh.y >= 1.0e-30f && zh.y <= hi));
+    } else {
+        redo = false;
+    }
+}
+
+template <int NS, int FL>
+static __device__ __forceinline__ void project_quad(const float *cm, int ns, int fl, const f2 (&X)[2], const f2 (&Y)[2],
+                                                    const f2 (&Z)[2], float min_dist, int W, int H, int (&px)[PH_PT])
+{
+    bool r0, r1;
+    project_pair<NS, FL, true>(cm, ns, fl, X[0], Y[0], Z[0], min_dist, W, H, px[0], px[1], r0);
+    project_pair<NS, FL, true>(cm, ns, fl, X[1], Y[1], Z[1], min_dist, W, H, px[2], px[3], r1);
+    if (__ballot(r0 | r1)) {          // never on real data: a depth-accepted point with |zh| outside [1e-30, 1e30)
+        project_pair<NS, FL, false>(cm, ns, fl, X[0], Y[0], Z[0], min_dist, W, H, px[0], px[1], r0);
+        project_pair<NS, FL, false>(cm, ns, fl, X[1], Y[1], Z[1], min_dist, W, H, px[2], px[3], r1);
+    }
 }
 
 // Conservative visibility cone of one camera, from its float32 record: a point can only pass the exact
@@ -140,12 +195,14 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     int *s_mcam = s_pix + (size_t)n_cams * PH_BLOCK_PTS;
     int *s_cnt = s_mcam + nm_cap;
 
-    // points of the first chunk are requested before the table staging so that both latencies overlap
+    // points of the first chunk are requested before the table staging so that both latencies overlap.
+    // Slots past the end of the frame hold NaN points: every test below rejects them by itself.
+    const float qnan = __int_as_float(0x7FC00000);
     float4 pt[PH_PT];
 #pragma unroll
     for (int j = 0; j < PH_PT; ++j) {
         const int i0 = (int)blockIdx.x * PH_BLOCK_PTS + ph_slot(j);
-        pt[j] = i0 < n ? points[p0 + i0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        pt[j] = i0 < n ? points[p0 + i0] : make_float4(qnan, qnan, qnan, 0.f);
     }
     for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS)
         s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
@@ -170,45 +227,41 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             idx[j] = base + ph_slot(j);
             in_range[j] = idx[j] < n;
         }
+        static_assert(PH_PT == 4, "points are handled as two pairs");
+        const f2 X[2] = {{pt[0].x, pt[1].x}, {pt[2].x, pt[3].x}};
+        const f2 Y[2] = {{pt[0].y, pt[1].y}, {pt[2].y, pt[3].y}};
+        const f2 Z[2] = {{pt[0].z, pt[1].z}, {pt[2].z, pt[3].z}};
         uint32_t cam_any = 0;
 #pragma unroll 1
         for (int c = 0; c < n_cams; ++c) {
             // conservative pre-test (a superset of the exact in-image test): is any of this wave's points
-            // inside the camera's visibility cone?  LiDAR points are stored ring by ring, so a wave's
-            // 4 x 64 points cover a small azimuth range and most cameras are rejected here for the whole wave.
+            // inside the camera's visibility cone?  A wave's 4 x 64 points are consecutive in the sweep, i.e. a
+            // short arc of the scan, and most cameras are rejected here for the whole wave.
+            //   inside  <=>  sdist - c6 >= 0  and  c7 * sdist^2 - r2 >= 0   (NaN compares false)
             const float *cn = s_cone[c];
-            bool acc[PH_PT], anyacc = false;
+            float inside;
+            {
+                f2 m[2];
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) {
-                const float vx = pt[j].x - cn[0], vy = pt[j].y - cn[1], vz = pt[j].z - cn[2];
-                const float sdist = fmaf(cn[5], vz, fmaf(cn[4], vy, cn[3] * vx));
-                const float r2 = fmaf(vz, vz, fmaf(vy, vy, vx * vx));
-                acc[j] = in_range[j] && sdist > cn[6] && r2 <= cn[7] * sdist * sdist;
-                anyacc = anyacc || acc[j];
+                for (int h = 0; h < 2; ++h) {
+                    const f2 vx = X[h] - cn[0], vy = Y[h] - cn[1], vz = Z[h] - cn[2];
+                    f2 sd = cn[3] * vx; sd = PK_FMA((f2)(cn[4]), vy, sd); sd = PK_FMA((f2)(cn[5]), vz, sd);
+                    f2 r2 = vx * vx; r2 = PK_FMA(vy, vy, r2); r2 = PK_FMA(vz, vz, r2);
+                    const f2 t = PK_FMA(cn[7] * sd, sd, -r2);
+                    m[h] = __builtin_elementwise_min(sd - cn[6], t);
+                }
+                inside = fmaxf(fmaxf(m[0].x, m[0].y), fmaxf(m[1].x, m[1].y));
             }
-            if (!__ballot(anyacc)) {
-#pragma unroll
-                for (int j = 0; j < PH_PT; ++j) s_pix[c * PH_BLOCK_PTS + ph_slot(j)] = -1;
-                continue;
-            }
-            bool any = false;
+            if (!__ballot(inside >= 0.0f)) continue;           // s_pix of this camera is never read (cam_any bit clear)
             const int ns = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 54]);
             const int fl = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 55]);
             const float *cm = s_cam + c * CM3D_CAM_STRIDE;
             int px[PH_PT];
-            if (ns == 2 && fl == 5) {                  // nuScenes: two stages, translate then rotate
-#pragma unroll
-                for (int j = 0; j < PH_PT; ++j) px[j] = project_pixel<2, 5>(cm, ns, fl, pt[j], acc[j], min_dist, W, H);
-            } else if (ns == 1 && fl == 1) {           // Waymo
-#pragma unroll
-                for (int j = 0; j < PH_PT; ++j) px[j] = project_pixel<1, 1>(cm, ns, fl, pt[j], acc[j], min_dist, W, H);
-            } else if (ns == 3 && fl == 10) {          // KITTI: rotate then translate twice, then R0
-#pragma unroll
-                for (int j = 0; j < PH_PT; ++j) px[j] = project_pixel<3, 10>(cm, ns, fl, pt[j], acc[j], min_dist, W, H);
-            } else {
-#pragma unroll
-                for (int j = 0; j < PH_PT; ++j) px[j] = project_pixel<-1, 0>(cm, ns, fl, pt[j], acc[j], min_dist, W, H);
-            }
+            if (ns == 2 && fl == 5) project_quad<2, 5>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);          // nuScenes
+            else if (ns == 1 && fl == 1) project_quad<1, 1>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);     // Waymo
+            else if (ns == 3 && fl == 10) project_quad<3, 10>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);   // KITTI
+            else project_quad<-1, 0>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);
+            bool any = false;
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
                 s_pix[c * PH_BLOCK_PTS + ph_slot(j)] = px[j];     // read back by this thread only
@@ -221,7 +274,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
                 const int i1 = (chunk + (int)gridDim.x) * PH_BLOCK_PTS + ph_slot(j);
-                pt[j] = i1 < n ? points[p0 + i1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                pt[j] = i1 < n ? points[p0 + i1] : make_float4(qnan, qnan, qnan, 0.f);
             }
         }
         for (int plane = 0; plane < planes; ++plane) {
@@ -235,6 +288,8 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                 int4 bb = s_bbox[k];
                 bb.x = __builtin_amdgcn_readfirstlane(bb.x); bb.y = __builtin_amdgcn_readfirstlane(bb.y);
                 bb.z = __builtin_amdgcn_readfirstlane(bb.z); bb.w = __builtin_amdgcn_readfirstlane(bb.w);
+                const int rx = bb.z - bb.x, ry = bb.w - bb.y;
+                if ((rx | ry) < 0) continue;                      // empty mask (wave-uniform)
                 const uint32_t *mw = packed + (size_t)(m0 + k) * mask_words;
                 uint32_t word[PH_PT];
                 int px[PH_PT];
@@ -243,7 +298,8 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                 for (int j = 0; j < PH_PT; ++j) {
                     px[j] = s_pix[c * PH_BLOCK_PTS + ph_slot(j)];
                     const int iu = px[j] & 0xFFFF, iv = px[j] >> 16;
-                    cand[j] = px[j] >= 0 && iu >= bb.x && iu <= bb.z && iv >= bb.y && iv <= bb.w;
+                    // px = -1 gives iv = -1 < bb.y: fails the unsigned range test by itself
+                    cand[j] = ((unsigned)(iu - bb.x) <= (unsigned)rx) & ((unsigned)(iv - bb.y) <= (unsigned)ry);
                     word[j] = 0;
                     if (cand[j]) word[j] = mw[(size_t)iv * Wp + (iu >> 5)];
                 }
