@@ -166,8 +166,14 @@ static __device__ void cone_setup(const float *cm, int W, int H, float min_dist,
 }
 
 // grid (G, F).  A block walks 1024-point chunks of one frame (chunk = blockIdx.x, += gridDim.x),
-// 4 points per thread (4 independent mask gathers in flight).  Per-frame tables (cameras, mask
-// cameras, mask bounding boxes) are staged into LDS once per block.
+// 4 points per thread (4 independent mask gathers in flight).  Per-frame tables (camera records, visibility
+// cones, per-camera mask sets) are staged into LDS once per block.  Per wave and chunk:
+//   for every camera that can see any of the wave's points (cone test): project the 4 points (pixel codes stay
+//   in registers), then for every mask of that camera: bounding-box test, one mask word per candidate point,
+//   bit test, per-mask hit count.
+// ONE_PLANE (<= 32 masks per frame): the hit word of a point lives in a register; otherwise in the thread's own
+// LDS slots, one per plane.
+template <bool ONE_PLANE>
 __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     const float4 *__restrict__ points, const int32_t *__restrict__ pt_off, int n_points_total,
     const float *__restrict__ cams, int n_cams, const int32_t *__restrict__ mask_off,
@@ -189,12 +195,13 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
 
     __shared__ float s_cam[CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
     __shared__ float s_cone[CM3D_MAX_CAMS][8];           // conservative visibility cone per camera
-    // dynamic LDS: bbox[nm_cap], pixel codes [n_cams][PH_BLOCK_PTS], mask camera[nm_cap], counts[nm_cap]
+    // dynamic LDS: masks of every camera as bit sets [n_cams][planes_cap], counts [nm_cap],
+    // and (several planes only) hit words [planes][PH_BLOCK_PTS]
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    int4 *s_bbox = reinterpret_cast<int4 *>(s_dyn);
-    int *s_pix = reinterpret_cast<int *>(s_dyn + (size_t)nm_cap * sizeof(int4));
-    int *s_mcam = s_pix + (size_t)n_cams * PH_BLOCK_PTS;
-    int *s_cnt = s_mcam + nm_cap;
+    const int planes_cap = (nm_cap + 31) >> 5;
+    uint32_t *s_cmask = reinterpret_cast<uint32_t *>(s_dyn);
+    int *s_cnt = reinterpret_cast<int *>(s_cmask + CM3D_MAX_CAMS * planes_cap);
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cnt + nm_cap);
 
     // points of the first chunk are requested before the table staging so that both latencies overlap.
     // Slots past the end of the frame hold NaN points: every test below rejects them by itself.
@@ -207,32 +214,34 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     }
     for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS)
         s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
-    for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
-        int c = mask_cam[m0 + k];
-        int4 bb = bbox[m0 + k];
-        if (c < 0 || c >= n_cams) { atomicOr(&status[0], 4); c = 0; bb = make_int4(1, 1, 0, 0); }
-        s_mcam[k] = c; s_bbox[k] = bb; s_cnt[k] = 0;
-    }
+    for (int q = threadIdx.x; q < CM3D_MAX_CAMS * planes_cap; q += PH_THREADS) s_cmask[q] = 0u;
+    for (int k = threadIdx.x; k < nm; k += PH_THREADS) s_cnt[k] = 0;
     __syncthreads();
+    for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
+        const int c = mask_cam[m0 + k];
+        if (c < 0 || c >= n_cams) atomicOr(&status[0], 4);           // such a mask gets no points
+        else atomicOr(&s_cmask[c * planes_cap + (k >> 5)], 1u << (k & 31));
+    }
     // visibility cones from the staged records (LDS reads; no dependent global loads)
     if (threadIdx.x < n_cams) cone_setup(s_cam + threadIdx.x * CM3D_CAM_STRIDE, W, H, min_dist, s_cone[threadIdx.x]);
     __syncthreads();
 
     const size_t mask_words = (size_t)H * Wp;
+    const int lane = cm3d_lane();
     for (int chunk = blockIdx.x; chunk < nblk; chunk += gridDim.x) {
         const int base = chunk * PH_BLOCK_PTS;
-        int idx[PH_PT];
-        bool in_range[PH_PT];
-#pragma unroll
-        for (int j = 0; j < PH_PT; ++j) {
-            idx[j] = base + ph_slot(j);
-            in_range[j] = idx[j] < n;
-        }
         static_assert(PH_PT == 4, "points are handled as two pairs");
         const f2 X[2] = {{pt[0].x, pt[1].x}, {pt[2].x, pt[3].x}};
         const f2 Y[2] = {{pt[0].y, pt[1].y}, {pt[2].y, pt[3].y}};
         const f2 Z[2] = {{pt[0].z, pt[1].z}, {pt[2].z, pt[3].z}};
-        uint32_t cam_any = 0;
+        uint32_t bits[PH_PT];
+#pragma unroll
+        for (int j = 0; j < PH_PT; ++j) bits[j] = 0;
+        if (!ONE_PLANE) {
+            for (int pl = 0; pl < planes; ++pl)
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j) s_bits[pl * PH_BLOCK_PTS + ph_slot(j)] = 0u;      // this thread's own slots
+        }
 #pragma unroll 1
         for (int c = 0; c < n_cams; ++c) {
             // conservative pre-test (a superset of the exact in-image test): is any of this wave's points
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                 }
                 inside = fmaxf(fmaxf(m[0].x, m[0].y), fmaxf(m[1].x, m[1].y));
             }
-            if (!__ballot(inside >= 0.0f)) continue;           // s_pix of this camera is never read (cam_any bit clear)
+            if (!__ballot(inside >= 0.0f)) continue;
             const int ns = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 54]);
             const int fl = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 55]);
             const float *cm = s_cam + c * CM3D_CAM_STRIDE;
@@ -262,15 +271,44 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             else if (ns == 1 && fl == 1) project_quad<1, 1>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);     // Waymo
             else if (ns == 3 && fl == 10) project_quad<3, 10>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);   // KITTI
             else project_quad<-1, 0>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);
-            bool any = false;
+            if (!__ballot((px[0] & px[1] & px[2] & px[3]) >= 0)) continue;      // no point of the wave in this image
+            int iu[PH_PT], iv[PH_PT];
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) {
-                s_pix[c * PH_BLOCK_PTS + ph_slot(j)] = px[j];     // read back by this thread only
-                any = any || px[j] >= 0;
+            for (int j = 0; j < PH_PT; ++j) { iu[j] = px[j] & 0xFFFF; iv[j] = px[j] >> 16; }    // px = -1: iv = -1
+            // the masks of this camera
+            for (int pl = 0; pl < planes; ++pl) {
+                uint32_t mm = __builtin_amdgcn_readfirstlane(s_cmask[c * planes_cap + pl]);
+                while (mm) {
+                    const int kb = __builtin_ctz(mm);
+                    mm &= mm - 1;
+                    const int k = pl * 32 + kb;
+                    const int4 bb = bbox[m0 + k];                          // uniform address: scalar load
+                    const int x0 = __builtin_amdgcn_readfirstlane(bb.x), y0 = __builtin_amdgcn_readfirstlane(bb.y);
+                    const int rx = __builtin_amdgcn_readfirstlane(bb.z) - x0, ry = __builtin_amdgcn_readfirstlane(bb.w) - y0;
+                    if ((rx | ry) < 0) continue;                           // empty mask (wave-uniform)
+                    const uint32_t *mw = packed + (size_t)(m0 + k) * mask_words;
+                    uint32_t word[PH_PT];
+                    bool cand[PH_PT];
+#pragma unroll
+                    for (int j = 0; j < PH_PT; ++j) {
+                        // iv = -1 < y0 fails the unsigned range test by itself
+                        cand[j] = ((unsigned)(iu[j] - x0) <= (unsigned)rx) & ((unsigned)(iv[j] - y0) <= (unsigned)ry);
+                        word[j] = 0;
+                        if (cand[j]) word[j] = mw[(size_t)iv[j] * Wp + (iu[j] >> 5)];
+                    }
+                    int cnt = 0;
+#pragma unroll
+                    for (int j = 0; j < PH_PT; ++j) {
+                        const bool hit = cand[j] && ((word[j] >> (iu[j] & 31)) & 1u);
+                        if (ONE_PLANE) bits[j] |= (hit ? 1u : 0u) << kb;
+                        else if (hit) s_bits[pl * PH_BLOCK_PTS + ph_slot(j)] |= 1u << kb;
+                        cnt += __popcll(__ballot(hit));
+                    }
+                    if (cnt && lane == 0) atomicAdd(&s_cnt[k], cnt);
+                }
             }
-            if (__ballot(any)) cam_any |= 1u << c;
         }
-        // prefetch the next chunk's points (if this block has one) under the mask phase
+        // prefetch the next chunk's points (if this block has one) under the count flush
         if (chunk + (int)gridDim.x < nblk) {
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
@@ -278,44 +316,15 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                 pt[j] = i1 < n ? points[p0 + i1] : make_float4(qnan, qnan, qnan, 0.f);
             }
         }
-        for (int plane = 0; plane < planes; ++plane) {
-            uint32_t bits[PH_PT];
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) bits[j] = 0;
-            const int kend = min(nm, plane * 32 + 32);
-            for (int k = plane * 32; k < kend; ++k) {
-                const int c = __builtin_amdgcn_readfirstlane(s_mcam[k]);
-                if (!((cam_any >> c) & 1u)) continue;            // wave-uniform
-                int4 bb = s_bbox[k];
-                bb.x = __builtin_amdgcn_readfirstlane(bb.x); bb.y = __builtin_amdgcn_readfirstlane(bb.y);
-                bb.z = __builtin_amdgcn_readfirstlane(bb.z); bb.w = __builtin_amdgcn_readfirstlane(bb.w);
-                const int rx = bb.z - bb.x, ry = bb.w - bb.y;
-                if ((rx | ry) < 0) continue;                      // empty mask (wave-uniform)
-                const uint32_t *mw = packed + (size_t)(m0 + k) * mask_words;
-                uint32_t word[PH_PT];
-                int px[PH_PT];
-                bool cand[PH_PT];
-#pragma unroll
-                for (int j = 0; j < PH_PT; ++j) {
-                    px[j] = s_pix[c * PH_BLOCK_PTS + ph_slot(j)];
-                    const int iu = px[j] & 0xFFFF, iv = px[j] >> 16;
-                    // px = -1 gives iv = -1 < bb.y: fails the unsigned range test by itself
-                    cand[j] = ((unsigned)(iu - bb.x) <= (unsigned)rx) & ((unsigned)(iv - bb.y) <= (unsigned)ry);
-                    word[j] = 0;
-                    if (cand[j]) word[j] = mw[(size_t)iv * Wp + (iu >> 5)];
-                }
-                int cnt = 0;
-#pragma unroll
-                for (int j = 0; j < PH_PT; ++j) {
-                    const bool hit = cand[j] && ((word[j] >> (px[j] & 31)) & 1u);
-                    bits[j] |= (hit ? 1u : 0u) << (k & 31);
-                    cnt += __popcll(__ballot(hit));
-                }
-                if (cnt && cm3d_lane() == 0) atomicAdd(&s_cnt[k], cnt);
+        for (int j = 0; j < PH_PT; ++j) {
+            const int idx = base + ph_slot(j);
+            if (idx < n) {
+                if (ONE_PLANE) hit_words[(size_t)p0 + idx] = bits[j];
+                else
+                    for (int pl = 0; pl < planes; ++pl)
+                        hit_words[(size_t)pl * n_points_total + p0 + idx] = s_bits[pl * PH_BLOCK_PTS + ph_slot(j)];
             }
-#pragma unroll
-            for (int j = 0; j < PH_PT; ++j)
-                if (in_range[j]) hit_words[(size_t)plane * n_points_total + p0 + idx[j]] = bits[j];
         }
         __syncthreads();
         // per-(block, mask) counts: exact output offsets come from their exclusive scan
@@ -560,10 +569,25 @@ extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int
     if ((long long)gx * n_frames > max_blocks) gx = (int)((max_blocks + n_frames - 1) / n_frames);
     if (gx > nblk_max) gx = nblk_max;
     if (gx < 1) gx = 1;
-    const size_t lds = (size_t)nm_cap * (sizeof(int4) + 2 * sizeof(int)) + (size_t)n_cams * PH_BLOCK_PTS * sizeof(int);
-    hipLaunchKernelGGL(k_project_hits, dim3(gx, n_frames), dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off, n_points_total,
-                       cams, n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, nm_cap, nblk_max, hit_words,
-                       hit_count, (int32_t *)workspace, status);
+    const int planes_cap = (nm_cap + 31) / 32;
+    size_t lds = (size_t)CM3D_MAX_CAMS * planes_cap * sizeof(uint32_t) + (size_t)nm_cap * sizeof(int);
+    if (planes_cap == 1) {
+        hipLaunchKernelGGL(k_project_hits<true>, dim3(gx, n_frames), dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off,
+                           n_points_total, cams, n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, nm_cap,
+                           nblk_max, hit_words, hit_count, (int32_t *)workspace, status);
+    } else {
+        lds += (size_t)planes_cap * PH_BLOCK_PTS * sizeof(uint32_t);
+        static size_t lds_allowed = 48 * 1024;
+        if (lds > lds_allowed) {
+            if (hipFuncSetAttribute((const void *)k_project_hits<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+                hipSuccess)
+                return CM3D_ERR_LAUNCH;
+            lds_allowed = lds;
+        }
+        hipLaunchKernelGGL(k_project_hits<false>, dim3(gx, n_frames), dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off,
+                           n_points_total, cams, n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, nm_cap,
+                           nblk_max, hit_words, hit_count, (int32_t *)workspace, status);
+    }
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }
