@@ -13,7 +13,7 @@
 #define EP_THREADS 256
 #define EP_MAX_WP 128          // supports W <= 4096
 #define EP_LDS_WORDS 8192      // dense kernel: at most 32 KiB of packed rows per workgroup (dynamic LDS)
-#define RLE_LDS_WORDS 4096     // RLE kernel: 16 KiB tiles (they are as narrow as the mask's rectangle)
+#define RLE_LDS_WORDS 8192     // RLE kernel: 32 KiB tiles (they are as narrow as the mask's rectangle)
 
 // one bit per non-zero byte of a 16-byte chunk -> 16 bits
 static __device__ __forceinline__ uint32_t pack16(uint4 v)
@@ -263,86 +263,169 @@ __global__ __launch_bounds__(256) void k_rle_to_dense(const uint32_t *__restrict
     }
 }
 
-// f1: RLE -> packed tile in LDS -> erode -> store.  grid (max_bands, n_masks).
-// A mask's work is its own rectangle (rows y_first..y_last, words xw0..xw1): the tile is as wide as the
-// rectangle (+ halo) and as tall as LDS allows, so most masks need one or two workgroups; the
-// other workgroups of the mask exit at once.  Nothing outside the rectangle is written.
-__global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *__restrict__ ends_all,
-                                                                const int32_t *__restrict__ rle_off,
-                                                                const int4 *__restrict__ mrect, int W, int H, int Wp,
+// sets the bits of pixels [s, e) (row-major pixel indices, clipped by the caller to the rows held in LDS)
+static __device__ __forceinline__ void rle_paint(uint32_t *s_rows, int lw, int xw0, int ya, int W, uint32_t s, uint32_t e)
+{
+    while (s < e) {
+        const uint32_t y = s / W, x = s - y * W;
+        const uint32_t xe = min((uint32_t)W, x + (e - s));   // exclusive end within this row
+        uint32_t *row = s_rows + ((int)y - ya) * lw + 1 - xw0;    // row[xw] = packed word xw
+        const uint32_t w0 = x >> 5, w1 = (xe - 1) >> 5;
+        const uint32_t m0 = 0xFFFFFFFFu << (x & 31);
+        const uint32_t m1 = 0xFFFFFFFFu >> (31 - ((xe - 1) & 31));
+        if (w0 == w1) atomicOr(&row[w0], m0 & m1);
+        else {
+            atomicOr(&row[w0], m0);
+            for (uint32_t w = w0 + 1; w < w1; ++w) atomicOr(&row[w], 0xFFFFFFFFu);
+            atomicOr(&row[w1], m1);
+        }
+        s += xe - x;
+    }
+}
+
+// One chunk of a mask's run lengths: thread t takes runs [base + 8 t, base + 8 t + 8); returns the start pixel
+// of its first run (block-wide exclusive scan on top of `carry`, which is advanced).  Two barriers.
+#define RS_PER 8
+#define RS_CHUNK (EP_THREADS * RS_PER)
+static __device__ __forceinline__ int rle_chunk_scan(const uint32_t *__restrict__ cnts, int n, int base, int (&v)[RS_PER], int *s_w,
+                                                     int &carry)
+{
+    const int i0 = base + (int)threadIdx.x * RS_PER;
+    int sum = 0;
+#pragma unroll
+    for (int q = 0; q < RS_PER; ++q) { v[q] = i0 + q < n ? (int)cnts[i0 + q] : 0; sum += v[q]; }
+    const int inc = cm3d_wave_incl_scan(sum);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (cm3d_lane() == 63) s_w[wave] = inc;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < EP_THREADS / 64; ++w) { const int c = s_w[w]; if (w < wave) wbase += c; tot += c; }
+    const int start = carry + wbase + inc - sum;
+    carry += tot;
+    return start;
+}
+
+// f1: run lengths -> packed tile in LDS -> erode -> store.  ONE workgroup per mask, one launch:
+//   pass 1 streams the run lengths (block scan, 2048 runs per step) and finds the rectangle of the set pixels;
+//   then, tile by tile over that rectangle (the tile is as wide as the rectangle + halo and as tall as LDS
+//   allows, so nearly every mask is a single tile): clear, paint the 1-runs, erode, store, reduce the bbox.
+// A mask of up to 2048 runs keeps its runs in registers between the passes; longer lists are streamed again
+// per tile.  Nothing outside the rectangle is written; the workgroup owns the mask's bbox (no global atomics).
+__global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *__restrict__ cnts_all,
+                                                                const int32_t *__restrict__ rle_off, int W, int H, int Wp,
                                                                 uint32_t *__restrict__ packed, int32_t *__restrict__ bbox)
 {
     extern __shared__ __align__(16) uint32_t s_rows[];
-    __shared__ int s_range[2];
-    const int m = blockIdx.y;
-    const int4 rc = mrect[m];
-    if (rc.x > rc.y) return;                                    // empty mask
-    const int xw0 = rc.z, wc = rc.w - rc.z + 1, lw = wc + 2;
-    int br = RLE_LDS_WORDS / lw - 2;                            // output rows per tile
-    const int need = rc.y - rc.x + 1;
-    if (br > need) br = need;
+    __shared__ int s_w[EP_THREADS / 64];
+    __shared__ int s_rect[4];                   // ylo, xlo, yhi, xhi of the set pixels
+    __shared__ int s_bb[4];                     // bbox of the eroded pixels
+    const int m = blockIdx.x;
     const int o = rle_off[m], n = rle_off[m + 1] - o;
-    const uint32_t *ends = ends_all + o;
-    // most masks fit one tile; the few that do not are walked by the mask's workgroups in a strided loop
-    for (int y0 = rc.x + (int)blockIdx.x * br; y0 <= rc.y; y0 += (int)gridDim.x * br) {
-    __syncthreads();                                            // the previous tile's readers are done
-    const int rows = min(br, rc.y - y0 + 1);
-    const int lrows = rows + 2;
-    const int ya = y0 - 1;                                      // image row of LDS row 0
-    // initial tile: ones outside the image, zeros inside; pad bits of a row's last word are ones
-    const uint32_t pad = (W & 31) ? ~((1u << (W & 31)) - 1u) : 0u;
+    const uint32_t *cnts = cnts_all + o;
+    if (threadIdx.x == 0) {
+        s_rect[0] = 0x7FFFFFFF; s_rect[1] = 0x7FFFFFFF; s_rect[2] = -1; s_rect[3] = -1;
+        s_bb[0] = 0x7FFFFFFF; s_bb[1] = 0x7FFFFFFF; s_bb[2] = -1; s_bb[3] = -1;
+    }
+    // ---- pass 1: rectangle
+    int v0[RS_PER], start0 = 0;                 // the first chunk stays in registers
     {
-    int r = (int)threadIdx.x / lw, c = (int)threadIdx.x - r * lw;
-    const int dr_step = EP_THREADS / lw, dc_step = EP_THREADS - dr_step * lw;
-    for (int q = threadIdx.x; q < lrows * lw; q += EP_THREADS, r += dr_step, c += dc_step) {
-        if (c >= lw) { c -= lw; ++r; }
-        const int y = ya + r, xw = xw0 - 1 + c;
-        uint32_t v = 0u;
-        if (y < 0 || y >= H || xw < 0 || xw >= Wp) v = 0xFFFFFFFFu;
-        else if (xw == Wp - 1) v = pad;
-        s_rows[q] = v;
-    }
-    }
-    if (threadIdx.x < 2) s_range[threadIdx.x] = 0;
-    __syncthreads();
-    const int yc0 = max(ya, 0), yc1 = min(ya + lrows - 1, H - 1);            // image rows held in LDS
-    const uint32_t px0 = (uint32_t)yc0 * W, px1 = (uint32_t)(yc1 + 1) * W;   // pixel range [px0, px1)
-    // cooperative lower bounds (ends is ascending): #runs with end <= px0, #runs with end <= px1-1
-    int c0 = 0, c1 = 0;
-    for (int i = threadIdx.x; i < n; i += EP_THREADS) {
-        const uint32_t e = ends[i];
-        c0 += e <= px0 ? 1 : 0;
-        c1 += e <= px1 - 1 ? 1 : 0;
-    }
-    c0 = cm3d_wave_sum(c0); c1 = cm3d_wave_sum(c1);
-    if (cm3d_lane() == 0) { atomicAdd(&s_range[0], c0); atomicAdd(&s_range[1], c1); }
-    __syncthreads();
-    const int r_first = s_range[0], r_last = min(s_range[1], n - 1);
-    // every 1-run (odd index) overlapping the tile sets its bits, row by row (all of them lie inside
-    // the word range of the rectangle)
-    for (int r = r_first + threadIdx.x; r <= r_last; r += EP_THREADS) {
-        if (!(r & 1)) continue;
-        uint32_t s = r > 0 ? ends[r - 1] : 0u, e = ends[r];
-        s = max(s, px0); e = min(e, px1);
-        while (s < e) {
-            const uint32_t y = s / W, x = s - y * W;
-            const uint32_t xe = min((uint32_t)W, x + (e - s));   // exclusive end within this row
-            uint32_t *row = s_rows + ((int)y - ya) * lw + 1 - xw0;    // row[xw] = packed word xw
-            uint32_t w0 = x >> 5, w1 = (xe - 1) >> 5;
-            uint32_t m0 = 0xFFFFFFFFu << (x & 31);
-            uint32_t m1 = 0xFFFFFFFFu >> (31 - ((xe - 1) & 31));
-            if (w0 == w1) atomicOr(&row[w0], m0 & m1);
-            else {
-                atomicOr(&row[w0], m0);
-                for (uint32_t w = w0 + 1; w < w1; ++w) atomicOr(&row[w], 0xFFFFFFFFu);
-                atomicOr(&row[w1], m1);
+        int carry = 0;
+        int ylo = 0x7FFFFFFF, yhi = -1, xlo = 0x7FFFFFFF, xhi = -1;
+        for (int base = 0; base < n; base += RS_CHUNK) {
+            int v[RS_PER];
+            int run = rle_chunk_scan(cnts, n, base, v, s_w, carry);
+            if (base == 0) {
+                start0 = run;
+#pragma unroll
+                for (int q = 0; q < RS_PER; ++q) v0[q] = v[q];
             }
-            s += xe - x;
+            const int i0 = base + (int)threadIdx.x * RS_PER;
+#pragma unroll
+            for (int q = 0; q < RS_PER; ++q) {
+                if (((i0 + q) & 1) && v[q] > 0) {                     // a 1-run [s, e)
+                    const int s = run, e = run + v[q];
+                    const int ys = s / W, ye = (e - 1) / W;
+                    ylo = min(ylo, ys); yhi = max(yhi, ye);
+                    if (ys == ye) { xlo = min(xlo, s - ys * W); xhi = max(xhi, e - 1 - ys * W); }
+                    else { xlo = 0; xhi = W - 1; }
+                }
+                run += v[q];
+            }
         }
+        ylo = cm3d_wave_min(ylo); xlo = cm3d_wave_min(xlo); yhi = cm3d_wave_max(yhi); xhi = cm3d_wave_max(xhi);
+        __syncthreads();                        // s_rect initialised
+        if (cm3d_lane() == 0 && yhi >= 0) {
+            atomicMin(&s_rect[0], ylo); atomicMin(&s_rect[1], xlo); atomicMax(&s_rect[2], yhi); atomicMax(&s_rect[3], xhi);
+        }
+        __syncthreads();
+    }
+    const int ry0 = s_rect[0], ry1 = min(s_rect[2], H - 1);
+    if (s_rect[2] < 0) {                        // empty mask
+        if (threadIdx.x == 0) { bbox[4 * m + 0] = 0x7FFFFFFF; bbox[4 * m + 1] = 0x7FFFFFFF; bbox[4 * m + 2] = -1; bbox[4 * m + 3] = -1; }
+        return;
+    }
+    const int xw0 = s_rect[1] >> 5, wc = (min(s_rect[3], W - 1) >> 5) - xw0 + 1, lw = wc + 2;
+    int br = RLE_LDS_WORDS / lw - 2;            // output rows per tile
+    br = min(br, ry1 - ry0 + 1);
+    const uint32_t pad = (W & 31) ? ~((1u << (W & 31)) - 1u) : 0u;
+    // ---- tiles
+    for (int y0 = ry0; y0 <= ry1; y0 += br) {
+        __syncthreads();                        // the previous tile's readers are done
+        const int rows = min(br, ry1 - y0 + 1);
+        const int lrows = rows + 2;
+        const int ya = y0 - 1;                  // image row of LDS row 0
+        // initial tile: ones outside the image, zeros inside; pad bits of a row's last word are ones
+        {
+            int r = (int)threadIdx.x / lw, c = (int)threadIdx.x - r * lw;
+            const int dr_step = EP_THREADS / lw, dc_step = EP_THREADS - dr_step * lw;
+            for (int q = threadIdx.x; q < lrows * lw; q += EP_THREADS, r += dr_step, c += dc_step) {
+                if (c >= lw) { c -= lw; ++r; }
+                const int y = ya + r, xw = xw0 - 1 + c;
+                uint32_t v = 0u;
+                if (y < 0 || y >= H || xw < 0 || xw >= Wp) v = 0xFFFFFFFFu;
+                else if (xw == Wp - 1) v = pad;
+                s_rows[q] = v;
+            }
+        }
+        __syncthreads();
+        const int yc0 = max(ya, 0), yc1 = min(ya + lrows - 1, H - 1);            // image rows held in LDS
+        const uint32_t px0 = (uint32_t)yc0 * W, px1 = (uint32_t)(yc1 + 1) * W;   // pixel range [px0, px1)
+        // every 1-run (odd index) overlapping the tile sets its bits (all of them lie inside the word range)
+        if (n <= RS_CHUNK) {
+            int run = start0;
+            const int i0 = (int)threadIdx.x * RS_PER;
+#pragma unroll
+            for (int q = 0; q < RS_PER; ++q) {
+                if (((i0 + q) & 1) && v0[q] > 0) {
+                    const uint32_t s = max((uint32_t)run, px0), e = min((uint32_t)(run + v0[q]), px1);
+                    rle_paint(s_rows, lw, xw0, ya, W, s, e);
+                }
+                run += v0[q];
+            }
+        } else {
+            int carry = 0;
+            for (int base = 0; base < n; base += RS_CHUNK) {
+                int v[RS_PER];
+                int run = rle_chunk_scan(cnts, n, base, v, s_w, carry);
+                const int i0 = base + (int)threadIdx.x * RS_PER;
+#pragma unroll
+                for (int q = 0; q < RS_PER; ++q) {
+                    if (((i0 + q) & 1) && v[q] > 0) {
+                        const uint32_t s = max((uint32_t)run, px0), e = min((uint32_t)(run + v[q]), px1);
+                        rle_paint(s_rows, lw, xw0, ya, W, s, e);
+                    }
+                    run += v[q];
+                }
+                if ((uint32_t)carry >= px1) break;          // uniform: the rest lies below the tile
+            }
+        }
+        __syncthreads();
+        erode_tile_store(s_rows, lw, wc, xw0, ya, rows, W, Wp, packed + (size_t)m * H * Wp, s_bb);
     }
     __syncthreads();
-    erode_tile_store(s_rows, lw, wc, xw0, ya, rows, W, Wp, packed + (size_t)m * H * Wp, bbox + 4 * m);
-    }
+    if (threadIdx.x < 4) bbox[4 * m + threadIdx.x] = s_bb[threadIdx.x];
 }
 
 static inline size_t rle_align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -383,17 +466,11 @@ extern "C" int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rl
         return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_rle_workspace_bytes(total_runs)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    uint32_t *ends = (uint32_t *)workspace;
-    int4 *mrect = (int4 *)((char *)workspace + rle_align16((size_t)total_runs * 4));
     const int Wp = (W + 31) / 32;
-    const int min_rows = RLE_LDS_WORDS / (Wp + 2) - 2;          // tile height of a full-width mask
-    if (min_rows < 1) return CM3D_ERR_ARG;
-    int max_bands = (H + min_rows - 1) / min_rows;
-    if (max_bands > 2) max_bands = 2;                           // workgroups per mask; each walks its tiles in a strided loop
-    hipLaunchKernelGGL(k_rle_ends, dim3(n_masks), dim3(RE_THREADS), 0, st, rle_counts, rle_off, W, ends, mrect, bbox);
-    CM3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_rle_erode_pack, dim3(max_bands, n_masks), dim3(EP_THREADS), (size_t)RLE_LDS_WORDS * 4, st, ends, rle_off, mrect,
-                       W, H, Wp, packed, bbox);
+    if (RLE_LDS_WORDS / (Wp + 2) - 2 < 1) return CM3D_ERR_ARG;  // tile height of a full-width mask
+    (void)workspace;                                            // reserved (the run ends are not materialised)
+    hipLaunchKernelGGL(k_rle_erode_pack, dim3(n_masks), dim3(EP_THREADS), (size_t)RLE_LDS_WORDS * 4, st, rle_counts, rle_off, W, H, Wp,
+                       packed, bbox);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }
