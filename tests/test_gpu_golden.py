@@ -96,7 +96,12 @@ def test_erode_and_decode_kernels_equal_oracle(oracle):
         masks.append(np.zeros((H, W), np.uint8))
         edge = np.zeros((H, W), np.uint8); edge[:, :3] = 1; edge[:2, :] = 1; edge[:, -2:] = 1
         masks.append(edge)
+        # long run lists (streamed 2048 runs at a time): dense noise that still leaves eroded pixels, stripes
+        masks.append((rng.random((H, W)) < 0.97).astype(np.uint8))
+        stripes = np.zeros((H, W), np.uint8); stripes[:, (np.arange(W) % 7) < 4] = 1; stripes[H // 2:, :] ^= 1
+        masks.append(stripes)
         counts = [rle.dense_to_counts(m) for m in masks]
+        assert W * H < 30000 or max(len(c) for c in counts) > 2048
         dense = ops.decode([{"size": [W, H], "counts": c} for c in counts], as_counts=True)
         assert np.array_equal(dense.cpu().numpy(), np.stack(masks)), "RLE expansion"
         # non-binary values (the producer writes alpha 153) count as set
