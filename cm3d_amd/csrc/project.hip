@@ -15,6 +15,7 @@
 #define PH_THREADS 256
 #define PH_PT 4                                   // points per thread
 #define PH_BLOCK_PTS (PH_THREADS * PH_PT)
+#define PH_MB 4                                   // masks of a camera handled together in the mask loop
 
 // Block-local slot of a thread's j-th point: wave w owns the 256 consecutive points [256 w, 256 w + 256)
 // (LiDAR points are stored ring by ring, so a wave then sees one short arc and few cameras); for a fixed j
@@ -275,36 +276,49 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             int iu[PH_PT], iv[PH_PT];
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) { iu[j] = px[j] & 0xFFFF; iv[j] = px[j] >> 16; }    // px = -1: iv = -1
-            // the masks of this camera
+            // the masks of this camera, PH_MB at a time: all bounding boxes, then all mask words of the batch are
+            // requested before the first one is used (one memory round trip per batch instead of one per mask)
             for (int pl = 0; pl < planes; ++pl) {
                 uint32_t mm = __builtin_amdgcn_readfirstlane(s_cmask[c * planes_cap + pl]);
                 while (mm) {
-                    const int kb = __builtin_ctz(mm);
-                    mm &= mm - 1;
-                    const int k = pl * 32 + kb;
-                    const int4 bb = bbox[m0 + k];                          // uniform address: scalar load
-                    const int x0 = __builtin_amdgcn_readfirstlane(bb.x), y0 = __builtin_amdgcn_readfirstlane(bb.y);
-                    const int rx = __builtin_amdgcn_readfirstlane(bb.z) - x0, ry = __builtin_amdgcn_readfirstlane(bb.w) - y0;
-                    if ((rx | ry) < 0) continue;                           // empty mask (wave-uniform)
-                    const uint32_t *mw = packed + (size_t)(m0 + k) * mask_words;
-                    uint32_t word[PH_PT];
-                    bool cand[PH_PT];
+                    int kb[PH_MB];
 #pragma unroll
-                    for (int j = 0; j < PH_PT; ++j) {
-                        // iv = -1 < y0 fails the unsigned range test by itself
-                        cand[j] = ((unsigned)(iu[j] - x0) <= (unsigned)rx) & ((unsigned)(iv[j] - y0) <= (unsigned)ry);
-                        word[j] = 0;
-                        if (cand[j]) word[j] = mw[(size_t)iv[j] * Wp + (iu[j] >> 5)];
+                    for (int b = 0; b < PH_MB; ++b) {
+                        kb[b] = mm ? __builtin_ctz(mm) : -1;
+                        mm = mm ? (mm & (mm - 1)) : 0u;
                     }
-                    int cnt = 0;
+                    int4 bb[PH_MB];
 #pragma unroll
-                    for (int j = 0; j < PH_PT; ++j) {
-                        const bool hit = cand[j] && ((word[j] >> (iu[j] & 31)) & 1u);
-                        if (ONE_PLANE) bits[j] |= (hit ? 1u : 0u) << kb;
-                        else if (hit) s_bits[pl * PH_BLOCK_PTS + ph_slot(j)] |= 1u << kb;
-                        cnt += __popcll(__ballot(hit));
+                    for (int b = 0; b < PH_MB; ++b) bb[b] = bbox[m0 + pl * 32 + max(kb[b], 0)];      // uniform: scalar loads
+                    uint32_t word[PH_MB][PH_PT];
+#pragma unroll
+                    for (int b = 0; b < PH_MB; ++b) {
+#pragma unroll
+                        for (int j = 0; j < PH_PT; ++j) word[b][j] = 0u;
+                        const int x0 = __builtin_amdgcn_readfirstlane(bb[b].x), y0 = __builtin_amdgcn_readfirstlane(bb[b].y);
+                        const int rx = __builtin_amdgcn_readfirstlane(bb[b].z) - x0, ry = __builtin_amdgcn_readfirstlane(bb[b].w) - y0;
+                        if (kb[b] < 0 || (rx | ry) < 0) continue;          // no such mask / empty mask (wave-uniform)
+                        const uint32_t *mw = packed + (size_t)(m0 + pl * 32 + kb[b]) * mask_words;
+#pragma unroll
+                        for (int j = 0; j < PH_PT; ++j) {
+                            // iv = -1 < y0 fails the unsigned range test by itself
+                            const bool cand = ((unsigned)(iu[j] - x0) <= (unsigned)rx) & ((unsigned)(iv[j] - y0) <= (unsigned)ry);
+                            if (cand) word[b][j] = mw[(size_t)iv[j] * Wp + (iu[j] >> 5)];
+                        }
                     }
-                    if (cnt && lane == 0) atomicAdd(&s_cnt[k], cnt);
+#pragma unroll
+                    for (int b = 0; b < PH_MB; ++b) {
+                        if (kb[b] < 0) continue;
+                        int cnt = 0;
+#pragma unroll
+                        for (int j = 0; j < PH_PT; ++j) {
+                            const bool hit = (word[b][j] >> (iu[j] & 31)) & 1u;          // word = 0 for a non-candidate
+                            if (ONE_PLANE) bits[j] |= (hit ? 1u : 0u) << kb[b];
+                            else if (hit) s_bits[pl * PH_BLOCK_PTS + ph_slot(j)] |= 1u << kb[b];
+                            cnt += __popcll(__ballot(hit));
+                        }
+                        if (cnt && lane == 0) atomicAdd(&s_cnt[pl * 32 + kb[b]], cnt);
+                    }
                 }
             }
         }

@@ -13,7 +13,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in "abc":
     for f in glob.glob(f"gpurun_out/pmc_insts/{d}/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():
     if k.startswith("k_"):
         print(k, {c: round(sum(x) / len(x) / 1e6, 3) for c, x in v.items()})

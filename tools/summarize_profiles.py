@@ -15,6 +15,14 @@ import sys
 STREAM_READERS = {"k_project_hits", "k_erode_pack"}        # float4 / uint4 coalesced point and mask streams
 
 
+def kname(full):
+    """'void k_project_hits<true>(float4 const*, ...)' -> 'k_project_hits'"""
+    n = full.split("(")[0].strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0]
+
+
 def main(tag):
     src = os.path.join("gpurun_out", tag)
     os.makedirs("profiles", exist_ok=True)
@@ -26,7 +34,7 @@ def main(tag):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv"))):
             if r["Counter_Name"] == c:
-                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+                agg[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             if k.startswith("k_"):
                 tr[k][c + "_KiB_per_launch"] = sum(v) / len(v)
@@ -43,7 +51,7 @@ def main(tag):
     rows = list(csv.DictReader(open(f"profiles/{tag}_c2_rle_kernel_stats.csv")))
     print(f"{'kernel':42s} {'calls':>5s} {'avg_us':>9s} {'%':>6s} {'HBM MB/launch':>14s}")
     for r in rows[:24]:
-        name = r["Name"].split("(")[0]
+        name = kname(r["Name"])
         mb = out.get(name, {}).get("hbm_bytes_per_launch")
         print(f"{name[:42]:42s} {r['Calls']:>5s} {float(r['AverageNs']) / 1e3:9.1f} {float(r['Percentage']):6.2f} {'' if mb is None else f'{mb / 1e6:14.1f}'}")
 
