@@ -32,20 +32,39 @@ static __device__ __forceinline__ float md_sqrt_core(float x)
 static __device__ __forceinline__ bool md_sqrt_ok(float x) { return (x < 1.0e30f) & ((x >= 1.0e-30f) | (x == 0.0f)); }
 
 struct TileBest { float s; int j; };
-struct TileDesc { int m, off, M, jt; };  // mask, start in hit_idx, list length, tile index inside the mask
+struct TileDesc { int m, off, M, jt, t; };  // mask, start in hit_idx, list length, tile index inside the mask, tile id
 
-// thread per mask: one descriptor per 64-column tile of its index list
-__global__ __launch_bounds__(256) void k_medoid_desc(int n_masks, const int32_t *__restrict__ hit_off,
-                                                     const int32_t *__restrict__ tile_off, int idx_cap, int tile_cap,
-                                                     TileDesc *__restrict__ desc)
+// One descriptor per 64-column tile of every index list, written in WORK order: tiles of the longest lists first
+// (classes by tile count; a tile's cost is its list length), so that the waves which run longest start first and
+// the short ones fill in behind them.  Results are indexed by the tile id t = tile_off[m] + jt, not by the work
+// position, so the order has no influence on any output.  One workgroup.
+#define MD_CLASSES 8
+__global__ __launch_bounds__(1024) void k_medoid_desc(int n_masks, const int32_t *__restrict__ hit_off,
+                                                      const int32_t *__restrict__ tile_off, int idx_cap, int tile_cap,
+                                                      TileDesc *__restrict__ desc)
 {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_masks) return;
-    const int off = hit_off[m];
-    int M = hit_off[m + 1] - off;
-    if (off + M > idx_cap) M = max(0, idx_cap - off);     // index capacity overflow: stay in bounds
-    const int t0 = tile_off[m], t1 = min(tile_off[m + 1], tile_cap);
-    for (int t = t0; t < t1; ++t) desc[t] = TileDesc{m, off, M, t - t0};
+    __shared__ int s_hist[MD_CLASSES], s_cur[MD_CLASSES];
+    if (threadIdx.x < MD_CLASSES) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int m = threadIdx.x; m < n_masks; m += 1024) {
+        const int t0 = tile_off[m], nt = max(0, min(tile_off[m + 1], tile_cap) - t0);
+        if (nt > 0) atomicAdd(&s_hist[min(nt, MD_CLASSES) - 1], nt);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = MD_CLASSES - 1; c >= 0; --c) { s_cur[c] = run; run += s_hist[c]; }
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < n_masks; m += 1024) {
+        const int t0 = tile_off[m], nt = max(0, min(tile_off[m + 1], tile_cap) - t0);
+        if (nt <= 0) continue;
+        const int off = hit_off[m];
+        int M = hit_off[m + 1] - off;
+        if (off + M > idx_cap) M = max(0, idx_cap - off);     // index capacity overflow: stay in bounds
+        const int pos = atomicAdd(&s_cur[min(nt, MD_CLASSES) - 1], nt);
+        for (int jt = 0; jt < nt; ++jt) desc[pos + jt] = TileDesc{m, off, M, jt, t0 + jt};
+    }
 }
 
 // squared distance of one staged row to this lane's column
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
             const int oj = __shfl_xor(bj, o, 64);
             if (better(os, oj, bs, bj)) { bs = os; bj = oj; }
         }
-        if (lane == 0) { tile_best[t].s = bs; tile_best[t].j = bj; }
+        if (lane == 0) { tile_best[d.t].s = bs; tile_best[d.t].j = bj; }
     }
 }
 
@@ -224,7 +243,7 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     const int tile_cap = (int)(tile_cap64 > 0x7FFFFFFF ? 0x7FFFFFFF : tile_cap64);
     TileDesc *desc = (TileDesc *)workspace;
     TileBest *best = (TileBest *)(desc + tile_cap);
-    hipLaunchKernelGGL(k_medoid_desc, dim3((n_masks + 255) / 256), dim3(256), 0, st, n_masks, hit_off, tile_off, idx_cap, tile_cap, desc);
+    hipLaunchKernelGGL(k_medoid_desc, dim3(1), dim3(1024), 0, st, n_masks, hit_off, tile_off, idx_cap, tile_cap, desc);
     CM3D_CHECK_LAUNCH();
     int grid = (tile_cap + MD_WAVES - 1) / MD_WAVES;
     int gmax = 4096;
