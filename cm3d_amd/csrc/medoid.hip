@@ -15,21 +15,30 @@
 
 #define MD_WAVES 4                       // waves per workgroup, one tile each
 #define MD_THREADS (MD_WAVES * 64)
+#define MD_STAGE 512                     // rows of a list staged in a wave's LDS slice at a time (8 KiB)
+
+typedef float f2 __attribute__((ext_vector_type(2)));      // two rows side by side: v_pk_{add,mul,fma}_f32
+typedef int i2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+#define PK_FMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
 
 // Correctly rounded float32 square root = sqrtf(), without the denormal pre-scaling hipcc emits around
-// v_sqrt_f32: v_sqrt_f32 is within 1 ulp, the two fma residuals pick the right neighbour (0 maps to 0).
-// Valid for x == 0 or 1e-30 <= x < 1e30; md_sqrt_ok() tells whether a value is in that domain, and the
-// caller falls back to sqrtf() for the whole wave when any lane is not (never on real coordinates).
-static __device__ __forceinline__ float md_sqrt_core(float x)
+// v_sqrt_f32, branch- and compare-free: v_sqrt_f32 is within 1 ulp; with s- / s+ its neighbours,
+//   t- = fma(s-, s, -x) >= 0  <=>  s- * s >= x  -> the root is nearer to s- than to s
+//   t+ = fma(s+, s, -x) <  0  <=>  s+ * s <  x  -> the root is nearer to s+ than to s
+// (an exact zero residual is +0 under round-to-nearest), so bits(result) = bits(s-) + sign(t-) + sign(t+).
+// Valid for 1e-30 <= x < 1e30 (md_sqrt_ok); the caller falls back to sqrtf() for the whole wave when any lane
+// is outside (zeros on the diagonal, never anything else on real coordinates).
+static __device__ __forceinline__ f2 md_sqrt_core2(f2 x)
 {
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float s_lo = __int_as_float(__float_as_int(s) - 1), s_hi = __int_as_float(__float_as_int(s) + 1);
-    const float r_lo = fmaf(-s_lo, s, x), r_hi = fmaf(-s_hi, s, x);
-    s = r_lo <= 0.0f ? s_lo : s;
-    s = r_hi > 0.0f ? s_hi : s;
-    return s;
+    const f2 s = {__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+    const i2 sb = __builtin_bit_cast(i2, s);
+    const i2 lo = sb - 1, hi = sb + 1;
+    const f2 t_lo = PK_FMA(__builtin_bit_cast(f2, lo), s, -x), t_hi = PK_FMA(__builtin_bit_cast(f2, hi), s, -x);
+    const u2 c = (__builtin_bit_cast(u2, t_lo) >> 31) + (__builtin_bit_cast(u2, t_hi) >> 31);
+    return __builtin_bit_cast(f2, lo + __builtin_bit_cast(i2, c));
 }
-static __device__ __forceinline__ bool md_sqrt_ok(float x) { return (x < 1.0e30f) & ((x >= 1.0e-30f) | (x == 0.0f)); }
+static __device__ __forceinline__ bool md_sqrt_ok(float x) { return (x < 1.0e30f) & (x >= 1.0e-30f); }
 
 struct TileBest { float s; int j; };
 struct TileDesc { int m, off, M, jt, t; };  // mask, start in hit_idx, list length, tile index inside the mask, tile id
@@ -38,83 +47,165 @@ struct TileDesc { int m, off, M, jt, t; };  // mask, start in hit_idx, list leng
 // (classes by tile count; a tile's cost is its list length), so that the waves which run longest start first and
 // the short ones fill in behind them.  Results are indexed by the tile id t = tile_off[m] + jt, not by the work
 // position, so the order has no influence on any output.  One workgroup.
-#define MD_CLASSES 8
+#define MD_CLASSES 8                     // class c < 7: exactly c + 1 tiles; class 7: 8 tiles or more
+#define MD_DESC_PER 8                    // masks per thread per round: all their loads are in flight together
+
+// tiles of the wave's lanes per class (wave-uniform values).  Lanes of a class below the last all carry the same
+// tile count, so a ballot and a popcount give the class sum without touching memory.
+static __device__ __forceinline__ void md_class_sums(int nt, int (&sum)[MD_CLASSES])
+{
+#pragma unroll
+    for (int c = 0; c < MD_CLASSES - 1; ++c) sum[c] += (int)__popcll(__ballot(nt == c + 1)) * (c + 1);
+    if (__ballot(nt >= MD_CLASSES)) sum[MD_CLASSES - 1] += cm3d_wave_sum(nt >= MD_CLASSES ? nt : 0);
+}
+
 __global__ __launch_bounds__(1024) void k_medoid_desc(int n_masks, const int32_t *__restrict__ hit_off,
                                                       const int32_t *__restrict__ tile_off, int idx_cap, int tile_cap,
                                                       TileDesc *__restrict__ desc)
 {
     __shared__ int s_hist[MD_CLASSES], s_cur[MD_CLASSES];
+    const int lane = cm3d_lane();
     if (threadIdx.x < MD_CLASSES) s_hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int m = threadIdx.x; m < n_masks; m += 1024) {
-        const int t0 = tile_off[m], nt = max(0, min(tile_off[m + 1], tile_cap) - t0);
-        if (nt > 0) atomicAdd(&s_hist[min(nt, MD_CLASSES) - 1], nt);
+    const bool one_round = n_masks <= 1024 * MD_DESC_PER;       // then a thread keeps its masks in registers
+    int t0[MD_DESC_PER], nt[MD_DESC_PER], off[MD_DESC_PER], M[MD_DESC_PER];
+    auto load_round = [&](int mb) {
+#pragma unroll
+        for (int q = 0; q < MD_DESC_PER; ++q) {
+            const int m = mb + q * 1024 + (int)threadIdx.x;
+            t0[q] = 0; nt[q] = 0; off[q] = 0; M[q] = 0;
+            if (m < n_masks) {
+                t0[q] = tile_off[m];
+                nt[q] = tile_off[m + 1];
+                off[q] = hit_off[m];
+                M[q] = hit_off[m + 1];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MD_DESC_PER; ++q) {
+            nt[q] = max(0, min(nt[q], tile_cap) - t0[q]);
+            M[q] -= off[q];
+            if (off[q] + M[q] > idx_cap) M[q] = max(0, idx_cap - off[q]);     // index capacity overflow: stay in bounds
+        }
+    };
+    // pass 1: tiles per class
+    int wsum[MD_CLASSES];
+#pragma unroll
+    for (int c = 0; c < MD_CLASSES; ++c) wsum[c] = 0;
+    for (int mb = 0; mb < n_masks; mb += 1024 * MD_DESC_PER) {
+        load_round(mb);
+#pragma unroll
+        for (int q = 0; q < MD_DESC_PER; ++q) md_class_sums(nt[q], wsum);
+    }
+    if (lane < MD_CLASSES) {
+        int mine = 0;
+#pragma unroll
+        for (int c = 0; c < MD_CLASSES; ++c) mine = lane == c ? wsum[c] : mine;
+        if (mine) atomicAdd(&s_hist[lane], mine);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
-        for (int c = MD_CLASSES - 1; c >= 0; --c) { s_cur[c] = run; run += s_hist[c]; }
+        for (int c = MD_CLASSES - 1; c >= 0; --c) { s_cur[c] = run; run += s_hist[c]; }     // longest lists first
     }
     __syncthreads();
-    for (int m = threadIdx.x; m < n_masks; m += 1024) {
-        const int t0 = tile_off[m], nt = max(0, min(tile_off[m + 1], tile_cap) - t0);
-        if (nt <= 0) continue;
-        const int off = hit_off[m];
-        int M = hit_off[m + 1] - off;
-        if (off + M > idx_cap) M = max(0, idx_cap - off);     // index capacity overflow: stay in bounds
-        const int pos = atomicAdd(&s_cur[min(nt, MD_CLASSES) - 1], nt);
-        for (int jt = 0; jt < nt; ++jt) desc[pos + jt] = TileDesc{m, off, M, jt, t0 + jt};
+    // pass 2: the wave reserves its share of every class with one atomic, positions inside it are ballot ranks
+    int wbase[MD_CLASSES];
+    {
+        int mine = 0;
+#pragma unroll
+        for (int c = 0; c < MD_CLASSES; ++c) mine = lane == c ? wsum[c] : mine;
+        int got = 0;
+        if (lane < MD_CLASSES && mine) got = atomicAdd(&s_cur[lane], mine);
+#pragma unroll
+        for (int c = 0; c < MD_CLASSES; ++c) wbase[c] = __builtin_amdgcn_readlane(got, c);
+    }
+    for (int mb = 0; mb < n_masks; mb += 1024 * MD_DESC_PER) {
+        if (!one_round) load_round(mb);
+#pragma unroll
+        for (int q = 0; q < MD_DESC_PER; ++q) {
+            int pos = 0;
+#pragma unroll
+            for (int c = 0; c < MD_CLASSES - 1; ++c) {
+                const uint64_t mk = __ballot(nt[q] == c + 1);
+                if (nt[q] == c + 1) pos = wbase[c] + cm3d_mbcnt(mk) * (c + 1);
+                wbase[c] += (int)__popcll(mk) * (c + 1);
+            }
+            if (__ballot(nt[q] >= MD_CLASSES)) {
+                const int v = nt[q] >= MD_CLASSES ? nt[q] : 0;
+                const int inc = cm3d_wave_incl_scan(v);
+                if (v) pos = wbase[MD_CLASSES - 1] + inc - v;
+                wbase[MD_CLASSES - 1] += __builtin_amdgcn_readlane(inc, 63);
+            }
+            if (nt[q] <= 0) continue;
+            const int m = mb + q * 1024 + (int)threadIdx.x;
+            for (int jt = 0; jt < nt[q]; ++jt) desc[pos + jt] = TileDesc{m, off[q], M[q], jt, t0[q] + jt};
+        }
     }
 }
 
-// squared distance of one staged row to this lane's column
-template <bool DIRECT>
-static __device__ __forceinline__ float md_pair(const float4 r, float qx, float qy, float qz, float qn)
+// LDS layout of a staged 64-row chunk: rows in pairs, component-major inside a pair, so that one ds_read_b128
+// delivers register pairs for packed math:  float4 A[p] = {x(2p), x(2p+1), y(2p), y(2p+1)},
+//                                           float4 B[p] = {z(2p), z(2p+1), w(2p), w(2p+1)}   at s4[2p], s4[2p+1].
+static __device__ __forceinline__ void md_stage(float4 *s4, int row, float4 r)
 {
+    float *f = (float *)s4 + (row >> 1) * 8 + (row & 1);
+    f[0] = r.x; f[2] = r.y; f[4] = r.z; f[6] = r.w;
+}
+
+// squared distances of the two rows of a pair to this lane's column
+template <bool DIRECT>
+static __device__ __forceinline__ f2 md_pair2(const float4 A, const float4 B, float qx, float qy, float qz, float qn)
+{
+    const f2 X = {A.x, A.y}, Y = {A.z, A.w}, Z = {B.x, B.y}, Wn = {B.z, B.w};
     if (DIRECT) {
-        float dd = fabsf(r.x - qx);
-        float agg = fmaf(dd, dd, 0.0f);
-        dd = fabsf(r.y - qy); agg = fmaf(dd, dd, agg);
-        dd = fabsf(r.z - qz); agg = fmaf(dd, dd, agg);
+        f2 dd = __builtin_elementwise_abs(X - qx);
+        f2 agg = PK_FMA(dd, dd, (f2)(0.0f));
+        dd = __builtin_elementwise_abs(Y - qy); agg = PK_FMA(dd, dd, agg);
+        dd = __builtin_elementwise_abs(Z - qz); agg = PK_FMA(dd, dd, agg);
         return agg;
     }
-    float acc = r.x * qx;                     // (-2 x_i) * x_j
-    acc = fmaf(r.y, qy, acc);
-    acc = fmaf(r.z, qz, acc);
-    acc = fmaf(r.w, 1.0f, acc);
-    acc = fmaf(1.0f, qn, acc);
+    f2 acc = X * qx;                          // (-2 x_i) * x_j
+    acc = PK_FMA(Y, (f2)(qy), acc);
+    acc = PK_FMA(Z, (f2)(qz), acc);
+    acc = acc + Wn;                           // fma(n_i, 1, acc)
+    acc = acc + qn;                           // fma(1, n_j, acc)
     // clamp_min_(0); the in-image test only lets finite points into a mask, so acc is never NaN
-    return fmaxf(acc, 0.0f);
+    return (f2){fmaxf(acc.x, 0.0f), fmaxf(acc.y, 0.0f)};
 }
 
 // adds the distances of `cnt` staged rows to s, in ascending row order.  8 rows per step: the distance chains
 // are independent (ILP, and the LDS reads of a step are issued together), only the adds into s are sequential
 // -- which is what fixes the float32 sum.
 template <bool DIRECT>
-static __device__ __forceinline__ float md_rows(const float4 *s_row, int cnt, float qx, float qy, float qz, float qn, float s)
+static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float qx, float qy, float qz, float qn, float s)
 {
-    constexpr int U = 8;
+    constexpr int U = 4;                      // pairs per step
     int ii = 0;
-    for (; ii + U <= cnt; ii += U) {
-        float d[U];
+    for (; ii + 2 * U <= cnt; ii += 2 * U) {
+        f2 d[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) d[u] = md_pair<DIRECT>(s_row[ii + u], qx, qy, qz, qn);
+        for (int u = 0; u < U; ++u) d[u] = md_pair2<DIRECT>(s4[ii + 2 * u], s4[ii + 2 * u + 1], qx, qy, qz, qn);
         // md_sqrt_core's domain, tested on the extremes (a 0 on the diagonal sends its step to sqrtf)
-        const float lo = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
-        const float hi = fmaxf(fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3])), fmaxf(fmaxf(d[4], d[5]), fmaxf(d[6], d[7])));
+        const float lo = fminf(fminf(fminf(d[0].x, d[0].y), fminf(d[1].x, d[1].y)), fminf(fminf(d[2].x, d[2].y), fminf(d[3].x, d[3].y)));
+        const float hi = fmaxf(fmaxf(fmaxf(d[0].x, d[0].y), fmaxf(d[1].x, d[1].y)), fmaxf(fmaxf(d[2].x, d[2].y), fmaxf(d[3].x, d[3].y)));
         if (__ballot(!(lo >= 1.0e-30f && hi < 1.0e30f))) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) d[u] = sqrtf(d[u]);
+            for (int u = 0; u < U; ++u) d[u] = (f2){sqrtf(d[u].x), sqrtf(d[u].y)};
         } else {
 #pragma unroll
-            for (int u = 0; u < U; ++u) d[u] = md_sqrt_core(d[u]);
+            for (int u = 0; u < U; ++u) d[u] = md_sqrt_core2(d[u]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) s = s + d[u];
+        for (int u = 0; u < U; ++u) { s = s + d[u].x; s = s + d[u].y; }
     }
-    for (; ii < cnt; ++ii) {
-        const float v = md_pair<DIRECT>(s_row[ii], qx, qy, qz, qn);
-        s = s + (__ballot(!md_sqrt_ok(v)) ? sqrtf(v) : md_sqrt_core(v));
+    for (; ii < cnt; ii += 2) {               // remaining pairs; the last one may hold a single row
+        const f2 d = md_pair2<DIRECT>(s4[ii], s4[ii + 1], qx, qy, qz, qn);
+        const bool two = ii + 1 < cnt;
+        const bool bad = !md_sqrt_ok(d.x) || (two && !md_sqrt_ok(d.y));
+        const f2 r = __ballot(bad) ? (f2){sqrtf(d.x), sqrtf(d.y)} : md_sqrt_core2((f2){d.x, two ? d.y : 1.0f});
+        s = s + r.x;
+        if (two) s = s + r.y;
     }
     return s;
 }
@@ -130,7 +221,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
                                                               TileBest *__restrict__ tile_best, int tile_cap,
                                                               float *__restrict__ colsum_opt)
 {
-    __shared__ float4 s_row_all[MD_WAVES][64];
+    __shared__ float4 s_row_all[MD_WAVES][MD_STAGE];
     const int wave = threadIdx.x >> 6, lane = cm3d_lane();
     float4 *s_row = s_row_all[wave];
     const int ntiles = min(tile_off[n_masks], tile_cap);
@@ -151,23 +242,29 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
         }
         float s = 0.f;
         const bool direct = M <= 25;
-        // rows are gathered one 64-row chunk ahead: the loads of chunk k+1 fly while chunk k is summed
-        float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < M) nxt = P[hit_row[off + lane]];
-        for (int i0 = 0; i0 < M; i0 += 64) {
-            __builtin_amdgcn_wave_barrier();
-            if (i0 + lane < M) {
-                float4 r = nxt;
-                r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
-                // the expansion branch only ever needs -2x, -2y, -2z of a row (exact products)
-                if (!direct) { r.x = -2.0f * r.x; r.y = -2.0f * r.y; r.z = -2.0f * r.z; }
-                s_row[lane] = r;
+        // Rows are staged MD_STAGE (512) at a time: all their index loads, then all their point gathers are in
+        // flight together (two memory latencies per 512 rows; a 64-row pipeline left the longest lists -- the
+        // waves the kernel waits for -- bound by one dependent gather per chunk).
+        for (int i0 = 0; i0 < M; i0 += MD_STAGE) {
+            __builtin_amdgcn_wave_barrier();                  // the previous rows' readers are done
+            float4 g[MD_STAGE / 64];
+#pragma unroll
+            for (int c = 0; c < MD_STAGE / 64; ++c)
+                if (i0 + c * 64 + lane < M) g[c] = P[hit_row[off + i0 + c * 64 + lane]];
+#pragma unroll
+            for (int c = 0; c < MD_STAGE / 64; ++c) {
+                if (i0 + c * 64 + lane < M) {
+                    float4 r = g[c];
+                    r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
+                    // the expansion branch only ever needs -2x, -2y, -2z of a row (exact products)
+                    if (!direct) { r.x = -2.0f * r.x; r.y = -2.0f * r.y; r.z = -2.0f * r.z; }
+                    md_stage(s_row, c * 64 + lane, r);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (i0 + 64 + lane < M) nxt = P[hit_row[off + i0 + 64 + lane]];
-            const int cnt = min(64, M - i0);
+            const int cnt = min(MD_STAGE, M - i0);
             s = direct ? md_rows<true>(s_row, cnt, qx, qy, qz, qn, s) : md_rows<false>(s_row, cnt, qx, qy, qz, qn, s);
         }
         if (act && colsum_opt) colsum_opt[off + j] = s;
