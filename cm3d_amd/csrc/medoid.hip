@@ -95,7 +95,10 @@ __global__ __launch_bounds__(1024) void k_medoid_desc(int n_masks, const int32_t
     for (int mb = 0; mb < n_masks; mb += 1024 * MD_DESC_PER) {
         load_round(mb);
 #pragma unroll
-        for (int q = 0; q < MD_DESC_PER; ++q) md_class_sums(nt[q], wsum);
+        for (int q = 0; q < MD_DESC_PER; ++q) {
+            if (mb + q * 1024 >= n_masks) break;                 // uniform: no mask in this slot for any thread
+            md_class_sums(nt[q], wsum);
+        }
     }
     if (lane < MD_CLASSES) {
         int mine = 0;
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(1024) void k_medoid_desc(int n_masks, const int32_t
         if (!one_round) load_round(mb);
 #pragma unroll
         for (int q = 0; q < MD_DESC_PER; ++q) {
+            if (mb + q * 1024 >= n_masks) break;                 // uniform
             int pos = 0;
 #pragma unroll
             for (int c = 0; c < MD_CLASSES - 1; ++c) {
