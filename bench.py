@@ -209,13 +209,20 @@ def main():
 
     # north_star's kernel: projection + in-mask gather (k_project_hits, one launch per pass)
     roofline = roof("k_project_hits", "project", r, "k_project_hits",
-                    "algorithmic bytes = 16 B/point + every bit-packed mask once + 4 B/point hit word; the kernel's "
-                    "bounding-box test lets it skip most mask bytes, so achieved can exceed what HBM would allow for a full read")
+                    "algorithmic bytes = 16 B/point + every bit-packed mask once + 4 B/point hit word (SURVEY 8d); the kernel's "
+                    "bounding-box test lets it skip most mask bytes, so `achieved` exceeds what HBM allows for a full read; "
+                    "traffic_rate = measured HBM bytes / time; the kernel is instruction-issue bound")
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
             roofline["traffic"] = tr.get(f"{args.config}_{main_mode}", {}).get("k_project_hits")
+            if roofline["traffic"]:
+                # what HBM actually moved per launch / time: the honest distance from the HBM roof (the kernel is
+                # bound by instruction issue; `frac` above is SURVEY 8(d)'s algorithmic figure)
+                rate = roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9
+                roofline["traffic_rate"] = round(rate, 1)
+                roofline["traffic_frac"] = round(rate / HBM_PEAK_GBS, 4)
         except (OSError, ValueError):
             pass
     mask_kernel = "k_erode_pack" if main_mode == "dense" else "k_rle_erode_pack"
