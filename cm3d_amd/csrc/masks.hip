@@ -9,11 +9,13 @@
 // A tile of packed rows (plus a one-word halo column on each side) lives in LDS; the erosion is
 // 9 word reads + shifts per output word; out-of-image neighbours count as set (cv2's border rule).
 #include "common.h"
+#include <cstdlib>
 
 #define EP_THREADS 256
 #define EP_MAX_WP 128          // supports W <= 4096
 #define EP_LDS_WORDS 8192      // dense kernel: at most 32 KiB of packed rows per workgroup (dynamic LDS)
-#define RLE_LDS_WORDS 8192     // RLE kernel: 32 KiB tiles (they are as narrow as the mask's rectangle)
+#define RLE_LDS_WORDS 4096     // RLE kernel: 16 KiB tiles (as narrow as the mask's rectangle).  The workgroups are latency-bound,
+                               // so residency counts: measured on C2 8 KiB 50 us, 16 KiB 45 us, 24 KiB 48 us, 32 KiB 59 us
 
 // one bit per non-zero byte of a 16-byte chunk -> 16 bits
 static __device__ __forceinline__ uint32_t pack16(uint4 v)
@@ -315,7 +317,8 @@ static __device__ __forceinline__ int rle_chunk_scan(const uint32_t *__restrict_
 // per tile.  Nothing outside the rectangle is written; the workgroup owns the mask's bbox (no global atomics).
 __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *__restrict__ cnts_all,
                                                                 const int32_t *__restrict__ rle_off, int W, int H, int Wp,
-                                                                uint32_t *__restrict__ packed, int32_t *__restrict__ bbox)
+                                                                int lds_words, uint32_t *__restrict__ packed,
+                                                                int32_t *__restrict__ bbox)
 {
     extern __shared__ __align__(16) uint32_t s_rows[];
     __shared__ int s_w[EP_THREADS / 64];
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
         return;
     }
     const int xw0 = s_rect[1] >> 5, wc = (min(s_rect[3], W - 1) >> 5) - xw0 + 1, lw = wc + 2;
-    int br = RLE_LDS_WORDS / lw - 2;            // output rows per tile
+    int br = lds_words / lw - 2;                // output rows per tile
     br = min(br, ry1 - ry0 + 1);
     const uint32_t pad = (W & 31) ? ~((1u << (W & 31)) - 1u) : 0u;
     // ---- tiles
@@ -467,10 +470,12 @@ extern "C" int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rl
     if (workspace_bytes < cm3d_rle_workspace_bytes(total_runs)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int Wp = (W + 31) / 32;
-    if (RLE_LDS_WORDS / (Wp + 2) - 2 < 1) return CM3D_ERR_ARG;  // tile height of a full-width mask
+    static int lds_words = 0;
+    if (!lds_words) { const char *e = getenv("CM3D_RLE_LDS_WORDS"); lds_words = e ? atoi(e) : RLE_LDS_WORDS; }
+    if (lds_words / (Wp + 2) - 2 < 1) return CM3D_ERR_ARG;      // tile height of a full-width mask
     (void)workspace;                                            // reserved (the run ends are not materialised)
-    hipLaunchKernelGGL(k_rle_erode_pack, dim3(n_masks), dim3(EP_THREADS), (size_t)RLE_LDS_WORDS * 4, st, rle_counts, rle_off, W, H, Wp,
-                       packed, bbox);
+    hipLaunchKernelGGL(k_rle_erode_pack, dim3(n_masks), dim3(EP_THREADS), (size_t)lds_words * 4, st, rle_counts, rle_off, W, H, Wp,
+                       lds_words, packed, bbox);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }
