@@ -437,6 +437,20 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
     const int p0 = pt_off[f], n = pt_off[f + 1] - p0;
     const int base = chunk * PH_BLOCK_PTS;
     if (base >= n) return;
+    const int m0 = mask_off[f];
+    const int nm = min(mask_off[f + 1] - m0, nm_cap);
+    const int planes = (nm + 31) >> 5;
+    const int wave = threadIdx.x >> 6, lane = cm3d_lane();
+    // the hit words and the block's output offsets of plane 0 are requested first: their latency overlaps the
+    // dropped-row bookkeeping below
+    const int run_first = lane < min(nm, 32) ? blk_base[((size_t)f * nblk_max + chunk) * nm_cap + lane] : 0;
+    int idx[PH_PT];
+    uint32_t w_first[PH_PT];
+#pragma unroll
+    for (int j = 0; j < PH_PT; ++j) {
+        idx[j] = base + ph_slot(j);
+        w_first[j] = idx[j] < n ? hit_words[(size_t)p0 + idx[j]] : 0u;
+    }
     // rows the sweep preparation dropped (ego box): the emitted index of a point is its row index minus the
     // number of dropped rows before it, i.e. its index in the reference's compacted cloud
     __shared__ uint32_t s_rm[PH_BLOCK_PTS / 32];      // dropped rows of this block, one bit per row
@@ -463,20 +477,13 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
         }
         __syncthreads();
     }
-    const int m0 = mask_off[f];
-    const int nm = min(mask_off[f + 1] - m0, nm_cap);
-    const int planes = (nm + 31) >> 5;
-    const int wave = threadIdx.x >> 6, lane = cm3d_lane();
     __shared__ int s_c[PH_THREADS / 64][32];
-    int idx[PH_PT];
-#pragma unroll
-    for (int j = 0; j < PH_PT; ++j) idx[j] = base + ph_slot(j);
     for (int plane = 0; plane < planes; ++plane) {
         const uint32_t *hw = hit_words + (size_t)plane * n_points_total + p0;
         uint32_t w[PH_PT];
         uint32_t any = 0;
 #pragma unroll
-        for (int j = 0; j < PH_PT; ++j) { w[j] = idx[j] < n ? hw[idx[j]] : 0u; any |= w[j]; }
+        for (int j = 0; j < PH_PT; ++j) { w[j] = plane == 0 ? w_first[j] : (idx[j] < n ? hw[idx[j]] : 0u); any |= w[j]; }
         const uint32_t orw = cm3d_wave_or(any);
         int mycnt = 0;                         // lane b < 32: hits of mask bit b in this wave's 256 points
         for (uint32_t r = orw; r; r &= r - 1) {
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
             int run = 0;
             if (lane < 32) {
                 const int k = plane * 32 + lane;
-                run = k < nm ? blk_base[((size_t)f * nblk_max + chunk) * nm_cap + k] : 0;
+                run = plane == 0 ? run_first : (k < nm ? blk_base[((size_t)f * nblk_max + chunk) * nm_cap + k] : 0);
                 for (int w2 = 0; w2 < wave; ++w2) run += s_c[w2][lane];
             }
             for (uint32_t r = orw; r; r &= r - 1) {
