@@ -77,6 +77,32 @@ def cpu_baseline(frames, lanes, frame_lane, hb, n_sample):
             "sample": f"first {n_sample} frames of the same synthetic batch, {dt:.1f} s, host has {os.cpu_count()} cores ({cpu_model})"}
 
 
+def cpu_baseline_all_cores(config_name, set_args, lane_points, workers, frames_per_worker):
+    """The same oracle, one process per core over disjoint frames (frames are independent); aggregate rate =
+    frames / slowest worker's oracle time.  SURVEY 8(d) asks for the all-cores figure beside the 1-thread one.
+    The workers are plain child processes (oracle/cpu_worker.py); they never touch the GPU."""
+    import subprocess
+    procs = []
+    for w in range(workers):
+        cmd = [sys.executable, "-m", "oracle.cpu_worker", config_name, str(100000 + w * frames_per_worker), str(frames_per_worker),
+               str(lane_points)] + list(set_args)
+        procs.append(subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+    res = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            raise
+        if pr.returncode != 0:
+            raise RuntimeError(f"cpu worker exited with {pr.returncode}")
+        res.append(json.loads(out.strip().splitlines()[-1]))
+    n = sum(r["frames"] for r in res)
+    dt = max(r["seconds"] for r in res)
+    return {"value": n / dt, "unit": "frames/s", "cores": workers, "kind": "port",
+            "sample": f"{workers} processes x {frames_per_worker} frames of the same synthetic workload, slowest {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +115,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=48, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--lane-points", type=int, default=50000)
     ap.add_argument("--no-secondary", action="store_true", help="skip the second mask mode")
+    ap.add_argument("--cpu-workers", type=int, default=16,
+                    help="processes of the all-cores CPU baseline (0 = skip; capped at the visible cores)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override a field of the synthetic config (e.g. --set n_masks=80); for experiments")
     args = ap.parse_args()
@@ -252,6 +280,13 @@ def main():
         out[f"stage_ms_{mode}_masks"] = {k: round(v, 4) for k, v in o["stage_ms"].items()}
     if world == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(frames, lanes, frame_lane, hb, args.cpu_sample)
+        workers = min(args.cpu_workers, os.cpu_count() or 1)
+        if workers > 1:
+            try:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.config, args.set, args.lane_points, workers,
+                                                                       max(8, args.cpu_sample // 4))
+            except Exception as exc:        # a reported extra: never let it break the bench line
+                out["cpu_baseline_all_cores"] = {"error": repr(exc)}
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
