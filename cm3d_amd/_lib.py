@@ -33,9 +33,10 @@ SIGNATURES = {
     "cm3d_project_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "cm3d_project_hits": (_i32, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32,
                                  _p, _p, _p, _p, _i64, _p]),
-    "cm3d_compact_hits": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i64, _p]),
+    "cm3d_compact_hits": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _i64, _p]),
+    "cm3d_tile_work_bytes": (_i64, [_i32, _i32]),
     "cm3d_medoid_workspace_bytes": (_i64, [_i32, _i32]),
-    "cm3d_medoid": (_i32, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _i64, _p]),
+    "cm3d_medoid": (_i32, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _p]),
     "cm3d_lane_grid_bytes": (_i64, [_i32, _i32]),
     "cm3d_lane_grid_build": (_i32, [_p, _p, _i32, _i32, _p, _i64, _p]),
     "cm3d_lane_nn_workspace_bytes": (_i64, [_i32]),

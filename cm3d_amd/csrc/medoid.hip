@@ -11,6 +11,7 @@
 // staged through LDS 64 at a time and read back as wave-wide broadcasts.  VALU-bound
 // (about 20 ops per pair incl. the IEEE sqrt); nothing M x M ever touches HBM.
 #include "common.h"
+#include "worklist.h"
 #include <stdlib.h>
 
 #define MD_WAVES 4                       // waves per workgroup, one tile each
@@ -41,111 +42,12 @@ static __device__ __forceinline__ f2 md_sqrt_core2(f2 x)
 static __device__ __forceinline__ bool md_sqrt_ok(float x) { return (x < 1.0e30f) & (x >= 1.0e-30f); }
 
 struct TileBest { float s; int j; };
-struct TileDesc { int m, off, M, jt, t; };  // mask, start in hit_idx, list length, tile index inside the mask, tile id
-
-// One descriptor per 64-column tile of every index list, written in WORK order: tiles of the longest lists first
-// (classes by tile count; a tile's cost is its list length), so that the waves which run longest start first and
-// the short ones fill in behind them.  Results are indexed by the tile id t = tile_off[m] + jt, not by the work
-// position, so the order has no influence on any output.  One workgroup.
-#define MD_CLASSES 8                     // class c < 7: exactly c + 1 tiles; class 7: 8 tiles or more
-#define MD_DESC_PER 8                    // masks per thread per round: all their loads are in flight together
-
-// tiles of the wave's lanes per class (wave-uniform values).  Lanes of a class below the last all carry the same
-// tile count, so a ballot and a popcount give the class sum without touching memory.
-static __device__ __forceinline__ void md_class_sums(int nt, int (&sum)[MD_CLASSES])
-{
-#pragma unroll
-    for (int c = 0; c < MD_CLASSES - 1; ++c) sum[c] += (int)__popcll(__ballot(nt == c + 1)) * (c + 1);
-    if (__ballot(nt >= MD_CLASSES)) sum[MD_CLASSES - 1] += cm3d_wave_sum(nt >= MD_CLASSES ? nt : 0);
-}
-
 __global__ __launch_bounds__(1024) void k_medoid_desc(int n_masks, const int32_t *__restrict__ hit_off,
                                                       const int32_t *__restrict__ tile_off, int idx_cap, int tile_cap,
                                                       TileDesc *__restrict__ desc)
 {
     __shared__ int s_hist[MD_CLASSES], s_cur[MD_CLASSES];
-    const int lane = cm3d_lane();
-    if (threadIdx.x < MD_CLASSES) s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    const bool one_round = n_masks <= 1024 * MD_DESC_PER;       // then a thread keeps its masks in registers
-    int t0[MD_DESC_PER], nt[MD_DESC_PER], off[MD_DESC_PER], M[MD_DESC_PER];
-    auto load_round = [&](int mb) {
-#pragma unroll
-        for (int q = 0; q < MD_DESC_PER; ++q) {
-            const int m = mb + q * 1024 + (int)threadIdx.x;
-            t0[q] = 0; nt[q] = 0; off[q] = 0; M[q] = 0;
-            if (m < n_masks) {
-                t0[q] = tile_off[m];
-                nt[q] = tile_off[m + 1];
-                off[q] = hit_off[m];
-                M[q] = hit_off[m + 1];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < MD_DESC_PER; ++q) {
-            nt[q] = max(0, min(nt[q], tile_cap) - t0[q]);
-            M[q] -= off[q];
-            if (off[q] + M[q] > idx_cap) M[q] = max(0, idx_cap - off[q]);     // index capacity overflow: stay in bounds
-        }
-    };
-    // pass 1: tiles per class
-    int wsum[MD_CLASSES];
-#pragma unroll
-    for (int c = 0; c < MD_CLASSES; ++c) wsum[c] = 0;
-    for (int mb = 0; mb < n_masks; mb += 1024 * MD_DESC_PER) {
-        load_round(mb);
-#pragma unroll
-        for (int q = 0; q < MD_DESC_PER; ++q) {
-            if (mb + q * 1024 >= n_masks) break;                 // uniform: no mask in this slot for any thread
-            md_class_sums(nt[q], wsum);
-        }
-    }
-    if (lane < MD_CLASSES) {
-        int mine = 0;
-#pragma unroll
-        for (int c = 0; c < MD_CLASSES; ++c) mine = lane == c ? wsum[c] : mine;
-        if (mine) atomicAdd(&s_hist[lane], mine);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int c = MD_CLASSES - 1; c >= 0; --c) { s_cur[c] = run; run += s_hist[c]; }     // longest lists first
-    }
-    __syncthreads();
-    // pass 2: the wave reserves its share of every class with one atomic, positions inside it are ballot ranks
-    int wbase[MD_CLASSES];
-    {
-        int mine = 0;
-#pragma unroll
-        for (int c = 0; c < MD_CLASSES; ++c) mine = lane == c ? wsum[c] : mine;
-        int got = 0;
-        if (lane < MD_CLASSES && mine) got = atomicAdd(&s_cur[lane], mine);
-#pragma unroll
-        for (int c = 0; c < MD_CLASSES; ++c) wbase[c] = __builtin_amdgcn_readlane(got, c);
-    }
-    for (int mb = 0; mb < n_masks; mb += 1024 * MD_DESC_PER) {
-        if (!one_round) load_round(mb);
-#pragma unroll
-        for (int q = 0; q < MD_DESC_PER; ++q) {
-            if (mb + q * 1024 >= n_masks) break;                 // uniform
-            int pos = 0;
-#pragma unroll
-            for (int c = 0; c < MD_CLASSES - 1; ++c) {
-                const uint64_t mk = __ballot(nt[q] == c + 1);
-                if (nt[q] == c + 1) pos = wbase[c] + cm3d_mbcnt(mk) * (c + 1);
-                wbase[c] += (int)__popcll(mk) * (c + 1);
-            }
-            if (__ballot(nt[q] >= MD_CLASSES)) {
-                const int v = nt[q] >= MD_CLASSES ? nt[q] : 0;
-                const int inc = cm3d_wave_incl_scan(v);
-                if (v) pos = wbase[MD_CLASSES - 1] + inc - v;
-                wbase[MD_CLASSES - 1] += __builtin_amdgcn_readlane(inc, 63);
-            }
-            if (nt[q] <= 0) continue;
-            const int m = mb + q * 1024 + (int)threadIdx.x;
-            for (int jt = 0; jt < nt[q]; ++jt) desc[pos + jt] = TileDesc{m, off[q], M[q], jt, t0[q] + jt};
-        }
-    }
+    md_build_worklist<1024>(n_masks, hit_off, tile_off, idx_cap, tile_cap, desc, s_hist, s_cur);
 }
 
 // LDS layout of a staged 64-row chunk: rows in pairs, component-major inside a pair, so that one ds_read_b128
@@ -319,9 +221,10 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
     centroid[3 * m + 0] = cx; centroid[3 * m + 1] = cy; centroid[3 * m + 2] = cz;
 }
 
-static inline int64_t md_tile_cap(int32_t n_masks, int32_t idx_cap)
+extern "C" int64_t cm3d_tile_work_bytes(int32_t n_masks, int32_t idx_cap)
 {
-    return (int64_t)n_masks + (int64_t)idx_cap / CM3D_MEDOID_TILE + 1;
+    if (n_masks <= 0 || idx_cap <= 0) return 0;
+    return md_tile_cap(n_masks, idx_cap) * (int64_t)sizeof(TileDesc);
 }
 
 extern "C" int64_t cm3d_medoid_workspace_bytes(int32_t n_masks, int32_t idx_cap)
@@ -332,7 +235,7 @@ extern "C" int64_t cm3d_medoid_workspace_bytes(int32_t n_masks, int32_t idx_cap)
 
 extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_frame, int32_t n_masks,
                            const int32_t *hit_off, const int32_t *tile_off, const int32_t *hit_row, int32_t idx_cap,
-                           int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
+                           const int32_t *tile_work, int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
                            int64_t workspace_bytes, cm3d_stream_t stream)
 {
     if (!points || !pt_off || !mask_frame || !hit_off || !tile_off || !hit_row || !medoid_pos || !centroid || !workspace)
@@ -342,10 +245,14 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     hipStream_t st = (hipStream_t)stream;
     const int64_t tile_cap64 = md_tile_cap(n_masks, idx_cap);
     const int tile_cap = (int)(tile_cap64 > 0x7FFFFFFF ? 0x7FFFFFFF : tile_cap64);
-    TileDesc *desc = (TileDesc *)workspace;
-    TileBest *best = (TileBest *)(desc + tile_cap);
-    hipLaunchKernelGGL(k_medoid_desc, dim3(1), dim3(1024), 0, st, n_masks, hit_off, tile_off, idx_cap, tile_cap, desc);
-    CM3D_CHECK_LAUNCH();
+    TileDesc *own = (TileDesc *)workspace;
+    TileBest *best = (TileBest *)(own + tile_cap);
+    const TileDesc *desc = (const TileDesc *)tile_work;
+    if (!desc) {                                   // no work list from cm3d_compact_hits: build it here
+        hipLaunchKernelGGL(k_medoid_desc, dim3(1), dim3(1024), 0, st, n_masks, hit_off, tile_off, idx_cap, tile_cap, own);
+        CM3D_CHECK_LAUNCH();
+        desc = own;
+    }
     int grid = (tile_cap + MD_WAVES - 1) / MD_WAVES;
     int gmax = 4096;
     if (const char *e = getenv("CM3D_MD_GRID")) gmax = atoi(e);

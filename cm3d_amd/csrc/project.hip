@@ -10,6 +10,7 @@
 // lists with wave ballot + mbcnt prefixes (no atomics on the output order, deterministic).
 // HBM-bound: algorithmic bytes = 16 N + n*ceil(W*H/8) + 4*sum(M) + 4(n+1) per frame.
 #include "common.h"
+#include "worklist.h"
 #include <cstdlib>
 
 #define PH_THREADS 256
@@ -273,9 +274,9 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             else if (ns == 3 && fl == 10) project_quad<3, 10>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);   // KITTI
             else project_quad<-1, 0>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);
             if (!__ballot((px[0] & px[1] & px[2] & px[3]) >= 0)) continue;      // no point of the wave in this image
-            int iu[PH_PT], iv[PH_PT];
-#pragma unroll
-            for (int j = 0; j < PH_PT; ++j) { iu[j] = px[j] & 0xFFFF; iv[j] = px[j] >> 16; }    // px = -1: iv = -1
+            // px = iv << 16 | iu; px = -1 gives iv = -1
+#define PX_IU(j) (px[j] & 0xFFFF)
+#define PX_IV(j) (px[j] >> 16)
             // the masks of this camera, PH_MB at a time: all bounding boxes, then all mask words of the batch are
             // requested before the first one is used (one memory round trip per batch instead of one per mask)
             for (int pl = 0; pl < planes; ++pl) {
@@ -302,8 +303,8 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
 #pragma unroll
                         for (int j = 0; j < PH_PT; ++j) {
                             // iv = -1 < y0 fails the unsigned range test by itself
-                            const bool cand = ((unsigned)(iu[j] - x0) <= (unsigned)rx) & ((unsigned)(iv[j] - y0) <= (unsigned)ry);
-                            if (cand) word[b][j] = mw[(size_t)iv[j] * Wp + (iu[j] >> 5)];
+                            const bool cand = ((unsigned)(PX_IU(j) - x0) <= (unsigned)rx) & ((unsigned)(PX_IV(j) - y0) <= (unsigned)ry);
+                            if (cand) word[b][j] = mw[(size_t)PX_IV(j) * Wp + (PX_IU(j) >> 5)];
                         }
                     }
 #pragma unroll
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                         int cnt = 0;
 #pragma unroll
                         for (int j = 0; j < PH_PT; ++j) {
-                            const bool hit = (word[b][j] >> (iu[j] & 31)) & 1u;          // word = 0 for a non-candidate
+                            const bool hit = (word[b][j] >> (px[j] & 31)) & 1u;          // word = 0 for a non-candidate
                             if (ONE_PLANE) bits[j] |= (hit ? 1u : 0u) << kb[b];
                             else if (hit) s_bits[pl * PH_BLOCK_PTS + ph_slot(j)] |= 1u << kb[b];
                             cnt += __popcll(__ballot(hit));
@@ -431,9 +432,21 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
                                                              const int32_t *__restrict__ blk_base,
                                                              const int32_t *__restrict__ removed_cnt,
                                                              const int32_t *__restrict__ removed_idx,
-                                                             int32_t *__restrict__ hit_idx, int32_t *__restrict__ hit_row, int idx_cap)
+                                                             int32_t *__restrict__ hit_idx, int32_t *__restrict__ hit_row, int idx_cap,
+                                                             int n_frames, int n_masks, const int32_t *__restrict__ hit_off,
+                                                             const int32_t *__restrict__ tile_off, int tile_cap,
+                                                             TileDesc *__restrict__ tile_work)
 {
-    const int f = blockIdx.y, chunk = blockIdx.x;
+    const int row0 = tile_work ? 1 : 0;
+    if (tile_work && blockIdx.y == 0) {
+        // extra row of the grid, dispatched first: one workgroup builds the medoid stage's work list from the
+        // offsets the previous launch wrote, beside (and hidden under) the compaction of the hit words
+        __shared__ int s_hist[MD_CLASSES], s_cur[MD_CLASSES];
+        if (blockIdx.x == 0)
+            md_build_worklist<PH_THREADS>(n_masks, hit_off, tile_off, idx_cap, tile_cap, tile_work, s_hist, s_cur);
+        return;
+    }
+    const int f = (int)blockIdx.y - row0, chunk = blockIdx.x;
     const int p0 = pt_off[f], n = pt_off[f + 1] - p0;
     const int base = chunk * PH_BLOCK_PTS;
     if (base >= n) return;
@@ -617,7 +630,8 @@ extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, cons
                                  int32_t max_pts_per_frame, int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
                                  const int32_t *hit_count, const int32_t *removed_cnt, const int32_t *removed_idx,
                                  int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx, int32_t *hit_row, int32_t idx_cap,
-                                 int32_t *status, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream)
+                                 int32_t *tile_work, int32_t *status, void *workspace, int64_t workspace_bytes,
+                                 cm3d_stream_t stream)
 {
     if (!hit_words || !pt_off || !mask_off || !hit_count || !hit_off || !tile_off || !hit_idx || !hit_row || !status || !workspace)
         return CM3D_ERR_ARG;
@@ -631,8 +645,11 @@ extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, cons
     hipLaunchKernelGGL(k_hit_offsets, dim3(n_frames), dim3(1024), 0, st, hit_count, n_masks, pt_off, mask_off, n_frames, nm_cap,
                        nblk_max, hit_off, tile_off, (int32_t *)workspace, idx_cap, status);
     CM3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_compact_hits, dim3(nblk_max, n_frames), dim3(PH_THREADS), 0, st, hit_words, n_points_total, pt_off, mask_off,
-                       nm_cap, nblk_max, (const int32_t *)workspace, removed_cnt, removed_idx, hit_idx, hit_row, idx_cap);
+    const int64_t tile_cap64 = md_tile_cap(n_masks, idx_cap);
+    const int tile_cap = (int)(tile_cap64 > 0x7FFFFFFF ? 0x7FFFFFFF : tile_cap64);
+    hipLaunchKernelGGL(k_compact_hits, dim3(nblk_max, n_frames + (tile_work ? 1 : 0)), dim3(PH_THREADS), 0, st, hit_words,
+                       n_points_total, pt_off, mask_off, nm_cap, nblk_max, (const int32_t *)workspace, removed_cnt, removed_idx, hit_idx,
+                       hit_row, idx_cap, n_frames, n_masks, hit_off, tile_off, tile_cap, (TileDesc *)tile_work);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

@@ -278,6 +278,7 @@ class LiftEngine:
         b.lane_idx = e(M); b.lane_dist = e(M, dtype=torch.float64)
         b.box = e(M, _lib.BOX_STRIDE, dtype=torch.float64); b.flags = e(M)
         L = self.lib
+        b.tile_work = torch.empty(int(L.cm3d_tile_work_bytes(M, b.idx_cap)), dtype=torch.uint8, device=d)
         ws = max(L.cm3d_rle_workspace_bytes(max(1, hb.rle_counts.size)),
                  L.cm3d_medoid_workspace_bytes(M, b.idx_cap),
                  L.cm3d_lane_nn_workspace_bytes(M))
@@ -363,13 +364,14 @@ class LiftEngine:
         b = self.b
         check(self.lib.cm3d_compact_hits(_ptr(b.hit_words), b.planes, _ptr(b.pt_off), b.F, b.max_pts, b.pt_cap, _ptr(b.mask_off),
                                          b.M, _ptr(b.hit_count), _ptr(b.removed_cnt), _ptr(b.removed_idx), _ptr(b.hit_off),
-                                         _ptr(b.tile_off), _ptr(b.hit_idx), _ptr(b.hit_row), b.idx_cap, _ptr(b.status), _ptr(b.pg_ws),
+                                         _ptr(b.tile_off), _ptr(b.hit_idx), _ptr(b.hit_row), b.idx_cap, _ptr(b.tile_work), _ptr(b.status),
+                                         _ptr(b.pg_ws),
                                          b.pg_ws_bytes, st), "cm3d_compact_hits")
 
     def stage_medoid(self, st):
         b = self.b
         check(self.lib.cm3d_medoid(_ptr(b.points), _ptr(b.pt_off), _ptr(b.mask_frame), b.M, _ptr(b.hit_off), _ptr(b.tile_off),
-                                   _ptr(b.hit_row), b.idx_cap, _ptr(b.medoid_pos), _ptr(b.centroid), _ptr(b.colsum),
+                                   _ptr(b.hit_row), b.idx_cap, _ptr(b.tile_work), _ptr(b.medoid_pos), _ptr(b.centroid), _ptr(b.colsum),
                                    _ptr(b.ws), b.ws_bytes, st), "cm3d_medoid")
 
     def stage_lane_grid(self, st):

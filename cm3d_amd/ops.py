@@ -116,7 +116,7 @@ def points_in_masks(points, cams, packed, bbox, cam_nums, W, H, min_dist=2.3):
                               hit_words.data_ptr(), hit_count.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), st),
           "cm3d_project_hits")
     check(L.cm3d_compact_hits(hit_words.data_ptr(), planes, pt_off.data_ptr(), 1, N, N, mask_off.data_ptr(), n, hit_count.data_ptr(),
-                              0, 0, hit_off.data_ptr(), tile_off.data_ptr(), hit_idx.data_ptr(), hit_row.data_ptr(), cap,
+                              0, 0, hit_off.data_ptr(), tile_off.data_ptr(), hit_idx.data_ptr(), hit_row.data_ptr(), cap, 0,
                               status.data_ptr(), ws.data_ptr(), ws.numel(), st), "cm3d_compact_hits")
     s = status.cpu().numpy()
     if s[0]:
@@ -143,7 +143,7 @@ def get_medoid(points, want_colsum=False):
     colsum = _e(max(M, 1), dtype=torch.float32)
     ws = _ws(L.cm3d_medoid_workspace_bytes(1, max(M, 1)))
     check(L.cm3d_medoid(pts.data_ptr(), pt_off.data_ptr(), mask_frame.data_ptr(), 1, hit_off.data_ptr(), tile_off.data_ptr(),
-                        hit_idx.data_ptr(), max(M, 1), med.data_ptr(), cen.data_ptr(), colsum.data_ptr(), ws.data_ptr(), ws.numel(),
+                        hit_idx.data_ptr(), max(M, 1), 0, med.data_ptr(), cen.data_ptr(), colsum.data_ptr(), ws.data_ptr(), ws.numel(),
                         _st()), "cm3d_medoid")
     j = int(med.cpu()[0])
     return (j, colsum.cpu().numpy()[:M]) if want_colsum else j

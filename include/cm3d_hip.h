@@ -143,25 +143,30 @@ int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_fram
  *  hit_idx  int32[idx_cap]   OUT ascending point indices of mask m at [hit_off[m], hit_off[m+1]): indices into the
  *                                frame's cloud WITHOUT the dropped rows, i.e. the reference's track_points
  *  hit_row  int32[idx_cap]   OUT the same points as frame-local row indices into `points` (for gathers)
+ *  tile_work OUT, optional (may be NULL): cm3d_tile_work_bytes(n_masks, idx_cap) bytes; the work list of
+ *            cm3d_medoid (one record per medoid tile, longest lists first), built beside the compaction
  *  workspace: the buffer cm3d_project_hits filled */
 int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, const int32_t *pt_off, int32_t n_frames,
                       int32_t max_pts_per_frame, int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
                       const int32_t *hit_count, const int32_t *removed_cnt, const int32_t *removed_idx,
                       int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx, int32_t *hit_row, int32_t idx_cap,
-                      int32_t *status, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream);
+                      int32_t *tile_work, int32_t *status, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream);
+int64_t cm3d_tile_work_bytes(int32_t n_masks, int32_t idx_cap);
 
 /* ---- a9: medoid --------------------------------------------------------------
  * Replaces get_medoid (2d_to_3d.py:116-119) + the gather at :620,645-647:
  * argmin_j sum_i cdist(P,P)[i][j] with torch.cdist's float32 arithmetic (direct form
  * for <=25 points, matmul expansion otherwise), rows summed in ascending i, first minimum.
  *  hit_row    the row-index list of cm3d_compact_hits (gathers go through it)
+ *  tile_work  the work list cm3d_compact_hits wrote for the same hit_off / tile_off, or NULL (then it is built here,
+ *             one more launch)
  *  medoid_pos int32[n_masks]    OUT position in the mask's index list (-1 if the list is empty)
  *  centroid   float[n_masks][3] OUT global-frame xyz of the medoid point
  *  workspace: cm3d_medoid_workspace_bytes(n_masks, idx_cap) */
 int64_t cm3d_medoid_workspace_bytes(int32_t n_masks, int32_t idx_cap);
 int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_frame, int32_t n_masks,
                 const int32_t *hit_off, const int32_t *tile_off, const int32_t *hit_row, int32_t idx_cap,
-                int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
+                const int32_t *tile_work, int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
                 int64_t workspace_bytes, cm3d_stream_t stream);
 
 /* ---- a10: nearest lane point --------------------------------------------------
