@@ -1,0 +1,118 @@
+// Work list of the medoid stage (a9): one descriptor per 64-column tile of every index list.
+// Shared by medoid.hip (stand-alone builder) and project.hip (built beside the compaction, see k_compact_hits).
+#pragma once
+#include "common.h"
+
+struct TileDesc { int m, off, M, jt, t; };  // mask, start in hit_idx, list length, tile index inside the mask, tile id
+
+// One descriptor per 64-column tile of every index list, written in WORK order: tiles of the longest lists first
+// (classes by tile count; a tile's cost is its list length), so that the waves which run longest start first and
+// the short ones fill in behind them.  Results are indexed by the tile id t = tile_off[m] + jt, not by the work
+// position, so the order has no influence on any output.  One workgroup of NT threads.
+#define MD_CLASSES 8                     // class c < 7: exactly c + 1 tiles; class 7: 8 tiles or more
+#define MD_DESC_PER 8                    // masks per thread per round: all their loads are in flight together
+
+// tiles of the wave's lanes per class (wave-uniform values).  Lanes of a class below the last all carry the same
+// tile count, so a ballot and a popcount give the class sum without touching memory.
+static __device__ __forceinline__ void md_class_sums(int nt, int (&sum)[MD_CLASSES])
+{
+#pragma unroll
+    for (int c = 0; c < MD_CLASSES - 1; ++c) sum[c] += (int)__popcll(__ballot(nt == c + 1)) * (c + 1);
+    if (__ballot(nt >= MD_CLASSES)) sum[MD_CLASSES - 1] += cm3d_wave_sum(nt >= MD_CLASSES ? nt : 0);
+}
+
+// tile capacity of a batch: every mask may end with a partial tile
+static inline int64_t md_tile_cap(int32_t n_masks, int32_t idx_cap)
+{
+    return (int64_t)n_masks + (int64_t)idx_cap / CM3D_MEDOID_TILE + 1;
+}
+
+// s_hist / s_cur: MD_CLASSES ints of LDS each.  Contains workgroup barriers: call with all NT threads.
+template <int NT>
+static __device__ __forceinline__ void md_build_worklist(int n_masks, const int32_t *__restrict__ hit_off,
+                                                         const int32_t *__restrict__ tile_off, int idx_cap, int tile_cap,
+                                                         TileDesc *__restrict__ desc, int *s_hist, int *s_cur)
+{
+    const int lane = cm3d_lane();
+    if (threadIdx.x < MD_CLASSES) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const bool one_round = n_masks <= NT * MD_DESC_PER;       // then a thread keeps its masks in registers
+    int t0[MD_DESC_PER], nt[MD_DESC_PER], off[MD_DESC_PER], M[MD_DESC_PER];
+    auto load_round = [&](int mb) {
+#pragma unroll
+        for (int q = 0; q < MD_DESC_PER; ++q) {
+            const int m = mb + q * NT + (int)threadIdx.x;
+            t0[q] = 0; nt[q] = 0; off[q] = 0; M[q] = 0;
+            if (m < n_masks) {
+                t0[q] = tile_off[m];
+                nt[q] = tile_off[m + 1];
+                off[q] = hit_off[m];
+                M[q] = hit_off[m + 1];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MD_DESC_PER; ++q) {
+            nt[q] = max(0, min(nt[q], tile_cap) - t0[q]);
+            M[q] -= off[q];
+            if (off[q] + M[q] > idx_cap) M[q] = max(0, idx_cap - off[q]);     // index capacity overflow: stay in bounds
+        }
+    };
+    // pass 1: tiles per class
+    int wsum[MD_CLASSES];
+#pragma unroll
+    for (int c = 0; c < MD_CLASSES; ++c) wsum[c] = 0;
+    for (int mb = 0; mb < n_masks; mb += NT * MD_DESC_PER) {
+        load_round(mb);
+#pragma unroll
+        for (int q = 0; q < MD_DESC_PER; ++q) {
+            if (mb + q * NT >= n_masks) break;                 // uniform: no mask in this slot for any thread
+            md_class_sums(nt[q], wsum);
+        }
+    }
+    if (lane < MD_CLASSES) {
+        int mine = 0;
+#pragma unroll
+        for (int c = 0; c < MD_CLASSES; ++c) mine = lane == c ? wsum[c] : mine;
+        if (mine) atomicAdd(&s_hist[lane], mine);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = MD_CLASSES - 1; c >= 0; --c) { s_cur[c] = run; run += s_hist[c]; }     // longest lists first
+    }
+    __syncthreads();
+    // pass 2: the wave reserves its share of every class with one atomic, positions inside it are ballot ranks
+    int wbase[MD_CLASSES];
+    {
+        int mine = 0;
+#pragma unroll
+        for (int c = 0; c < MD_CLASSES; ++c) mine = lane == c ? wsum[c] : mine;
+        int got = 0;
+        if (lane < MD_CLASSES && mine) got = atomicAdd(&s_cur[lane], mine);
+#pragma unroll
+        for (int c = 0; c < MD_CLASSES; ++c) wbase[c] = __builtin_amdgcn_readlane(got, c);
+    }
+    for (int mb = 0; mb < n_masks; mb += NT * MD_DESC_PER) {
+        if (!one_round) load_round(mb);
+#pragma unroll
+        for (int q = 0; q < MD_DESC_PER; ++q) {
+            if (mb + q * NT >= n_masks) break;                 // uniform
+            int pos = 0;
+#pragma unroll
+            for (int c = 0; c < MD_CLASSES - 1; ++c) {
+                const uint64_t mk = __ballot(nt[q] == c + 1);
+                if (nt[q] == c + 1) pos = wbase[c] + cm3d_mbcnt(mk) * (c + 1);
+                wbase[c] += (int)__popcll(mk) * (c + 1);
+            }
+            if (__ballot(nt[q] >= MD_CLASSES)) {
+                const int v = nt[q] >= MD_CLASSES ? nt[q] : 0;
+                const int inc = cm3d_wave_incl_scan(v);
+                if (v) pos = wbase[MD_CLASSES - 1] + inc - v;
+                wbase[MD_CLASSES - 1] += __builtin_amdgcn_readlane(inc, 63);
+            }
+            if (nt[q] <= 0) continue;
+            const int m = mb + q * NT + (int)threadIdx.x;
+            for (int jt = 0; jt < nt[q]; ++jt) desc[pos + jt] = TileDesc{m, off[q], M[q], jt, t0[q] + jt};
+        }
+    }
+}
