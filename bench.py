@@ -244,7 +244,9 @@ def main():
     if os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
-            roofline["traffic"] = tr.get(f"{args.config}_{main_mode}", {}).get("k_project_hits")
+            # the PMC passes were taken on the default workload; a different batch gets no traffic figure
+            if args.frames == int(tr.get("frames_per_gpu", 256)) and not args.set:
+                roofline["traffic"] = tr.get(f"{args.config}_{main_mode}", {}).get("k_project_hits")
             if roofline["traffic"]:
                 # what HBM actually moved per launch / time: the honest distance from the HBM roof (the kernel is
                 # bound by instruction issue; `frac` above is SURVEY 8(d)'s algorithmic figure)

@@ -46,7 +46,8 @@ def main(tag):
         v["hbm_bytes_per_launch"] = int((f * corr + w) * 1024)
         out[k] = v
     json.dump(out, open(f"profiles/{tag}_c2_rle_pmc_traffic.json", "w"), indent=1)
-    traffic = {"c2_rle": {k: v["hbm_bytes_per_launch"] for k, v in out.items()}, "source": f"profiles/{tag}_c2_rle_pmc_traffic.json"}
+    traffic = {"c2_rle": {k: v["hbm_bytes_per_launch"] for k, v in out.items()}, "source": f"profiles/{tag}_c2_rle_pmc_traffic.json",
+               "frames_per_gpu": 256}
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
     rows = list(csv.DictReader(open(f"profiles/{tag}_c2_rle_kernel_stats.csv")))
     print(f"{'kernel':42s} {'calls':>5s} {'avg_us':>9s} {'%':>6s} {'HBM MB/launch':>14s}")
