@@ -180,7 +180,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     const float4 *__restrict__ points, const int32_t *__restrict__ pt_off, int n_points_total,
     const float *__restrict__ cams, int n_cams, const int32_t *__restrict__ mask_off,
     const int32_t *__restrict__ mask_cam, const int4 *__restrict__ bbox, const uint32_t *__restrict__ packed,
-    int W, int H, int Wp, float min_dist, int nm_cap, int nblk_max, uint32_t *__restrict__ hit_words,
+    int W, int H, int Wp, float min_dist, int nm_cap, int nblk_max, int chunks_per_block, uint32_t *__restrict__ hit_words,
     int32_t *__restrict__ hit_count, int32_t *__restrict__ blk_cnt, int32_t *__restrict__ status)
 {
     const int f = blockIdx.y;
@@ -197,13 +197,13 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
 
     __shared__ float s_cam[CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
     __shared__ float s_cone[CM3D_MAX_CAMS][8];           // conservative visibility cone per camera
-    // dynamic LDS: masks of every camera as bit sets [n_cams][planes_cap], counts [nm_cap],
-    // and (several planes only) hit words [planes][PH_BLOCK_PTS]
+    // dynamic LDS: masks of every camera as bit sets [n_cams][planes_cap], counts [chunks_per_block][nm_cap] (one
+    // row per chunk this block walks), and (several planes only) hit words [planes][PH_BLOCK_PTS]
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const int planes_cap = (nm_cap + 31) >> 5;
     uint32_t *s_cmask = reinterpret_cast<uint32_t *>(s_dyn);
     int *s_cnt = reinterpret_cast<int *>(s_cmask + CM3D_MAX_CAMS * planes_cap);
-    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cnt + nm_cap);
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cnt + chunks_per_block * nm_cap);
 
     // points of the first chunk are requested before the table staging so that both latencies overlap.
     // Slots past the end of the frame hold NaN points: every test below rejects them by itself.
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS)
         s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
     for (int q = threadIdx.x; q < CM3D_MAX_CAMS * planes_cap; q += PH_THREADS) s_cmask[q] = 0u;
-    for (int k = threadIdx.x; k < nm; k += PH_THREADS) s_cnt[k] = 0;
+    for (int k = threadIdx.x; k < chunks_per_block * nm_cap; k += PH_THREADS) s_cnt[k] = 0;
     __syncthreads();
     for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
         const int c = mask_cam[m0 + k];
@@ -230,8 +230,13 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
 
     const size_t mask_words = (size_t)H * Wp;
     const int lane = cm3d_lane();
-    for (int chunk = blockIdx.x; chunk < nblk; chunk += gridDim.x) {
+    // The waves of a block walk its chunks without meeting: the per-(chunk, mask) counts collect in LDS rows and are
+    // flushed once, behind the only barrier after the loop (a barrier per chunk made every wave wait for the
+    // slowest one of each chunk).
+    int ci = 0;
+    for (int chunk = blockIdx.x; chunk < nblk; chunk += gridDim.x, ++ci) {
         const int base = chunk * PH_BLOCK_PTS;
+        int *s_cnt_row = s_cnt + ci * nm_cap;
         static_assert(PH_PT == 4, "points are handled as two pairs");
         const f2 X[2] = {{pt[0].x, pt[1].x}, {pt[2].x, pt[3].x}};
         const f2 Y[2] = {{pt[0].y, pt[1].y}, {pt[2].y, pt[3].y}};
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                             else if (hit) s_bits[pl * PH_BLOCK_PTS + ph_slot(j)] |= 1u << kb[b];
                             cnt += __popcll(__ballot(hit));
                         }
-                        if (cnt && lane == 0) atomicAdd(&s_cnt[pl * 32 + kb[b]], cnt);
+                        if (cnt && lane == 0) atomicAdd(&s_cnt_row[pl * 32 + kb[b]], cnt);
                     }
                 }
             }
@@ -341,15 +346,18 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                         hit_words[(size_t)pl * n_points_total + p0 + idx] = s_bits[pl * PH_BLOCK_PTS + ph_slot(j)];
             }
         }
-        __syncthreads();
-        // per-(block, mask) counts: exact output offsets come from their exclusive scan
-        for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
-            const int c = s_cnt[k];
+    }
+    __syncthreads();
+    // per-(chunk, mask) counts: exact output offsets come from their exclusive scan (k_hit_offsets)
+    for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
+        int tot = 0;
+        int r = 0;
+        for (int chunk = blockIdx.x; chunk < nblk; chunk += gridDim.x, ++r) {
+            const int c = s_cnt[r * nm_cap + k];
             blk_cnt[((size_t)f * nblk_max + chunk) * nm_cap + k] = c;
-            if (c) atomicAdd(&hit_count[m0 + k], c);
-            s_cnt[k] = 0;
+            tot += c;
         }
-        __syncthreads();
+        if (tot) atomicAdd(&hit_count[m0 + k], tot);
     }
 }
 
@@ -596,19 +604,25 @@ extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int
     const int nblk_max = (max_pts_per_frame + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
     const int nm_cap = ph_nm_cap(planes);
     // enough blocks to fill the chip (256 CUs x 6 resident), each walking a few chunks of its frame so that the
-    // per-block table staging is amortised (measured on C2: 4608 -> 96 us, 16384 -> 100 us, 1536 -> 111 us)
+    // per-block table staging is amortised (measured on C2: 2304 -> 81 us, 4608 -> 83 us, 1536 -> 89 us)
     int gx = nblk_max;
     static long long max_blocks = 0;             // beyond that blocks walk several chunks
-    if (!max_blocks) { const char *e = getenv("CM3D_PH_MAXBLK"); max_blocks = e ? atoll(e) : 4608; }
+    if (!max_blocks) { const char *e = getenv("CM3D_PH_MAXBLK"); max_blocks = e ? atoll(e) : 2304; }
     if ((long long)gx * n_frames > max_blocks) gx = (int)((max_blocks + n_frames - 1) / n_frames);
     if (gx > nblk_max) gx = nblk_max;
     if (gx < 1) gx = 1;
     const int planes_cap = (nm_cap + 31) / 32;
-    size_t lds = (size_t)CM3D_MAX_CAMS * planes_cap * sizeof(uint32_t) + (size_t)nm_cap * sizeof(int);
+    {   // the per-chunk count rows of a block live in LDS: at most 32 KiB of them
+        const int max_cpb = 8192 / nm_cap > 1 ? 8192 / nm_cap : 1;
+        const int gx_min = (nblk_max + max_cpb - 1) / max_cpb;
+        if (gx < gx_min) gx = gx_min;
+    }
+    const int chunks_per_block = (nblk_max + gx - 1) / gx;
+    size_t lds = (size_t)CM3D_MAX_CAMS * planes_cap * sizeof(uint32_t) + (size_t)chunks_per_block * nm_cap * sizeof(int);
     if (planes_cap == 1) {
         hipLaunchKernelGGL(k_project_hits<true>, dim3(gx, n_frames), dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off,
                            n_points_total, cams, n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, nm_cap,
-                           nblk_max, hit_words, hit_count, (int32_t *)workspace, status);
+                           nblk_max, chunks_per_block, hit_words, hit_count, (int32_t *)workspace, status);
     } else {
         lds += (size_t)planes_cap * PH_BLOCK_PTS * sizeof(uint32_t);
         static size_t lds_allowed = 48 * 1024;
@@ -620,7 +634,7 @@ extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int
         }
         hipLaunchKernelGGL(k_project_hits<false>, dim3(gx, n_frames), dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off,
                            n_points_total, cams, n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, nm_cap,
-                           nblk_max, hit_words, hit_count, (int32_t *)workspace, status);
+                           nblk_max, chunks_per_block, hit_words, hit_count, (int32_t *)workspace, status);
     }
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
