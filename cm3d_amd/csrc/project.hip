@@ -103,16 +103,24 @@ static __device__ __forceinline__ void project_pair(const float *cm, int ns_rt, 
     }
 }
 
+#define PH_NP (PH_PT / 2)                         // point pairs per thread
 template <int NS, int FL>
-static __device__ __forceinline__ void project_quad(const float *cm, int ns, int fl, const f2 (&X)[2], const f2 (&Y)[2],
-                                                    const f2 (&Z)[2], float min_dist, int W, int H, int (&px)[PH_PT])
+static __device__ __forceinline__ void project_quad(const float *cm, int ns, int fl, const f2 (&X)[PH_NP], const f2 (&Y)[PH_NP],
+                                                    const f2 (&Z)[PH_NP], float min_dist, int W, int H, int (&px)[PH_PT])
 {
-    bool r0, r1;
-    project_pair<NS, FL, true>(cm, ns, fl, X[0], Y[0], Z[0], min_dist, W, H, px[0], px[1], r0);
-    project_pair<NS, FL, true>(cm, ns, fl, X[1], Y[1], Z[1], min_dist, W, H, px[2], px[3], r1);
-    if (__ballot(r0 | r1)) {          // never on real data: a depth-accepted point with |zh| outside [1e-30, 1e30)
-        project_pair<NS, FL, false>(cm, ns, fl, X[0], Y[0], Z[0], min_dist, W, H, px[0], px[1], r0);
-        project_pair<NS, FL, false>(cm, ns, fl, X[1], Y[1], Z[1], min_dist, W, H, px[2], px[3], r1);
+    bool redo = false;
+#pragma unroll
+    for (int h = 0; h < PH_NP; ++h) {
+        bool r;
+        project_pair<NS, FL, true>(cm, ns, fl, X[h], Y[h], Z[h], min_dist, W, H, px[2 * h], px[2 * h + 1], r);
+        redo |= r;
+    }
+    if (__ballot(redo)) {             // never on real data: a depth-accepted point with |zh| outside [1e-30, 1e30)
+#pragma unroll
+        for (int h = 0; h < PH_NP; ++h) {
+            bool r;
+            project_pair<NS, FL, false>(cm, ns, fl, X[h], Y[h], Z[h], min_dist, W, H, px[2 * h], px[2 * h + 1], r);
+        }
     }
 }
 
@@ -237,10 +245,14 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     for (int chunk = blockIdx.x; chunk < nblk; chunk += gridDim.x, ++ci) {
         const int base = chunk * PH_BLOCK_PTS;
         int *s_cnt_row = s_cnt + ci * nm_cap;
-        static_assert(PH_PT == 4, "points are handled as two pairs");
-        const f2 X[2] = {{pt[0].x, pt[1].x}, {pt[2].x, pt[3].x}};
-        const f2 Y[2] = {{pt[0].y, pt[1].y}, {pt[2].y, pt[3].y}};
-        const f2 Z[2] = {{pt[0].z, pt[1].z}, {pt[2].z, pt[3].z}};
+        static_assert(PH_PT % 2 == 0, "points are handled in pairs");
+        f2 X[PH_NP], Y[PH_NP], Z[PH_NP];
+#pragma unroll
+        for (int h = 0; h < PH_NP; ++h) {
+            X[h] = (f2){pt[2 * h].x, pt[2 * h + 1].x};
+            Y[h] = (f2){pt[2 * h].y, pt[2 * h + 1].y};
+            Z[h] = (f2){pt[2 * h].z, pt[2 * h + 1].z};
+        }
         uint32_t bits[PH_PT];
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) bits[j] = 0;
@@ -258,16 +270,18 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             const float *cn = s_cone[c];
             float inside;
             {
-                f2 m[2];
+                f2 m[PH_NP];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < PH_NP; ++h) {
                     const f2 vx = X[h] - cn[0], vy = Y[h] - cn[1], vz = Z[h] - cn[2];
                     f2 sd = cn[3] * vx; sd = PK_FMA((f2)(cn[4]), vy, sd); sd = PK_FMA((f2)(cn[5]), vz, sd);
                     f2 r2 = vx * vx; r2 = PK_FMA(vy, vy, r2); r2 = PK_FMA(vz, vz, r2);
                     const f2 t = PK_FMA(cn[7] * sd, sd, -r2);
                     m[h] = __builtin_elementwise_min(sd - cn[6], t);
                 }
-                inside = fmaxf(fmaxf(m[0].x, m[0].y), fmaxf(m[1].x, m[1].y));
+                inside = fmaxf(m[0].x, m[0].y);
+#pragma unroll
+                for (int h = 1; h < PH_NP; ++h) inside = fmaxf(inside, fmaxf(m[h].x, m[h].y));
             }
             if (!__ballot(inside >= 0.0f)) continue;
             const int ns = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 54]);
@@ -278,7 +292,10 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             else if (ns == 1 && fl == 1) project_quad<1, 1>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);     // Waymo
             else if (ns == 3 && fl == 10) project_quad<3, 10>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);   // KITTI
             else project_quad<-1, 0>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);
-            if (!__ballot((px[0] & px[1] & px[2] & px[3]) >= 0)) continue;      // no point of the wave in this image
+            int pxall = px[0];
+#pragma unroll
+            for (int j = 1; j < PH_PT; ++j) pxall &= px[j];
+            if (!__ballot(pxall >= 0)) continue;                 // no point of the wave in this image
             // px = iv << 16 | iu; px = -1 gives iv = -1
 #define PX_IU(j) (px[j] & 0xFFFF)
 #define PX_IV(j) (px[j] >> 16)
