@@ -167,6 +167,63 @@ def test_second_pass_is_identical(oracle):
         assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True) and np.array_equal(outs[0][k], outs[2][k], equal_nan=True), k
 
 
+def test_wider_sample_against_oracle(oracle):
+    """A dozen headline-shaped frames (C2, firing-order sweeps) against the oracle: ~400 k points x 6 cameras through
+    the packed-float32 projection and its division shortcut, every index list compared."""
+    hb, got, exp = _run("c2", 12, "rle", oracle)
+    assert exp["hit_idx"].size > 10000
+    _compare(hb, got, exp)
+
+
+def test_full_size_batch_properties():
+    """BASELINE's full C2 batch (256 frames x 35 k points x 20 masks of 1600x900), too large for the oracle: the two
+    independent mask paths (run lengths -> packed, and run lengths -> dense bytes -> packed) must give identical
+    results, index lists must be ascending and in range, counts must add up, and a second pass must reproduce
+    the first bit for bit."""
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config("c2")
+    F = 256
+    frames = [syn.make_frame(cfg, 5000 + i) for i in range(F)]
+    lanes = [syn.make_lane_table([600.0, 1600.0], 50000, seed=3, extent=260.0)]
+    hb = lifting.pack_frames(frames, lanes, [0] * F)
+    del frames
+    eng = lifting.LiftEngine()
+    eng.upload(hb)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    a = eng.download()
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    a2 = eng.download()
+    eng.decode_masks_dense()
+    eng.run(masks="dense")
+    torch.cuda.synchronize()
+    b = eng.download()
+    for k in a:
+        assert np.array_equal(a[k], a2[k], equal_nan=True), f"second pass differs in {k}"
+        assert np.array_equal(a[k], b[k], equal_nan=True), f"mask paths differ in {k}"
+    off, idx = a["hit_off"], a["hit_idx"]
+    assert off[0] == 0 and off[-1] == idx.size and np.all(np.diff(off) >= 0) and idx.size > 200000
+    # ascending inside every list, inside the frame's point range
+    starts = np.zeros(idx.size, bool); starts[off[:-1][np.diff(off) > 0]] = True
+    assert np.all((np.diff(idx) > 0) | starts[1:])
+    n_pts = np.diff(a["pt_off"])
+    per_mask_frame = np.repeat(np.arange(F), np.diff(hb.mask_off))
+    cnt = np.diff(off)
+    assert np.all(idx >= 0) and np.all(idx < np.repeat(n_pts[per_mask_frame], cnt))
+    # medoid position inside its list, exactly the masks with points have a centroid
+    mp = a["medoid_pos"]
+    assert np.array_equal(mp >= 0, cnt > 0) and np.all(mp[cnt > 0] < cnt[cnt > 0])
+    # the centroid is the medoid point of the frame's (reference-order) cloud
+    sel = np.nonzero(cnt > 0)[0]
+    pts = a["points"][a["pt_off"][per_mask_frame[sel]] + idx[off[sel] + mp[sel]]]
+    assert np.array_equal(pts[:, :3].view(np.uint32), a["centroid"][sel].view(np.uint32))
+    # a box exists (bit 0) exactly for the masks with points; NMS (bit 1) keeps a subset of them
+    assert np.array_equal((a["flags"] & 1) != 0, cnt > 0) and np.all(((a["flags"] & 2) == 0) | (cnt > 0))
+    assert int(((a["flags"] & 3) == 3).sum()) > 2000
+
+
 def test_waymo_pipeline(oracle):
     """a17: single-stage cameras, no ego-box filter, medoid -> global for the lane lookup, boxes back in the
     vehicle frame with heading, NMS per Waymo type.  The float32 pose inverse limits agreement with the
