@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcm3d_hip.so")
+LIB_PATH = os.environ.get("CM3D_LIB") or os.path.join(_HERE, "libcm3d_hip.so")      # CM3D_LIB: experiments only
 
 ABI_VERSION = 1
 CAM_STRIDE = 64
@@ -35,6 +35,7 @@ SIGNATURES = {
                                  _p, _p, _p, _p, _i64, _p]),
     "cm3d_compact_hits": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _i64, _p]),
     "cm3d_tile_work_bytes": (_i64, [_i32, _i32]),
+    "cm3d_selftest_sqrt": (_i32, [C.c_uint32, C.c_uint32, _p, _p, _p]),
     "cm3d_medoid_workspace_bytes": (_i64, [_i32, _i32]),
     "cm3d_medoid": (_i32, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _p]),
     "cm3d_lane_grid_bytes": (_i64, [_i32, _i32]),

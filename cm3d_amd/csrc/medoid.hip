@@ -14,23 +14,43 @@
 #include "worklist.h"
 #include <stdlib.h>
 
+#ifndef MD_WAVES
 #define MD_WAVES 4                       // waves per workgroup, one tile each
+#endif
 #define MD_THREADS (MD_WAVES * 64)
+#ifndef MD_STAGE
 #define MD_STAGE 512                     // rows of a list staged in a wave's LDS slice at a time (8 KiB)
+#endif
 
 typedef float f2 __attribute__((ext_vector_type(2)));      // two rows side by side: v_pk_{add,mul,fma}_f32
 typedef int i2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 #define PK_FMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
 
-// Correctly rounded float32 square root = sqrtf(), without the denormal pre-scaling hipcc emits around
-// v_sqrt_f32, branch- and compare-free: v_sqrt_f32 is within 1 ulp; with s- / s+ its neighbours,
+// Correctly rounded float32 square root = sqrtf() for 1e-30 <= x < 1e30 (md_sqrt_ok; the caller falls back to
+// sqrtf() for the whole wave when any lane is outside -- zeros on the diagonal, never anything else on real
+// coordinates), all in packable arithmetic: v_rsq_f32 (1 ulp), then the coupled Newton step on (s, h) ~ (sqrt x,
+// 1 / (2 sqrt x)) and a final residual correction -- the sequence LLVM emits for a correctly rounded f32 sqrt when
+// no denormal can be involved.  7 packed-able operations + the rsq per value, against 8 scalar ones + v_sqrt_f32 for
+// the neighbour test (md_sqrt_core2_ref, kept as the checker: cm3d_selftest_sqrt compares the two and sqrtf() over
+// every float of the domain, tests/test_gpu_golden.py).
+static __device__ __forceinline__ f2 md_sqrt_core2(f2 x)
+{
+    const f2 r = {__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
+    f2 s = x * r;
+    f2 h = r * 0.5f;
+    const f2 e = PK_FMA(-h, s, (f2)(0.5f));
+    h = PK_FMA(h, e, h);
+    s = PK_FMA(s, e, s);
+    const f2 d = PK_FMA(-s, s, x);
+    return PK_FMA(d, h, s);
+}
+
+// v_sqrt_f32 is within 1 ulp; with s- / s+ its neighbours,
 //   t- = fma(s-, s, -x) >= 0  <=>  s- * s >= x  -> the root is nearer to s- than to s
 //   t+ = fma(s+, s, -x) <  0  <=>  s+ * s <  x  -> the root is nearer to s+ than to s
 // (an exact zero residual is +0 under round-to-nearest), so bits(result) = bits(s-) + sign(t-) + sign(t+).
-// Valid for 1e-30 <= x < 1e30 (md_sqrt_ok); the caller falls back to sqrtf() for the whole wave when any lane
-// is outside (zeros on the diagonal, never anything else on real coordinates).
-static __device__ __forceinline__ f2 md_sqrt_core2(f2 x)
+static __device__ __forceinline__ f2 md_sqrt_core2_ref(f2 x)
 {
     const f2 s = {__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
     const i2 sb = __builtin_bit_cast(i2, s);
@@ -86,15 +106,39 @@ static __device__ __forceinline__ f2 md_pair2(const float4 A, const float4 B, fl
 template <bool DIRECT>
 static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float qx, float qy, float qz, float qn, float s)
 {
-    constexpr int U = 4;                      // pairs per step
+#ifndef MD_U
+#define MD_U 4
+#endif
+    constexpr int U = MD_U;                   // pairs per step
     int ii = 0;
     for (; ii + 2 * U <= cnt; ii += 2 * U) {
         f2 d[U];
+        if (DIRECT) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) d[u] = md_pair2<DIRECT>(s4[ii + 2 * u], s4[ii + 2 * u + 1], qx, qy, qz, qn);
+            for (int u = 0; u < U; ++u) d[u] = md_pair2<true>(s4[ii + 2 * u], s4[ii + 2 * u + 1], qx, qy, qz, qn);
+        } else {
+            // the U chains written side by side, one operation of every chain at a time: back-to-back dependent
+            // packed operations of one chain cost wait states, operations of different chains do not
+            float4 A[U], B[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { A[u] = s4[ii + 2 * u]; B[u] = s4[ii + 2 * u + 1]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = (f2){A[u].x, A[u].y} * qx;                       // (-2 x_i) * x_j
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = PK_FMA(((f2){A[u].z, A[u].w}), (f2)(qy), d[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = PK_FMA(((f2){B[u].x, B[u].y}), (f2)(qz), d[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = d[u] + (f2){B[u].z, B[u].w};                     // fma(n_i, 1, acc)
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = d[u] + qn;                                       // fma(1, n_j, acc)
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = (f2){fmaxf(d[u].x, 0.0f), fmaxf(d[u].y, 0.0f)};  // clamp_min_(0)
+        }
         // md_sqrt_core's domain, tested on the extremes (a 0 on the diagonal sends its step to sqrtf)
-        const float lo = fminf(fminf(fminf(d[0].x, d[0].y), fminf(d[1].x, d[1].y)), fminf(fminf(d[2].x, d[2].y), fminf(d[3].x, d[3].y)));
-        const float hi = fmaxf(fmaxf(fmaxf(d[0].x, d[0].y), fmaxf(d[1].x, d[1].y)), fmaxf(fmaxf(d[2].x, d[2].y), fmaxf(d[3].x, d[3].y)));
+        float lo = fminf(d[0].x, d[0].y), hi = fmaxf(d[0].x, d[0].y);
+#pragma unroll
+        for (int u = 1; u < U; ++u) { lo = fminf(lo, fminf(d[u].x, d[u].y)); hi = fmaxf(hi, fmaxf(d[u].x, d[u].y)); }
         if (__ballot(!(lo >= 1.0e-30f && hi < 1.0e30f))) {
 #pragma unroll
             for (int u = 0; u < U; ++u) d[u] = (f2){sqrtf(d[u].x), sqrtf(d[u].y)};
@@ -262,6 +306,40 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     CM3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_medoid_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, (const float4 *)points, pt_off, mask_frame,
                        n_masks, hit_off, tile_off, hit_row, idx_cap, best, tile_cap, medoid_pos, centroid);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Diagnostic: every float32 bit pattern in [first_bits, last_bits] (positive, inside md_sqrt_ok's domain) through
+// md_sqrt_core2, md_sqrt_core2_ref and sqrtf(); counts the values on which they are not all bit-identical.
+__global__ __launch_bounds__(256) void k_selftest_sqrt(uint32_t first_bits, uint32_t last_bits, unsigned long long *n_bad,
+                                                        uint32_t *first_bad)
+{
+    unsigned long long bad = 0;
+    const unsigned long long span = (unsigned long long)last_bits - first_bits + 1ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < span;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t b = first_bits + (uint32_t)i;
+        const float x = __uint_as_float(b);
+        if (!md_sqrt_ok(x)) continue;
+        const float want = sqrtf(x);
+        const float a = md_sqrt_core2((f2){x, x}).x, c = md_sqrt_core2_ref((f2){x, x}).y;
+        if (__float_as_uint(a) != __float_as_uint(want) || __float_as_uint(c) != __float_as_uint(want)) {
+            ++bad;
+            atomicMin(first_bad, b);
+        }
+    }
+    if (bad) atomicAdd(n_bad, bad);
+}
+
+extern "C" int cm3d_selftest_sqrt(uint32_t first_bits, uint32_t last_bits, uint64_t *n_bad, uint32_t *first_bad, cm3d_stream_t stream)
+{
+    if (!n_bad || !first_bad || last_bits < first_bits || (last_bits >> 31)) return CM3D_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(n_bad, 0, sizeof(uint64_t), st) != hipSuccess) return CM3D_ERR_LAUNCH;
+    if (hipMemsetAsync(first_bad, 0xFF, sizeof(uint32_t), st) != hipSuccess) return CM3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_selftest_sqrt, dim3(8192), dim3(256), 0, st, first_bits, last_bits, (unsigned long long *)n_bad, first_bad);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

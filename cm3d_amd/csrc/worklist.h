@@ -9,16 +9,30 @@ struct TileDesc { int m, off, M, jt, t; };  // mask, start in hit_idx, list leng
 // (classes by tile count; a tile's cost is its list length), so that the waves which run longest start first and
 // the short ones fill in behind them.  Results are indexed by the tile id t = tile_off[m] + jt, not by the work
 // position, so the order has no influence on any output.  One workgroup of NT threads.
-#define MD_CLASSES 8                     // class c < 7: exactly c + 1 tiles; class 7: 8 tiles or more
+#define MD_UNI 7                         // classes 0..6: exactly 1..7 tiles (lists of up to 448 points)
+#define MD_CLASSES 16                    // classes 7..15: 8-9, 10-12, 13-16, 17-21, 22-28, 29-37, 38-49, 50-65, 66+ tiles
 #define MD_DESC_PER 8                    // masks per thread per round: all their loads are in flight together
 
-// tiles of the wave's lanes per class (wave-uniform values).  Lanes of a class below the last all carry the same
+// class of a list with nt >= 1 tiles: geometric steps of about 1.3 above 7 tiles, so that "longest first" holds to
+// within a class width for the long lists that carry most of the work of a multi-sweep batch
+static __device__ __forceinline__ int md_class(int nt)
+{
+    if (nt <= MD_UNI) return nt - 1;
+    return MD_UNI + (nt >= 10) + (nt >= 13) + (nt >= 17) + (nt >= 22) + (nt >= 29) + (nt >= 38) + (nt >= 50) + (nt >= 66);
+}
+
+// tiles of the wave's lanes per class (wave-uniform values).  Lanes of a class below MD_UNI all carry the same
 // tile count, so a ballot and a popcount give the class sum without touching memory.
 static __device__ __forceinline__ void md_class_sums(int nt, int (&sum)[MD_CLASSES])
 {
 #pragma unroll
-    for (int c = 0; c < MD_CLASSES - 1; ++c) sum[c] += (int)__popcll(__ballot(nt == c + 1)) * (c + 1);
-    if (__ballot(nt >= MD_CLASSES)) sum[MD_CLASSES - 1] += cm3d_wave_sum(nt >= MD_CLASSES ? nt : 0);
+    for (int c = 0; c < MD_UNI; ++c) sum[c] += (int)__popcll(__ballot(nt == c + 1)) * (c + 1);
+    if (__ballot(nt > MD_UNI)) {
+        const int cls = nt > MD_UNI ? md_class(nt) : -1;
+#pragma unroll
+        for (int c = MD_UNI; c < MD_CLASSES; ++c)
+            if (__ballot(cls == c)) sum[c] += cm3d_wave_sum(cls == c ? nt : 0);
+    }
 }
 
 // tile capacity of a batch: every mask may end with a partial tile
@@ -99,16 +113,21 @@ static __device__ __forceinline__ void md_build_worklist(int n_masks, const int3
             if (mb + q * NT >= n_masks) break;                 // uniform
             int pos = 0;
 #pragma unroll
-            for (int c = 0; c < MD_CLASSES - 1; ++c) {
+            for (int c = 0; c < MD_UNI; ++c) {
                 const uint64_t mk = __ballot(nt[q] == c + 1);
                 if (nt[q] == c + 1) pos = wbase[c] + cm3d_mbcnt(mk) * (c + 1);
                 wbase[c] += (int)__popcll(mk) * (c + 1);
             }
-            if (__ballot(nt[q] >= MD_CLASSES)) {
-                const int v = nt[q] >= MD_CLASSES ? nt[q] : 0;
-                const int inc = cm3d_wave_incl_scan(v);
-                if (v) pos = wbase[MD_CLASSES - 1] + inc - v;
-                wbase[MD_CLASSES - 1] += __builtin_amdgcn_readlane(inc, 63);
+            if (__ballot(nt[q] > MD_UNI)) {
+                const int cls = nt[q] > MD_UNI ? md_class(nt[q]) : -1;
+#pragma unroll
+                for (int c = MD_UNI; c < MD_CLASSES; ++c) {
+                    if (!__ballot(cls == c)) continue;
+                    const int v = cls == c ? nt[q] : 0;
+                    const int inc = cm3d_wave_incl_scan(v);
+                    if (v) pos = wbase[c] + inc - v;
+                    wbase[c] += __builtin_amdgcn_readlane(inc, 63);
+                }
             }
             if (nt[q] <= 0) continue;
             const int m = mb + q * NT + (int)threadIdx.x;

@@ -169,6 +169,11 @@ int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_
                 const int32_t *tile_work, int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
                 int64_t workspace_bytes, cm3d_stream_t stream);
 
+/* Diagnostic for the tests: runs every float32 bit pattern in [first_bits, last_bits] (positive values) that lies in
+ * the medoid kernel's fast-path domain [1e-30, 1e30) through the kernel's square root, its reference form and sqrtf();
+ * *n_bad (device) = number of values on which the three are not bit-identical, *first_bad = smallest such pattern. */
+int cm3d_selftest_sqrt(uint32_t first_bits, uint32_t last_bits, uint64_t *n_bad, uint32_t *first_bad, cm3d_stream_t stream);
+
 /* ---- a10: nearest lane point --------------------------------------------------
  * Replaces lane_yaws_distances_and_coords (2d_to_3d.py:277-302): float64 Euclidean
  * distance on (x,y) between float32-rounded centroids and lane points, first minimum.

@@ -5,8 +5,9 @@ import numpy as np
 import torch
 from cm3d_amd import lifting, synthetic as syn
 
-cfg = syn.config("c2")
-F = 256
+import sys
+cfg = syn.config(sys.argv[1] if len(sys.argv) > 1 else "c2")
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 frames = [syn.make_frame(cfg, i) for i in range(F)]
 lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 50000, seed=1, extent=260.0)]
 hb = lifting.pack_frames(frames, lanes, [0] * F)

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_insts
 mkdir -p $OUT
-B="python3 bench.py --cpu-sample 0 --no-secondary --steps 2 --warmup 1"
+B="python3 bench.py --cpu-sample 0 --no-secondary --steps 2 --warmup 1 $*"
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --kernel-trace -d $OUT/a -o p --output-format csv -- $B > $OUT/a.json 2> $OUT/a.err || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/b -o p --output-format csv -- $B > $OUT/b.json 2> $OUT/b.err || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA --kernel-trace -d $OUT/c -o p --output-format csv -- $B > $OUT/c.json 2> $OUT/c.err || exit 1

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_stall
 rm -rf $OUT; mkdir -p $OUT
-B="python3 bench.py --cpu-sample 0 --no-secondary --steps 2 --warmup 1"
+B="python3 bench.py --cpu-sample 0 --no-secondary --steps 2 --warmup 1 $*"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_IFETCH_LEVEL" "SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH" "SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU"; do
   i=$((i+1))
