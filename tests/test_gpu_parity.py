@@ -147,6 +147,59 @@ def test_heavy_ego_box_drop(oracle):
     _compare(hb, got, exp)
 
 
+def test_index_capacity_overflow_is_reported(oracle):
+    """Too small an index buffer: nothing is written out of bounds, the status word says so and the host raises."""
+    import torch
+    from cm3d_amd import _lib, lifting
+    cfg = syn.config("c1")
+    frames = [syn.make_frame(cfg, i) for i in range(2)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 2000, seed=1)]
+    hb = lifting.pack_frames(frames, lanes, [0, 0])
+    eng = lifting.LiftEngine()
+    eng.hits_per_point = 0.0                 # -> the minimum capacity of 1024 indices, far below this batch's hits
+    eng.upload(hb)
+    guard = torch.full((4096,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")     # allocated right after the engine's buffers
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.Cm3dError, match="capacity"):
+        eng.download()
+    assert int((guard != 0x5A5A5A5A).sum()) == 0
+    # the same engine recovers with a sufficient capacity
+    eng.hits_per_point = 2.0
+    eng.upload(hb)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    got = eng.download()
+    exp = oracle_batch(oracle, frames, lanes, [0, 0], hb)
+    _compare(hb, got, exp)
+
+
+def test_frame_without_points(oracle):
+    """A frame whose only sweep is empty (and one whose rows all fall into the ego box): no points, no boxes, and the
+    neighbouring frames are unaffected."""
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config("tiny")
+    frames = [syn.make_frame(cfg, i) for i in range(4)]
+    frames[1].sweeps_raw = [frames[1].sweeps_raw[0][:0]]
+    frames[1].sweep_xf = frames[1].sweep_xf[:1]
+    for sw in frames[2].sweeps_raw:
+        sw[:, 0] = 0.5; sw[:, 1] = -0.5          # every row inside the ego box
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 1000, seed=1)]
+    hb = lifting.pack_frames(frames, lanes, [0] * 4)
+    eng = lifting.LiftEngine(keep_colsum=True)
+    eng.upload(hb)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    got = eng.download()
+    exp = oracle_batch(oracle, frames, lanes, [0] * 4, hb)
+    _compare(hb, got, exp)
+    for f in (1, 2):
+        m0, m1 = hb.mask_off[f], hb.mask_off[f + 1]
+        assert got["pt_off"][f + 1] == got["pt_off"][f] and (got["flags"][m0:m1] == 0).all()
+    assert (got["flags"][:hb.mask_off[1]] != 0).any() and (got["flags"][hb.mask_off[3]:] != 0).any()
+
+
 def test_second_pass_is_identical(oracle):
     """Running the resident batch twice gives bit-identical outputs (no state leaks between passes,
     no order-dependent atomics on anything that is an output)."""
