@@ -629,8 +629,9 @@ extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int
     if (gx > nblk_max) gx = nblk_max;
     if (gx < 1) gx = 1;
     const int planes_cap = (nm_cap + 31) / 32;
-    {   // the per-chunk count rows of a block live in LDS: at most 32 KiB of them
-        const int max_cpb = 8192 / nm_cap > 1 ? 8192 / nm_cap : 1;
+    {   // the per-chunk count rows of a block live in LDS: at most 16 KiB of them (with 1024 masks per frame the
+        // per-thread hit words already take 128 KiB of the 160)
+        const int max_cpb = 4096 / nm_cap > 1 ? 4096 / nm_cap : 1;
         const int gx_min = (nblk_max + max_cpb - 1) / max_cpb;
         if (gx < gx_min) gx = gx_min;
     }

@@ -93,6 +93,25 @@ def test_many_masks_three_planes(oracle):
     _compare(hb, got, exp)
 
 
+def test_a_thousand_masks_in_a_frame(oracle):
+    """The per-frame mask limit (CM3D_MAX_MASKS_PER_FRAME = 1024, 32 hit-word planes): 1000 small masks in one frame."""
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config("tiny", n_masks=1000, n_points=6000, duplicate_prob=0.5)
+    frames = [syn.make_frame(cfg, 3), syn.make_frame(syn.config("tiny"), 4)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 1000, seed=1)]
+    hb = lifting.pack_frames(frames, lanes, [0, 0])
+    assert hb.mask_off[1] == 1000
+    eng = lifting.LiftEngine(keep_colsum=True)
+    eng.upload(hb)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    got = eng.download()
+    exp = oracle_batch(oracle, frames, lanes, [0, 0], hb)
+    assert exp["hit_idx"].size > 5000
+    _compare(hb, got, exp)
+
+
 def test_ragged_batch(oracle):
     """Frames with different point counts and mask counts in one batch, incl. a frame whose masks are all empty."""
     import torch
