@@ -16,7 +16,8 @@
 //    does not matter and the first minimum wins on ties, like np.argmin.
 #define LG_MAX_CELLS 32768          // cells per table: the whole cell index lives in LDS (128 KiB) during the build
 #define LG_CELL0 4.0f               // preferred cell edge [m]
-#define LG_MAX_RINGS 10             // rings a centroid may visit before it is handed to the brute-force kernel
+#define LG_MAX_RINGS 64             // rings (256 m at the preferred cell size) a search may cover before the wave scans its whole table
+#define LG_BIG_CELL 12         // points in a cell above which the whole wave scans it together
 #define LG_BUILD_THREADS 1024
 
 struct LaneGrid { float x0, y0, h, inv_h; int gw, gh, cell_base; float margin; };
@@ -154,50 +155,65 @@ __global__ __launch_bounds__(256) void k_lane_nn_grid(const float *__restrict__ 
         const int out_i = qi < 0 ? -qi : (qi >= g.gw ? qi - g.gw + 1 : 0);
         const int out_j = qj < 0 ? -qj : (qj >= g.gh ? qj - g.gh + 1 : 0);
         const int32_t *cs = cell_start + g.cell_base;
-        int rings = 0;
-        for (int r = max(out_i, out_j); rings < max_rings; ++r, ++rings) {
-            if (r == 0) {
-                // centroid inside the grid: rings 0, 1 and 2 (the 5 x 5 cells around it) in one round of loads --
-                // nearly every search ends here, after one memory round trip instead of three
-                if (lane < 25) {
-                    const int ci = qi - 2 + lane % 5, cj = qj - 2 + lane / 5;
-                    if (ci >= 0 && ci < g.gw && cj >= 0 && cj < g.gh) {
-                        const int a = cs[cj * g.gw + ci], b = cs[cj * g.gw + ci + 1];
-                        for (int q = a; q < b; ++q) {
-                            const LanePt p = sorted[q];
-                            const double dx = cx - (double)p.x, dy = cy - (double)p.y;
-                            lg_consider(dx * dx + dy * dy, p.idx, d2cut, sbest, jbest);
-                        }
-                    }
-                }
-                r = 2; rings = 2;
-            } else {
-            const int ncells = 8 * r;
-            for (int u = lane; u < ncells; u += 64) {
-                int ci = qi, cj = qj;
-                {
-                    const int side = u / (2 * r), t = u - side * 2 * r;
-                    if (side == 0)      { cj = qj - r; ci = qi - r + t; }
-                    else if (side == 1) { ci = qi + r; cj = qj - r + t; }
-                    else if (side == 2) { cj = qj + r; ci = qi + r - t; }
-                    else                { ci = qi - r; cj = qj + r - t; }
-                }
-                if (ci < 0 || ci >= g.gw || cj < 0 || cj >= g.gh) continue;
-                const int a = cs[cj * g.gw + ci], b = cs[cj * g.gw + ci + 1];
+        // Every lane brings the point range [a, b) of one cell (empty if it has none).  Short ranges are scanned by
+        // their lane; a long one (a cell where many lanes and connectors meet -- one lane would keep the whole wave
+        // waiting) is handed to the whole wave, 64 points per step.  Collective: call with all lanes.
+        auto visit = [&](int a, int b) {
+            const bool big = b - a > LG_BIG_CELL;
+            if (!big) {
                 for (int q = a; q < b; ++q) {
                     const LanePt p = sorted[q];
                     const double dx = cx - (double)p.x, dy = cy - (double)p.y;
                     lg_consider(dx * dx + dy * dy, p.idx, d2cut, sbest, jbest);
                 }
             }
+            for (uint64_t bm = __ballot(big); bm; bm &= bm - 1) {
+                const int src = (int)__builtin_ctzll(bm);
+                const int ra = __builtin_amdgcn_readlane(a, src), rb = __builtin_amdgcn_readlane(b, src);
+                for (int q = ra + lane; q < rb; q += 64) {
+                    const LanePt p = sorted[q];
+                    const double dx = cx - (double)p.x, dy = cy - (double)p.y;
+                    lg_consider(dx * dx + dy * dy, p.idx, d2cut, sbest, jbest);
+                }
             }
+        };
+        // Rings are searched in batches that grow with the distance: [0..2] (the 5 x 5 cells around the centroid --
+        // nearly every search ends there), then 3 more rings, then half as many again as are behind, ...  A batch
+        // [r_lo..r_hi] is a square annulus; cut into ROW SEGMENTS it is a short list of contiguous point ranges (the
+        // cells of a grid row are consecutive in the sorted copy): (r_hi - r_lo + 1) full-width rows above and below,
+        // and a left and a right piece for each of the 2 r_lo - 1 rows in between.  One lane per segment, one round of
+        // range loads, one stop test and one wave reduction per batch: a centroid 40 m from the nearest lane point
+        // costs four batches of one step each.
+        int r_done = max(out_i, out_j) - 1;                        // rings up to r_done are searched
+        while (r_done < max_rings) {
+            const int r_lo = r_done + 1;
+            const int r_hi = r_lo == 0 ? 2 : min(max_rings, r_lo + max(2, r_lo / 2));
+            const int w = r_hi - r_lo + 1;
+            const int nseg = r_lo == 0 ? 5 : 2 * w + 2 * (2 * r_lo - 1);
+            for (int s0 = 0; s0 < nseg; s0 += 64) {                // wave-uniform trip count: visit() is collective
+                const int sg = s0 + lane;
+                int row, c0, c1;
+                if (r_lo == 0) { row = qj - 2 + sg; c0 = qi - 2; c1 = qi + 2; }
+                else if (sg < w) { row = qj - r_hi + sg; c0 = qi - r_hi; c1 = qi + r_hi; }
+                else if (sg < 2 * w) { row = qj + r_lo + (sg - w); c0 = qi - r_hi; c1 = qi + r_hi; }
+                else {
+                    const int m = sg - 2 * w;
+                    row = qj - r_lo + 1 + (m >> 1);
+                    if (m & 1) { c0 = qi + r_lo; c1 = qi + r_hi; } else { c0 = qi - r_hi; c1 = qi - r_lo; }
+                }
+                c0 = max(c0, 0); c1 = min(c1, g.gw - 1);
+                int a = 0, b = 0;
+                if (sg < nseg && row >= 0 && row < g.gh && c0 <= c1) { a = cs[row * g.gw + c0]; b = cs[row * g.gw + c1 + 1]; }
+                visit(a, b);
+            }
+            r_done = r_hi;
             // wave-wide best distance so far
             double wb = sbest;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) wb = fmin(wb, __shfl_xor(wb, o, 64));
-            // every unvisited point is at least r*h - margin away
-            if (wb < (double)r * (double)g.h - (double)g.margin) { resolved = true; break; }
-            if (qi - r <= 0 && qi + r >= g.gw - 1 && qj - r <= 0 && qj + r >= g.gh - 1) { resolved = true; break; }   // whole grid seen
+            // every unvisited point is at least r_done * h - margin away
+            if (wb < (double)r_done * (double)g.h - (double)g.margin) { resolved = true; break; }
+            if (qi - r_done <= 0 && qi + r_done >= g.gw - 1 && qj - r_done <= 0 && qj + r_done >= g.gh - 1) { resolved = true; break; }   // whole grid seen
         }
     }
     if (!resolved) {
@@ -206,10 +222,19 @@ __global__ __launch_bounds__(256) void k_lane_nn_grid(const float *__restrict__ 
         // (distance, index) order whatever the visiting order.
         const int32_t *cs = cell_start + g.cell_base;
         const int a = cs[0], b = cs[g.gw * g.gh];
-        for (int q = a + lane; q < b; q += 64) {
-            const LanePt p = sorted[q];
-            const double dx = cx - (double)p.x, dy = cy - (double)p.y;
-            lg_consider(dx * dx + dy * dy, p.idx, d2cut, sbest, jbest);
+        for (int q0 = a; q0 < b; q0 += 8 * 64) {                  // 8 loads in flight per lane: a streaming scan
+            LanePt p[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int q = q0 + v * 64 + lane;
+                p[v] = q < b ? sorted[q] : LanePt{0.f, 0.f, 0, 0};
+            }
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                if (q0 + v * 64 + lane >= b) continue;
+                const double dx = cx - (double)p[v].x, dy = cy - (double)p[v].y;
+                lg_consider(dx * dx + dy * dy, p[v].idx, d2cut, sbest, jbest);
+            }
         }
     }
     // lexicographic (distance, index) minimum over the lanes
