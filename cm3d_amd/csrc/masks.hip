@@ -3,9 +3,10 @@
 //   bool/transpose/H2D at :542-544.
 // HBM-bound streaming kernels (no MFMA):
 //   k_erode_pack      reads n*W*H dense bytes once (+ 2 halo rows per band), writes n*H*Wp*4
-//   k_rle_to_dense    reads the run ends (KBs), writes n*W*H
-//   k_rle_erode_pack  reads the run ends (KBs), writes only the rectangle of packed words that can
-//                     hold an eroded pixel (rows/words outside a mask's bbox are never read downstream)
+//   k_rle_ends + k_rle_to_dense   run lengths -> run ends (KBs) -> n*W*H dense bytes
+//   k_rle_erode_pack  streams the run lengths (KBs), writes only the rectangle of packed words that can
+//                     hold an eroded pixel (rows/words outside a mask's bbox are never read downstream);
+//                     latency-bound, one workgroup per mask
 // A tile of packed rows (plus a one-word halo column on each side) lives in LDS; the erosion is
 // 9 word reads + shifts per output word; out-of-image neighbours count as set (cv2's border rule).
 #include "common.h"

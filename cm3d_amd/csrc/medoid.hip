@@ -7,9 +7,10 @@
 // (the expansion's cancellation error at global-frame magnitudes is part
 // of the reference's behaviour and is reproduced, not fixed.)
 // Column j lives in one thread and is summed over rows i in ascending order, so the float32
-// column sums do not depend on the launch geometry.  A tile = 256 columns of one mask; rows are
-// staged through LDS 64 at a time and read back as wave-wide broadcasts.  VALU-bound
-// (about 20 ops per pair incl. the IEEE sqrt); nothing M x M ever touches HBM.
+// column sums do not depend on the launch geometry.  A tile = 64 columns of one mask = one wave; rows are
+// staged through LDS 512 at a time and read back as wave-wide broadcasts, 8 rows per step in packed
+// float32.  VALU-bound (about 14 issue slots per pair incl. the correctly rounded sqrt); nothing M x M ever
+// touches HBM.  The tiles are worked longest lists first (worklist.h).
 #include "common.h"
 #include "worklist.h"
 #include <stdlib.h>
