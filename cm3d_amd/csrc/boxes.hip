@@ -67,9 +67,11 @@ __global__ __launch_bounds__(LG_BUILD_THREADS) void k_lane_grid_build(const floa
         if (!(mxx >= mnx)) { mnx = mny = 0.f; mxx = mxy = 0.f; }      // empty table
         float h = LG_CELL0;
         const float ex = mxx - mnx, ey = mxy - mny;
-        while ((double)(floorf(ex / h) + 1.f) * (double)(floorf(ey / h) + 1.f) > (double)LG_MAX_CELLS) h *= 1.25f;
+        while ((double)(floorf(ex / h) + 2.f) * (double)(floorf(ey / h) + 1.f) > (double)LG_MAX_CELLS) h *= 1.25f;
         g.x0 = mnx; g.y0 = mny; g.h = h; g.inv_h = 1.0f / h;
         g.gw = (int)floorf(ex / h) + 1; g.gh = (int)floorf(ey / h) + 1;
+        g.gw |= 1;      // odd row stride (at most one empty column more): consecutive points of a lane running along y
+                        // fall into cells gw apart, and a stride that is a multiple of 32 would put them all into one LDS bank
         g.cell_base = t * (LG_MAX_CELLS + 1);
         // points are binned with float32 arithmetic: a point can sit in the neighbouring cell of its
         // exact position by a few ulp of the coordinate magnitude; the ring bound gives that much away
