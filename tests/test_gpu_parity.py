@@ -112,6 +112,13 @@ def test_a_thousand_masks_in_a_frame(oracle):
     _compare(hb, got, exp)
 
 
+def test_many_small_frames(oracle):
+    """1200 small frames in one batch (grid dimensions, per-frame workgroups, offsets across many frames)."""
+    hb, got, exp = _run("tiny", 1200, "rle", oracle)
+    assert exp["hit_idx"].size > 50000
+    _compare(hb, got, exp)
+
+
 def test_ragged_batch(oracle):
     """Frames with different point counts and mask counts in one batch, incl. a frame whose masks are all empty."""
     import torch
