@@ -23,6 +23,7 @@ from . import synthetic as syn
 
 CAM_LIST = ["CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_BACK_RIGHT", "CAM_BACK", "CAM_BACK_LEFT", "CAM_FRONT_LEFT"]
 TABLES = ["scene", "sample", "sample_data", "ego_pose", "calibrated_sensor", "sensor", "log"]
+ANNOTATION_TABLES = ["category", "attribute", "instance", "sample_annotation"]       # only the evaluation harness needs them
 
 
 class NuscTables:
@@ -34,6 +35,15 @@ class NuscTables:
             with open(os.path.join(base, name + ".json")) as f:
                 rows = json.load(f)
             self.t[name] = {r["token"]: r for r in rows}
+        for name in ANNOTATION_TABLES:
+            fn = os.path.join(base, name + ".json")
+            if os.path.exists(fn):
+                with open(fn) as f:
+                    self.t[name] = {r["token"]: r for r in json.load(f)}
+        # sample['anns'] like the devkit builds it
+        self.anns_of = {}
+        for ann in self.t.get("sample_annotation", {}).values():
+            self.anns_of.setdefault(ann["sample_token"], []).append(ann["token"])
         sensors = self.t["sensor"]
         cs = self.t["calibrated_sensor"]
         # sample['data'][channel] like the devkit builds it: key frames only
@@ -62,6 +72,10 @@ class NuscTables:
             out.append(s)
             tok = s["next"]
         return out
+
+    def category_name(self, ann):
+        """the devkit's reverse-indexed `category_name` of a sample_annotation row"""
+        return self.get("category", self.get("instance", ann["instance_token"])["category_token"])["name"]
 
     def location(self, scene):
         return self.get("log", scene["log_token"])["location"]
@@ -142,8 +156,16 @@ def write_synthetic_dataset(root, cfg: syn.SyntheticConfig, n_scenes=2, frames_p
     os.makedirs(os.path.join(dataroot, version), exist_ok=True)
     os.makedirs(os.path.join(dataroot, "sweeps", "LIDAR_TOP"), exist_ok=True)
     os.makedirs(os.path.join(dataroot, "lanes"), exist_ok=True)
-    tabs = {k: [] for k in TABLES}
+    tabs = {k: [] for k in TABLES + ANNOTATION_TABLES}
     tok = lambda kind, *a: f"{kind}-" + "-".join(str(x) for x in a)
+    # ground truth of the synthetic objects (evaluation harness): one category per detection class
+    category_of = {"car": "vehicle.car", "truck": "vehicle.truck", "bus": "vehicle.bus.rigid", "trailer": "vehicle.trailer",
+                   "construction_vehicle": "vehicle.construction", "pedestrian": "human.pedestrian.adult",
+                   "motorcycle": "vehicle.motorcycle", "bicycle": "vehicle.bicycle", "traffic_cone": "movable_object.trafficcone",
+                   "barrier": "movable_object.barrier"}
+    for cat in sorted(set(category_of.values())):
+        tabs["category"].append({"token": tok("cat", cat), "name": cat})
+    from .lifting import get_detection_name
     for ch in ["LIDAR_TOP"] + CAM_LIST:
         tabs["sensor"].append({"token": tok("sensor", ch), "channel": ch, "modality": "lidar" if ch == "LIDAR_TOP" else "camera"})
     names = []
@@ -160,7 +182,7 @@ def write_synthetic_dataset(root, cfg: syn.SyntheticConfig, n_scenes=2, frames_p
             if first_center is None:
                 first_center = fr.ego_xyz[:2].copy()
             st = sample_tokens[f]
-            tabs["sample"].append({"token": st, "scene_token": tok("scene", s), "timestamp": f,
+            tabs["sample"].append({"token": st, "scene_token": tok("scene", s), "timestamp": 500000 * f,
                                    "prev": sample_tokens[f - 1] if f else "", "next": sample_tokens[f + 1] if f + 1 < frames_per_scene else ""})
             # lidar sweeps: a `next`-linked chain, the first one is the key frame
             for k, (raw, xf) in enumerate(zip(fr.sweeps_raw, fr.sweep_xf)):
@@ -190,6 +212,17 @@ def write_synthetic_dataset(root, cfg: syn.SyntheticConfig, n_scenes=2, frames_p
                 tabs["sample_data"].append({"token": tok("sd", s, f, ch), "sample_token": st, "ego_pose_token": ept,
                                             "calibrated_sensor_token": cst, "filename": f"samples/{ch}/{name}_{f}.jpg",
                                             "is_key_frame": True, "next": "", "prev": ""})
+            for j, obj in enumerate(fr.meta.get("objects", [])):
+                det = get_detection_name(obj["label"])
+                if det not in category_of:
+                    continue
+                itok = tok("inst", s, f, j)          # synthetic objects are redrawn every frame: one instance per annotation
+                tabs["instance"].append({"token": itok, "category_token": tok("cat", category_of[det]), "nbr_annotations": 1,
+                                         "first_annotation_token": tok("ann", s, f, j), "last_annotation_token": tok("ann", s, f, j)})
+                tabs["sample_annotation"].append({"token": tok("ann", s, f, j), "sample_token": st, "instance_token": itok,
+                                                  "attribute_tokens": [], "translation": obj["center"], "size": obj["size"],
+                                                  "rotation": [1.0, 0.0, 0.0, 0.0], "prev": "", "next": "",
+                                                  "num_lidar_pts": 10, "num_radar_pts": 0, "visibility_token": "4"})
             with open(os.path.join(mask_dir, name, f"{f}_masks.pkl"), "wb") as fh:
                 pickle.dump(fr.rles, fh)
             with open(os.path.join(mask_dir, name, f"{f}_data.json"), "w") as fh:

@@ -226,7 +226,23 @@ def make_frame(cfg: SyntheticConfig, index: int) -> Frame:
         rles[n - 2] = {"size": [W, H], "counts": rlemod.counts_to_string(_ellipse_rle(W * 0.5, H * 0.55, 1.0, 1.0, W, H))}
     return Frame(token=f"synthetic-{cfg.seed}-{index:06d}", sweeps_raw=sweeps_raw, sweep_xf=np.stack(sweep_xf),
                  cams=cams, rles=rles, labels=labels, scores=scores, cam_nums=cam_nums,
-                 ego_xyz=ego_t.copy(), width=W, height=H, meta={"ego_yaw": ego_yaw})
+                 ego_xyz=ego_t.copy(), width=W, height=H,
+                 meta={"ego_yaw": ego_yaw, "objects": _ground_truth_objects(objects, obj_of_mask, cls, sweep_xf[0])})
+
+
+def _ground_truth_objects(objects, obj_of_mask, cls, xf0):
+    """The synthetic cylinders as ground-truth boxes in the global frame of the key sweep: what an annotator would have
+    drawn (centre, size w = l = diameter, h, class of the first mask that shows the object).  Used by the synthetic
+    dataset writer to emit sample_annotation rows for the evaluation harness; draws no random numbers."""
+    xf0 = np.asarray(xf0, np.float64)
+    R_cs, t_cs, R_ego, t_ego = xf0[0:9].reshape(3, 3), xf0[9:12], xf0[12:21].reshape(3, 3), xf0[21:24]
+    out = []
+    for j, (oa, od, orad, oh) in enumerate(objects):
+        first = next(i for i, o in enumerate(obj_of_mask) if o == j)
+        p_s = np.array([od * np.cos(oa), od * np.sin(oa), -1.84 + 0.5 * oh])
+        p_g = R_ego @ (R_cs @ p_s + t_cs) + t_ego
+        out.append({"center": p_g.tolist(), "size": [2.0 * orad, 2.0 * orad, float(oh)], "label": PRODUCER_LABELS[int(cls[first])]})
+    return out
 
 
 def make_waymo_frame(cfg: SyntheticConfig, index: int):

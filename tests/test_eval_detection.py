@@ -1,0 +1,128 @@
+"""CPU: the detection evaluation harness against hand-computed
+known answers and on the synthetic dataset.  The reference module needs nuscenes-devkit at import time, so there
+is no golden vector for it (parity unpinned, see the module docstring)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from cm3d_amd import eval_detection as ev
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _boxes(per_sample):
+    out = ev.EvalBoxes()
+    for tok, rows in per_sample.items():
+        out.add_boxes(tok, [ev._box(tok, r["t"], r.get("size", (2, 4, 1.5)), r.get("rot", (1, 0, 0, 0)), r.get("vel", (0, 0)), 5,
+                                    r.get("name", "car"), r.get("score", -1.0), r.get("attr", "")) for r in rows])
+    return out
+
+
+def test_matching_precision_recall_and_ap_by_hand():
+    gt = _boxes({"s": [{"t": (0, 0, 0)}, {"t": (10, 0, 0)}]})
+    pred = _boxes({"s": [{"t": (0.3, 0, 0), "score": 0.9}, {"t": (5, 5, 0), "score": 0.8}, {"t": (10.2, 0, 0), "score": 0.7}]})
+    md, rec_actual = ev.accumulate_object_class(gt, pred, None, 2.0)
+    rec2, md2 = ev.accumulate_with_recall(gt, pred, "car", None, 2.0)
+    assert rec_actual == 1.0 and rec2 == 1.0 and np.array_equal(md.precision, md2.precision)
+    # tp = 1,0,1 -> precision 1, 1/2, 2/3 at recall 1/2, 1/2, 1: below recall 0.5 the curve is 1, at 0.5 it drops to 0.5
+    # and rises linearly to 2/3 at recall 1
+    r = np.linspace(0, 1, 101)
+    want = np.where(r < 0.5, 1.0, 0.5 + (r - 0.5) / 0.5 * (2.0 / 3.0 - 0.5))
+    assert np.allclose(md.precision, want, atol=1e-12)
+    ap = ev.calc_ap(md, 0.1, 0.1)
+    assert abs(ap - np.mean(np.maximum(want[11:] - 0.1, 0.0)) / 0.9) < 1e-12
+    # translation error of the matches: 0.3 then mean(0.3, 0.2); aligned with the confidence curve
+    assert abs(md.trans_err[md.max_recall_ind] - 0.25) < 1e-9
+    assert abs(ev.calc_tp(md, 0.1, "trans_err") - float(np.mean(md.trans_err[11:md.max_recall_ind + 1]))) < 1e-12
+    # a tighter threshold loses the 0.3 m match but keeps the 0.2 m one
+    md_t, rec_t = ev.accumulate_object_class(gt, pred, None, 0.25)
+    assert rec_t == 0.5
+
+
+def test_greedy_matching_takes_ground_truth_once_and_respects_classes():
+    gt = _boxes({"a": [{"t": (0, 0, 0), "name": "car"}], "b": [{"t": (0, 0, 0), "name": "pedestrian"}]})
+    pred = _boxes({"a": [{"t": (0.1, 0, 0), "score": 0.5, "name": "car"}, {"t": (0.0, 0, 0), "score": 0.9, "name": "car"}],
+                   "b": [{"t": (0, 0.1, 0), "score": 0.7, "name": "car"}]})
+    md, rec = ev.accumulate_object_class(gt, pred, None, 1.0)          # class-agnostic: both GT found, one duplicate is a FP
+    assert rec == 1.0
+    rec_car, _ = ev.accumulate_with_recall(gt, pred, "car", None, 1.0)
+    rec_ped, md_ped = ev.accumulate_with_recall(gt, pred, "pedestrian", None, 1.0)
+    assert rec_car == 1.0 and rec_ped == 0 and np.all(md_ped.precision == 0)
+    # no ground truth at all
+    md0, rec0 = ev.accumulate_object_class(_boxes({"a": []}), pred, None, 1.0)
+    assert rec0 == 0 and np.all(md0.trans_err == 1)
+
+
+def test_per_match_measures():
+    c, s = np.cos(0.25), np.sin(0.25)          # yaw 0.5 as a quaternion about z
+    a = ev._box("s", (0, 0, 0), (2, 4, 1), (1, 0, 0, 0), (1.0, 0.0), attribute_name="vehicle.moving")
+    b = ev._box("s", (3, 4, 9), (1, 4, 2), (c, 0, 0, s), (0.0, 2.0), attribute_name="vehicle.parked")
+    assert ev.center_distance(a, b) == 5.0 and abs(ev.velocity_l2(a, b) - np.sqrt(5)) < 1e-12
+    assert abs(ev.scale_iou(a, b) - 4.0 / (8 + 8 - 4)) < 1e-12
+    assert abs(ev.yaw_diff(a, b) - 0.5) < 1e-12
+    flipped = ev._box("s", (0, 0, 0), (2, 4, 1), (np.cos((np.pi + 0.1) / 2), 0, 0, np.sin((np.pi + 0.1) / 2)))
+    assert abs(ev.yaw_diff(a, flipped, period=np.pi) - 0.1) < 1e-9 and abs(ev.yaw_diff(a, flipped) - (np.pi - 0.1)) < 1e-9
+    assert ev.attr_acc(a, b) == 0.0 and np.isnan(ev.attr_acc(ev._box("s", (0, 0, 0), (1, 1, 1), (1, 0, 0, 0)), b))
+    assert np.allclose(ev.cummean(np.array([1.0, np.nan, 3.0])), [1.0, 1.0, 2.0]) and np.all(ev.cummean(np.array([np.nan])) == 1)
+    assert ev.category_to_detection_name("human.pedestrian.child") == "pedestrian"
+    assert ev.category_to_detection_name("human.pedestrian.child", rare=True) == "child"
+    assert ev.category_to_detection_name("animal") is None
+
+
+@pytest.fixture()
+def synthetic_eval(tmp_path, oracle):
+    from cm3d_amd import lifting, nusc_io, synthetic as syn
+    from tests.helpers import oracle_results
+    cfg = syn.config("tiny")
+    dataroot, mask_dir, names = nusc_io.write_synthetic_dataset(str(tmp_path), cfg, n_scenes=1, frames_per_scene=3)
+    tables = nusc_io.NuscTables("v1.0-synth", dataroot)
+    scene = tables.scene_by_name(names[0])
+    frames = nusc_io.frames_of_scene(tables, scene, mask_dir, n_sweeps=3, ratio=cfg.ratio)
+    lanes = [nusc_io.load_lane_points(dataroot, tables.location(scene))]
+    results = oracle_results(oracle, frames, lanes, [0] * len(frames))
+    path = tmp_path / "pseudolabels.json"
+    json.dump({"meta": {"use_lidar": False}, "results": results}, open(path, "w"))
+    return tables, dataroot, str(path), tmp_path
+
+
+def test_ground_truth_against_itself_is_perfect(synthetic_eval):
+    tables, dataroot, _, tmp = synthetic_eval
+    gt = ev.load_gt(tables)
+    assert len(gt.all) > 10 and all(b["num_pts"] == 10 for b in gt.all)
+    perfect = {tok: [dict(sample_token=tok, translation=b["translation"], size=b["size"], rotation=b["rotation"], velocity=[0, 0],
+                          detection_name=b["detection_name"], detection_score=0.5 + 0.001 * i, attribute_name="")
+                     for i, b in enumerate(boxes)] for tok, boxes in gt.boxes.items()}
+    path = tmp / "perfect.json"
+    json.dump({"meta": {}, "results": perfect}, open(path, "w"))
+    for object_only in (True, False):
+        de = ev.DetectionEval(tables, ev.config_factory(), str(path), None, str(tmp / "out"), False, object_only, verbose=False)
+        summary = de.main()
+        n_in_range = len(de.gt_boxes.all)
+        assert 0 < n_in_range <= len(gt.all)
+        aps = [v for name, v in summary["mean_dist_aps"].items() if any(b["detection_name"] == name or object_only for b in de.gt_boxes.all)]
+        assert aps and all(abs(a - 1.0) < 1e-9 for a in aps)
+        present = ["object"] if object_only else sorted({b["detection_name"] for b in de.gt_boxes.all})
+        for name in present:          # (classes without ground truth keep the devkit's error of 1)
+            assert summary["label_tp_errors"][name]["trans_err"] < 1e-9 and summary["label_tp_errors"][name]["scale_err"] < 1e-9
+
+
+def test_pseudo_labels_on_the_synthetic_scene(synthetic_eval):
+    tables, dataroot, result_path, tmp = synthetic_eval
+    de = ev.DetectionEval(tables, ev.config_factory(), result_path, None, str(tmp / "metrics"), False, True, verbose=False)
+    summary = de.main()
+    # the tiny synthetic scene (3000-point sweeps, random extra masks, duplicates) is no accuracy benchmark: the
+    # check is that real pseudo-labels flow through matching, AP and the TP metrics and find some of the objects
+    assert 0.02 < summary["mean_dist_aps"]["object"] <= 1.0 and 0.0 < summary["mean_recall"] <= 1.0
+    assert 0.0 <= summary["tp_errors"]["trans_err"] < 2.0
+    assert 0.0 <= summary["nd_score"] <= 1.0 and os.path.exists(tmp / "metrics" / "metrics_summary.json")
+    # the command-line entry point gives the same numbers
+    r = subprocess.run([sys.executable, "eval_custom.py", result_path, "--output_dir", str(tmp / "cli"), "--dataroot", dataroot,
+                        "--version", "v1.0-synth", "--object_only", "1", "--verbose", "0"],
+                       cwd=os.path.join(ROOT, "src", "nuscenes"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cli = json.load(open(tmp / "cli" / "metrics_summary.json"))
+    assert abs(cli["mean_ap"] - summary["mean_ap"]) < 1e-12
