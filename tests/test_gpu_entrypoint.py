@@ -50,6 +50,14 @@ def test_nuscenes_entry_point_end_to_end(tmp_path, oracle):
     assert n_boxes > 10
     last = tables.samples_of_scene(tables.scene_by_name(names[1]))[2]["token"]
     assert got["results"][last] == []
+    # f3: the evaluation entry point on the file the lifting entry point just wrote
+    r = subprocess.run([sys.executable, "eval_custom.py", str(out_dir / "pseudolabels_minival.json"), "--output_dir", str(tmp_path / "metrics"),
+                        "--dataroot", dataroot, "--version", "v1.0-synth", "--object_only", "1"],
+                       cwd=os.path.join(ROOT, "src", "nuscenes"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "NDS:" in r.stdout and "object" in r.stdout
+    summary = json.load(open(tmp_path / "metrics" / "metrics_summary.json"))
+    assert 0.0 < summary["mean_ap"] <= 1.0
 
 
 def test_waymo_entry_point(tmp_path, oracle):
