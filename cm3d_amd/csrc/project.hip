@@ -464,11 +464,12 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
 {
     const int row0 = tile_work ? 1 : 0;
     if (tile_work && blockIdx.y == 0) {
-        // extra row of the grid, dispatched first: one workgroup builds the medoid stage's work list from the
-        // offsets the previous launch wrote, beside (and hidden under) the compaction of the hit words
+        // extra row of the grid, dispatched first: its workgroups build the medoid stage's work list from the offsets
+        // the previous launch wrote (each its own share, without talking to each other), beside -- and hidden under --
+        // the compaction of the hit words
         __shared__ int s_hist[MD_CLASSES], s_cur[MD_CLASSES];
-        if (blockIdx.x == 0)
-            md_build_worklist<PH_THREADS>(n_masks, hit_off, tile_off, idx_cap, tile_cap, tile_work, s_hist, s_cur);
+        md_build_worklist<PH_THREADS, 2>(n_masks, hit_off, tile_off, idx_cap, tile_cap, tile_work, s_hist, s_cur, (int)blockIdx.x,
+                                      (int)gridDim.x);
         return;
     }
     const int f = (int)blockIdx.y - row0, chunk = blockIdx.x;

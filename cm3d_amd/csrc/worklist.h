@@ -31,7 +31,7 @@ static __device__ __forceinline__ void md_class_sums(int nt, int (&sum)[MD_CLASS
         const int cls = nt > MD_UNI ? md_class(nt) : -1;
 #pragma unroll
         for (int c = MD_UNI; c < MD_CLASSES; ++c)
-            if (__ballot(cls == c)) sum[c] += cm3d_wave_sum(cls == c ? nt : 0);
+            if (__ballot(cls == c)) sum[c] += __builtin_amdgcn_readfirstlane(cm3d_wave_sum(cls == c ? nt : 0));   // keeps sum[] in SGPRs
     }
 }
 
@@ -42,22 +42,79 @@ static inline int64_t md_tile_cap(int32_t n_masks, int32_t idx_cap)
 }
 
 // s_hist / s_cur: MD_CLASSES ints of LDS each.  Contains workgroup barriers: call with all NT threads.
-template <int NT>
+// The list can be built by `nparts` workgroups that never talk to each other: masks are cut into slots of NT
+// consecutive masks, workgroup `part` places the masks of a contiguous run of slots.  Every workgroup counts ALL
+// masks (class totals -> where each class starts; the counts of the slots before its own -> where its share of a
+// class starts), which costs n_masks loads from L2, and writes only its own share.
+template <int NT, int PER = MD_DESC_PER>
 static __device__ __forceinline__ void md_build_worklist(int n_masks, const int32_t *__restrict__ hit_off,
                                                          const int32_t *__restrict__ tile_off, int idx_cap, int tile_cap,
-                                                         TileDesc *__restrict__ desc, int *s_hist, int *s_cur)
+                                                         TileDesc *__restrict__ desc, int *s_hist, int *s_cur, int part = 0,
+                                                         int nparts = 1)
 {
     const int lane = cm3d_lane();
-    if (threadIdx.x < MD_CLASSES) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x < MD_CLASSES) { s_hist[threadIdx.x] = 0; s_cur[threadIdx.x] = 0; }
     __syncthreads();
-    const bool one_round = n_masks <= NT * MD_DESC_PER;       // then a thread keeps its masks in registers
-    int t0[MD_DESC_PER], nt[MD_DESC_PER], off[MD_DESC_PER], M[MD_DESC_PER];
-    auto load_round = [&](int mb) {
+    const int nslots = (n_masks + NT - 1) / NT;
+    const int per_part = (nslots + nparts - 1) / nparts;
+    const int slot0 = part * per_part, slot1 = min(nslots, slot0 + per_part);      // this workgroup's slots
+    auto tiles_of = [&](int m) {                        // tile count of mask m (0 past the end)
+        if (m >= n_masks) return 0;
+        const int a = tile_off[m];
+        return max(0, min(tile_off[m + 1], tile_cap) - a);
+    };
+    // pass 1: tiles per class -- of all masks (s_hist) and of the masks in the slots before this workgroup's (s_cur)
+    int wsum[MD_CLASSES], wbefore[MD_CLASSES], wmine[MD_CLASSES];
 #pragma unroll
-        for (int q = 0; q < MD_DESC_PER; ++q) {
-            const int m = mb + q * NT + (int)threadIdx.x;
+    for (int c = 0; c < MD_CLASSES; ++c) { wsum[c] = 0; wbefore[c] = 0; wmine[c] = 0; }
+    for (int g0 = 0; g0 < nslots; g0 += PER) {
+        int nt[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) nt[q] = tiles_of((g0 + q) * NT + (int)threadIdx.x);      // loads in flight together
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int g = g0 + q;
+            if (g >= nslots) continue;                   // uniform
+            if (g < slot0) md_class_sums(nt[q], wbefore);
+            else if (g < slot1) md_class_sums(nt[q], wmine);
+            else md_class_sums(nt[q], wsum);
+        }
+    }
+    if (lane < MD_CLASSES) {
+        int all = 0, before = 0;
+#pragma unroll
+        for (int c = 0; c < MD_CLASSES; ++c) {
+            all = lane == c ? wsum[c] + wbefore[c] + wmine[c] : all;
+            before = lane == c ? wbefore[c] : before;
+        }
+        if (all) atomicAdd(&s_hist[lane], all);
+        if (before) atomicAdd(&s_cur[lane], before);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = MD_CLASSES - 1; c >= 0; --c) { const int n = s_hist[c]; s_cur[c] += run; run += n; }     // longest lists first
+    }
+    __syncthreads();
+    // pass 2 (own slots only): the wave reserves its share of every class with one atomic, positions inside it are
+    // ballot ranks
+    int wbase[MD_CLASSES];
+    {
+        int mine = 0;
+#pragma unroll
+        for (int c = 0; c < MD_CLASSES; ++c) mine = lane == c ? wmine[c] : mine;
+        int got = 0;
+        if (lane < MD_CLASSES && mine) got = atomicAdd(&s_cur[lane], mine);
+#pragma unroll
+        for (int c = 0; c < MD_CLASSES; ++c) wbase[c] = __builtin_amdgcn_readlane(got, c);
+    }
+    for (int g0 = slot0; g0 < slot1; g0 += PER) {
+        int t0[PER], nt[PER], off[PER], M[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int m = (g0 + q) * NT + (int)threadIdx.x;
             t0[q] = 0; nt[q] = 0; off[q] = 0; M[q] = 0;
-            if (m < n_masks) {
+            if (g0 + q < slot1 && m < n_masks) {
                 t0[q] = tile_off[m];
                 nt[q] = tile_off[m + 1];
                 off[q] = hit_off[m];
@@ -65,52 +122,14 @@ static __device__ __forceinline__ void md_build_worklist(int n_masks, const int3
             }
         }
 #pragma unroll
-        for (int q = 0; q < MD_DESC_PER; ++q) {
+        for (int q = 0; q < PER; ++q) {
             nt[q] = max(0, min(nt[q], tile_cap) - t0[q]);
             M[q] -= off[q];
             if (off[q] + M[q] > idx_cap) M[q] = max(0, idx_cap - off[q]);     // index capacity overflow: stay in bounds
         }
-    };
-    // pass 1: tiles per class
-    int wsum[MD_CLASSES];
 #pragma unroll
-    for (int c = 0; c < MD_CLASSES; ++c) wsum[c] = 0;
-    for (int mb = 0; mb < n_masks; mb += NT * MD_DESC_PER) {
-        load_round(mb);
-#pragma unroll
-        for (int q = 0; q < MD_DESC_PER; ++q) {
-            if (mb + q * NT >= n_masks) break;                 // uniform: no mask in this slot for any thread
-            md_class_sums(nt[q], wsum);
-        }
-    }
-    if (lane < MD_CLASSES) {
-        int mine = 0;
-#pragma unroll
-        for (int c = 0; c < MD_CLASSES; ++c) mine = lane == c ? wsum[c] : mine;
-        if (mine) atomicAdd(&s_hist[lane], mine);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int c = MD_CLASSES - 1; c >= 0; --c) { s_cur[c] = run; run += s_hist[c]; }     // longest lists first
-    }
-    __syncthreads();
-    // pass 2: the wave reserves its share of every class with one atomic, positions inside it are ballot ranks
-    int wbase[MD_CLASSES];
-    {
-        int mine = 0;
-#pragma unroll
-        for (int c = 0; c < MD_CLASSES; ++c) mine = lane == c ? wsum[c] : mine;
-        int got = 0;
-        if (lane < MD_CLASSES && mine) got = atomicAdd(&s_cur[lane], mine);
-#pragma unroll
-        for (int c = 0; c < MD_CLASSES; ++c) wbase[c] = __builtin_amdgcn_readlane(got, c);
-    }
-    for (int mb = 0; mb < n_masks; mb += NT * MD_DESC_PER) {
-        if (!one_round) load_round(mb);
-#pragma unroll
-        for (int q = 0; q < MD_DESC_PER; ++q) {
-            if (mb + q * NT >= n_masks) break;                 // uniform
+        for (int q = 0; q < PER; ++q) {
+            if (g0 + q >= slot1) continue;               // uniform
             int pos = 0;
 #pragma unroll
             for (int c = 0; c < MD_UNI; ++c) {
@@ -130,7 +149,7 @@ static __device__ __forceinline__ void md_build_worklist(int n_masks, const int3
                 }
             }
             if (nt[q] <= 0) continue;
-            const int m = mb + q * NT + (int)threadIdx.x;
+            const int m = (g0 + q) * NT + (int)threadIdx.x;
             for (int jt = 0; jt < nt[q]; ++jt) desc[pos + jt] = TileDesc{m, off[q], M[q], jt, t0[q] + jt};
         }
     }
