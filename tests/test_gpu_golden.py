@@ -154,3 +154,28 @@ def test_medoid_sqrt_is_correctly_rounded_on_its_whole_domain():
     torch.cuda.synchronize()
     assert hi - lo > 1.6e9
     assert int(n_bad.item()) == 0, f"{int(n_bad.item())} mismatches, first at bits 0x{int(first.item()) & 0xFFFFFFFF:08x}"
+
+
+def test_integration_md_binding_runs_as_written(oracle):
+    """The ctypes stub printed in INTEGRATION.md (what a maintainer of the reference would paste next to 2d_to_3d.py) is
+    executed verbatim -- only the library path is filled in -- and must give the oracle's index lists."""
+    import os
+    import re
+    import torch
+    from cm3d_amd import _lib, synthetic as syn
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libcm3d_hip.so")', f'ctypes.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    cfg = syn.config("tiny")
+    fr = syn.make_frame(cfg, 11)
+    pts = np.concatenate([oracle.sweep_prep(r, x[0:9], x[9:12], x[12:21], x[21:24]) for r, x in zip(fr.sweeps_raw, fr.sweep_xf)], 0)
+    masks = np.stack([oracle.rle_decode(r).T for r in fr.rles])                     # (n,H,W) like depth_images (:425-428)
+    want, _, _ = oracle.lift_frame_reference_order(pts, fr.cams, list(masks), fr.cam_nums)
+    got = ns["points_in_all_masks"](torch.from_numpy(np.ascontiguousarray(pts.T)).cuda(), torch.from_numpy(fr.cams).cuda(),
+                                    torch.from_numpy(np.ascontiguousarray(masks * 153)).cuda(), fr.cam_nums)
+    assert len(got) == len(want) and sum(w.size for w in want) > 50
+    for g, w in zip(got, want):
+        assert np.array_equal(g.cpu().numpy(), w)
