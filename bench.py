@@ -241,12 +241,14 @@ def main():
                     "bounding-box test lets it skip most mask bytes, so `achieved` exceeds what HBM allows for a full read; "
                     "traffic_rate = measured HBM bytes / time; the kernel is instruction-issue bound")
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    per_kernel = {}
     if os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
             # the PMC passes were taken on the default workload; a different batch gets no traffic figure
             if args.frames == int(tr.get("frames_per_gpu", 256)) and not args.set:
-                roofline["traffic"] = tr.get(f"{args.config}_{main_mode}", {}).get("k_project_hits")
+                per_kernel = tr.get(f"{args.config}_{main_mode}", {})
+                roofline["traffic"] = per_kernel.get("k_project_hits")
             if roofline["traffic"]:
                 # what HBM actually moved per launch / time: the honest distance from the HBM roof (the kernel is
                 # bound by instruction issue; `frac` above is SURVEY 8(d)'s algorithmic figure)
@@ -257,10 +259,12 @@ def main():
             pass
     mask_kernel = "k_erode_pack" if main_mode == "dense" else "k_rle_erode_pack"
     kernels = {
-        "masks": roof(mask_kernel, "masks", r, mask_kernel, "HBM streaming"),
-        "sweeps": roof("k_sweep", "sweeps", r, "k_sweep_xform", "HBM streaming, one pass"),
+        "masks": roof(mask_kernel, "masks", r, mask_kernel, "latency-bound (one workgroup per mask); stage time incl. the launch boundary"),
+        "sweeps": roof("k_sweep", "sweeps", r, "k_sweep_xform", "HBM streaming, one pass; stage time incl. the launch boundary"),
         "stage_ms": {k: round(v, 4) for k, v in r["stage_ms"].items()},
     }
+    kernels["masks"]["traffic"] = per_kernel.get(mask_kernel)
+    kernels["sweeps"]["traffic"] = per_kernel.get("k_sweep_xform")
     out = {
         "metric": "pseudo-label frames/sec on nuScenes-shaped sweeps", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(r["dt"] / args.steps * 1e3, 4),
