@@ -35,6 +35,21 @@ static __device__ __forceinline__ void rot3_2(const float *R, f2 x, f2 y, f2 z, 
     ox = a; oy = b; oz = c;
 }
 
+// u = uh / zh and v = vh / zh for two points: the rcp + fma sequence hipcc emits for an IEEE float32 division,
+// without v_div_scale / v_div_fixup and with the refined reciprocal shared by both quotients (see project_pair).
+static __device__ __forceinline__ void ph_div_pair(f2 uh, f2 vh, f2 zh, f2 &u, f2 &v)
+{
+    f2 r = {__builtin_amdgcn_rcpf(zh.x), __builtin_amdgcn_rcpf(zh.y)};
+    const f2 e = PK_FMA(-zh, r, (f2)(1.0f));
+    r = PK_FMA(e, r, r);
+    f2 q = uh * r;
+    f2 t = PK_FMA(-zh, q, uh); q = PK_FMA(t, r, q);
+    t = PK_FMA(-zh, q, uh);    u = PK_FMA(t, r, q);
+    q = vh * r;
+    t = PK_FMA(-zh, q, vh);    q = PK_FMA(t, r, q);
+    t = PK_FMA(-zh, q, vh);    v = PK_FMA(t, r, q);
+}
+
 // Pinhole projection of TWO points through the reference's float32 op chain, branch-free and in packed
 // float32 (the kernel is instruction-issue bound).  Returns the pixel codes (iv << 16 | iu) or -1.
 // cm = camera record in LDS.
@@ -42,8 +57,9 @@ static __device__ __forceinline__ void rot3_2(const float *R, f2 x, f2 y, f2 z, 
 // straight-line code); NS < 0: read both from the record.
 // FASTDIV: u = uh/zh and v = vh/zh through the same rcp + fma sequence hipcc emits for an IEEE division, but
 // without v_div_scale / v_div_fixup and with the refined reciprocal shared by both quotients.  For zh in
-// [1e-30, 1e30) the scaling steps are the identity unless the quotient is < 2^-100 or > 2^96 in magnitude
-// (rejected by the range test either way), so accepted pixels are bit-identical; `redo` is set when a
+// [1e-30, 1e30) the scaling steps are the identity unless the quotient is > 2^96 in magnitude or the numerator is
+// below 2^-103 (quotient < 1/8) -- the range test rejects the point either way -- so accepted pixels are
+// bit-identical (cm3d_selftest_div: 4e9 pairs on the device, tests/test_gpu_golden.py); `redo` is set when a
 // lane that passes the depth test has zh outside that range, and the caller repeats the camera with the
 // true division.
 template <int NS, int FL, bool FASTDIV>
@@ -73,15 +89,7 @@ static __device__ __forceinline__ void project_pair(const float *cm, int ns_rt, 
     f2 zh = K[6] * ax; zh = PK_FMA((f2)(K[7]), ay, zh); zh = PK_FMA((f2)(K[8]), az, zh);
     f2 u, v;
     if (FASTDIV) {
-        f2 r = {__builtin_amdgcn_rcpf(zh.x), __builtin_amdgcn_rcpf(zh.y)};
-        const f2 e = PK_FMA(-zh, r, (f2)(1.0f));
-        r = PK_FMA(e, r, r);
-        f2 q = uh * r;
-        f2 t = PK_FMA(-zh, q, uh); q = PK_FMA(t, r, q);
-        t = PK_FMA(-zh, q, uh);    u = PK_FMA(t, r, q);
-        q = vh * r;
-        t = PK_FMA(-zh, q, vh);    q = PK_FMA(t, r, q);
-        t = PK_FMA(-zh, q, vh);    v = PK_FMA(t, r, q);
+        ph_div_pair(uh, vh, zh, u, v);
     } else {
         u = uh / zh; v = vh / zh;                             // IEEE division, any operand
     }
@@ -568,6 +576,56 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Diagnostic: pseudo-random (numerator, denominator) pairs -- denominators log-uniform over the shortcut's domain
+// [1e-30, 1e30), numerators log-uniform over +-[1e-38, 1e38] or small integers times the denominator +- a few ulp
+// (quotients next to integers are what floor() is sensitive to) -- through ph_div_pair and through the IEEE division.
+// n_bad[0] counts the pairs whose true quotient q has 1/8 <= |q| < 2^96 and differs in any bit: must stay 0.
+// n_bad[1] counts differing pairs with |q| < 1/8 (a numerator below 2^-103, where v_div_scale would have rescaled):
+// both quotients are then below 1 in magnitude and the pixel range test rejects the point either way.
+__global__ __launch_bounds__(256) void k_selftest_div(uint64_t seed, uint64_t count, unsigned long long *n_bad)
+{
+    unsigned long long bad = 0, benign = 0;
+    uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1));
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    auto check = [&](float got, float want) {
+        if (__float_as_uint(got) == __float_as_uint(want)) return;
+        const float mag = fabsf(want);
+        if (mag >= 0.125f && mag < 7.9e28f) ++bad;
+        else if (mag < 0.125f && fabsf(got) < 1.0f) ++benign;
+        else if (mag < 0.125f) ++bad;                        // a small quotient that the shortcut made large: not benign
+    };
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t a = next(), b = next();
+        // denominator: exponent 28..226 (about 1e-30..1e30), random mantissa, positive
+        float den = __uint_as_float((uint32_t)((28 + (a % 199)) << 23) | (uint32_t)((a >> 20) & 0x7FFFFF));
+        if (!(den >= 1.0e-30f && den <= 9.99999e29f)) den = 2.5f;
+        float num;
+        if (b & 1) {                 // quotient near an integer: (k * den) +- a few ulp
+            const float k = (float)((b >> 8) % 4096);
+            const float tweak = __uint_as_float(__float_as_uint(k * den) + (int)((b >> 40) % 9) - 4);
+            num = (b & 2) ? -tweak : tweak;
+        } else {
+            num = __uint_as_float((uint32_t)((1 + ((b >> 8) % 253)) << 23) | (uint32_t)((b >> 20) & 0x7FFFFF) | (uint32_t)((b >> 1) & 1) << 31);
+        }
+        f2 u, v;
+        ph_div_pair((f2){num, -num}, (f2){num * 0.5f, num}, (f2){den, den}, u, v);
+        check(u.x, num / den); check(v.y, num / den); check(u.y, -num / den); check(v.x, (num * 0.5f) / den);
+    }
+    if (bad) atomicAdd(&n_bad[0], bad);
+    if (benign) atomicAdd(&n_bad[1], benign);
+}
+
+extern "C" int cm3d_selftest_div(uint64_t seed, uint64_t count, uint64_t *n_bad, cm3d_stream_t stream)
+{
+    if (!n_bad || count == 0) return CM3D_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(n_bad, 0, 2 * sizeof(uint64_t), st) != hipSuccess) return CM3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_selftest_div, dim3(8192), dim3(256), 0, st, seed, count, (unsigned long long *)n_bad);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
 }
 
 __global__ void k_batch_begin(int32_t *__restrict__ status, int32_t *__restrict__ hit_count, int n_masks,

@@ -169,6 +169,13 @@ int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_
                 const int32_t *tile_work, int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
                 int64_t workspace_bytes, cm3d_stream_t stream);
 
+/* Diagnostic for the tests: `count` pseudo-random (numerator, denominator) pairs, denominators over the projection
+ * kernel's shortcut domain [1e-30, 1e30), quotients next to integers over-represented, through the kernel's division
+ * sequence and through the IEEE division; n_bad (device, 2 words): [0] = differing quotients q with 1/8 <= |q| < 2^96
+ * (must be 0), [1] = differing quotients with |q| < 1/8 in both forms (numerators below 2^-103; the pixel range test
+ * rejects those points whatever the low bits are). */
+int cm3d_selftest_div(uint64_t seed, uint64_t count, uint64_t *n_bad, cm3d_stream_t stream);
+
 /* Diagnostic for the tests: runs every float32 bit pattern in [first_bits, last_bits] (positive values) that lies in
  * the medoid kernel's fast-path domain [1e-30, 1e30) through the kernel's square root, its reference form and sqrtf();
  * *n_bad (device) = number of values on which the three are not bit-identical, *first_bad = smallest such pattern. */

@@ -179,3 +179,18 @@ def test_integration_md_binding_runs_as_written(oracle):
     assert len(got) == len(want) and sum(w.size for w in want) > 50
     for g, w in zip(got, want):
         assert np.array_equal(g.cpu().numpy(), w)
+
+
+def test_projection_division_shortcut_equals_ieee_division():
+    """The projection kernel's division sequence (no v_div_scale / v_div_fixup, shared refined reciprocal) against the
+    IEEE division on 4e9 pseudo-random pairs over its domain, quotients next to integers over-represented."""
+    import torch
+    from cm3d_amd import _lib
+    L = _lib.lib()
+    n_bad = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for seed in (1, 2):
+        _lib.check(L.cm3d_selftest_div(seed, 2_000_000_000, n_bad.data_ptr(), torch.cuda.current_stream().cuda_stream), "cm3d_selftest_div")
+        torch.cuda.synchronize()
+        bad, benign = (int(v) for v in n_bad.cpu())
+        # [1]: numerators below 2^-103, both quotients below 1 in magnitude -- never an accepted pixel
+        assert bad == 0, f"{bad} quotients of magnitude >= 1/8 differ (seed {seed}); {benign} tiny ones"
