@@ -21,17 +21,26 @@ static __device__ __forceinline__ int md_class(int nt)
     return MD_UNI + (nt >= 10) + (nt >= 13) + (nt >= 17) + (nt >= 22) + (nt >= 29) + (nt >= 38) + (nt >= 50) + (nt >= 66);
 }
 
-// tiles of the wave's lanes per class (wave-uniform values).  Lanes of a class below MD_UNI all carry the same
-// tile count, so a ballot and a popcount give the class sum without touching memory.
-static __device__ __forceinline__ void md_class_sums(int nt, int (&sum)[MD_CLASSES])
+// Adds the tiles of the wave's lanes, class by class, to a LANE-DISTRIBUTED accumulator: lane c of `acc` holds the sum of
+// class c (one VGPR instead of MD_CLASSES scalar registers -- the builder shares a kernel with the compaction, whose
+// workgroups pay for every register the builder needs).  Lanes of a class below MD_UNI all carry the same tile
+// count, so a ballot and a popcount give the class sum without touching memory.
+static __device__ __forceinline__ void md_class_sums(int nt, int &acc)
 {
+    const int lane = cm3d_lane();
 #pragma unroll
-    for (int c = 0; c < MD_UNI; ++c) sum[c] += (int)__popcll(__ballot(nt == c + 1)) * (c + 1);
+    for (int c = 0; c < MD_UNI; ++c) {
+        const int x = (int)__popcll(__ballot(nt == c + 1)) * (c + 1);
+        acc += lane == c ? x : 0;
+    }
     if (__ballot(nt > MD_UNI)) {
         const int cls = nt > MD_UNI ? md_class(nt) : -1;
 #pragma unroll
-        for (int c = MD_UNI; c < MD_CLASSES; ++c)
-            if (__ballot(cls == c)) sum[c] += __builtin_amdgcn_readfirstlane(cm3d_wave_sum(cls == c ? nt : 0));   // keeps sum[] in SGPRs
+        for (int c = MD_UNI; c < MD_CLASSES; ++c) {
+            if (!__ballot(cls == c)) continue;
+            const int x = __builtin_amdgcn_readfirstlane(cm3d_wave_sum(cls == c ? nt : 0));
+            acc += lane == c ? x : 0;
+        }
     }
 }
 
@@ -64,9 +73,7 @@ static __device__ __forceinline__ void md_build_worklist(int n_masks, const int3
         return max(0, min(tile_off[m + 1], tile_cap) - a);
     };
     // pass 1: tiles per class -- of all masks (s_hist) and of the masks in the slots before this workgroup's (s_cur)
-    int wsum[MD_CLASSES], wbefore[MD_CLASSES], wmine[MD_CLASSES];
-#pragma unroll
-    for (int c = 0; c < MD_CLASSES; ++c) { wsum[c] = 0; wbefore[c] = 0; wmine[c] = 0; }
+    int wrest = 0, wbefore = 0, wmine = 0;              // lane c: tiles of class c (slots after / before / of this workgroup)
     for (int g0 = 0; g0 < nslots; g0 += PER) {
         int nt[PER];
 #pragma unroll
@@ -77,18 +84,13 @@ static __device__ __forceinline__ void md_build_worklist(int n_masks, const int3
             if (g >= nslots) continue;                   // uniform
             if (g < slot0) md_class_sums(nt[q], wbefore);
             else if (g < slot1) md_class_sums(nt[q], wmine);
-            else md_class_sums(nt[q], wsum);
+            else md_class_sums(nt[q], wrest);
         }
     }
     if (lane < MD_CLASSES) {
-        int all = 0, before = 0;
-#pragma unroll
-        for (int c = 0; c < MD_CLASSES; ++c) {
-            all = lane == c ? wsum[c] + wbefore[c] + wmine[c] : all;
-            before = lane == c ? wbefore[c] : before;
-        }
+        const int all = wrest + wbefore + wmine;
         if (all) atomicAdd(&s_hist[lane], all);
-        if (before) atomicAdd(&s_cur[lane], before);
+        if (wbefore) atomicAdd(&s_cur[lane], wbefore);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -98,16 +100,8 @@ static __device__ __forceinline__ void md_build_worklist(int n_masks, const int3
     __syncthreads();
     // pass 2 (own slots only): the wave reserves its share of every class with one atomic, positions inside it are
     // ballot ranks
-    int wbase[MD_CLASSES];
-    {
-        int mine = 0;
-#pragma unroll
-        for (int c = 0; c < MD_CLASSES; ++c) mine = lane == c ? wmine[c] : mine;
-        int got = 0;
-        if (lane < MD_CLASSES && mine) got = atomicAdd(&s_cur[lane], mine);
-#pragma unroll
-        for (int c = 0; c < MD_CLASSES; ++c) wbase[c] = __builtin_amdgcn_readlane(got, c);
-    }
+    int vbase = 0;                                      // lane c: next free position of class c in this wave's share
+    if (lane < MD_CLASSES && wmine) vbase = atomicAdd(&s_cur[lane], wmine);
     for (int g0 = slot0; g0 < slot1; g0 += PER) {
         int t0[PER], nt[PER], off[PER], M[PER];
 #pragma unroll
@@ -134,8 +128,9 @@ static __device__ __forceinline__ void md_build_worklist(int n_masks, const int3
 #pragma unroll
             for (int c = 0; c < MD_UNI; ++c) {
                 const uint64_t mk = __ballot(nt[q] == c + 1);
-                if (nt[q] == c + 1) pos = wbase[c] + cm3d_mbcnt(mk) * (c + 1);
-                wbase[c] += (int)__popcll(mk) * (c + 1);
+                if (!mk) continue;
+                if (nt[q] == c + 1) pos = __builtin_amdgcn_readlane(vbase, c) + cm3d_mbcnt(mk) * (c + 1);
+                vbase += lane == c ? (int)__popcll(mk) * (c + 1) : 0;
             }
             if (__ballot(nt[q] > MD_UNI)) {
                 const int cls = nt[q] > MD_UNI ? md_class(nt[q]) : -1;
@@ -144,8 +139,8 @@ static __device__ __forceinline__ void md_build_worklist(int n_masks, const int3
                     if (!__ballot(cls == c)) continue;
                     const int v = cls == c ? nt[q] : 0;
                     const int inc = cm3d_wave_incl_scan(v);
-                    if (v) pos = wbase[c] + inc - v;
-                    wbase[c] += __builtin_amdgcn_readlane(inc, 63);
+                    if (v) pos = __builtin_amdgcn_readlane(vbase, c) + inc - v;
+                    vbase += lane == c ? __builtin_amdgcn_readlane(inc, 63) : 0;
                 }
             }
             if (nt[q] <= 0) continue;
