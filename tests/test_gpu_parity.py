@@ -359,3 +359,28 @@ def test_kitti_pipeline(oracle):
     assert pred == pred_e and len(pred) == int((np.diff(exp["hit_off"][hb.mask_off[0]:hb.mask_off[1] + 1]) > 3).sum())
     f = pred[0].split()
     assert len(f) == 16 and f[1:8] == ["-1", "-1", "-10", "0", "0", "0", "0"] and len(pseudo[0].split()) == 15
+
+
+def test_graph_replay_equals_eager(oracle):
+    """One pass captured into a HIP graph (LiftEngine.capture_graph) gives the eager results, replay after replay."""
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config("tiny")
+    frames = [syn.make_frame(cfg, i) for i in range(4)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 2000, seed=1)]
+    hb = lifting.pack_frames(frames, lanes, [0] * 4)
+    eng = lifting.LiftEngine()
+    eng.upload(hb)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    eager = eng.download()
+    g = eng.capture_graph(masks="rle")
+    for _ in range(3):
+        eng.b.hit_idx.fill_(-7); eng.b.box.fill_(0)          # whatever the replay does not rewrite would show
+        g.replay()
+        torch.cuda.synchronize()
+        got = eng.download()
+        for k in eager:
+            assert np.array_equal(eager[k], got[k], equal_nan=True), k
+    exp = oracle_batch(oracle, frames, lanes, [0] * 4, hb)
+    _compare(hb, got, exp)
