@@ -281,6 +281,10 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
         "frame_alg_bytes": int(alg["frame_total"] // hb.n_frames),
+        # the whole pass against the HBM roof: SURVEY 8(d)'s end-to-end algorithmic bytes per frame x frames/s
+        "pass_roofline": {"bound": "hbm", "achieved": round(alg["frame_total"] / hb.n_frames * value / world / 1e9, 1), "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": round(alg["frame_total"] / hb.n_frames * value / world / 1e9 / HBM_PEAK_GBS, 4),
+                          "note": "per GPU; ALG_FRAME with the masks read in the form they are resident in"},
         "boxes_per_step": r["n_boxes"], "in_mask_points_per_step": r["sum_hits"], "max_points_in_a_mask": r["max_hits"],
         "gen_seconds": round(t_gen, 1),
     }
