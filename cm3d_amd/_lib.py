@@ -17,6 +17,8 @@ MAX_MASKS_PER_FRAME = 1024
 BOX_STRIDE = 10
 MEDOID_TILE = 64
 STATUS_WORDS = 4
+MAX_MATCH_BOXES = 1024
+MATCH_BOX_STRIDE = 6
 
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -46,6 +48,8 @@ SIGNATURES = {
     "cm3d_circle_nms": (_i32, [_p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p]),
     "cm3d_box_nms": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
     "cm3d_centroid_transform": (_i32, [_p, _p, _p, _i32, _p, _p, _p]),
+    "cm3d_bev_match_workspace_bytes": (_i64, [_i64]),
+    "cm3d_bev_match": (_i32, [_p, _p, _i32, _p, _p, _i32, _p, _i32, _i64, C.c_double, _p, _p, _p, _p, _p, _i64, _p]),
 }
 
 

@@ -221,3 +221,52 @@ def circle_nms(dets, det_labels, threshs_by_label):
     check(L.cm3d_circle_nms(x.data_ptr(), y.data_ptr(), sc.data_ptr(), lab.data_ptr(), off.data_ptr(), 1, thr.data_ptr(),
                             len(names), keep.data_ptr(), _st()), "cm3d_circle_nms")
     return np.flatnonzero(keep.cpu().numpy()).tolist()
+
+
+# ----------------------------------------------------------------------------- f4: SAM3D fusion matching
+def match_records(boxes7):
+    """(n,7) [center_x, center_y, bottom_z, length, width, height, heading] -> (n,6) float64 records of
+    cm3d_bev_match.  The values pass through float32 like `tf.convert_to_tensor(boxes, dtype=float)`
+    (linear_matching.py:248-249); cos/sin of the float32 heading are taken in float64 on the host."""
+    b = np.asarray(boxes7, np.float64).reshape(-1, 7).astype(np.float32).astype(np.float64)
+    return np.stack([b[:, 0], b[:, 1], b[:, 3], b[:, 4], np.cos(b[:, 6]), np.sin(b[:, 6])], axis=1)
+
+
+def bev_match(pred_boxes, gt_boxes, iou=0.2):
+    """`match(pred_boxes, sam3d_boxes, iou, Type.TYPE_2D)` (linear_matching.py:53-104) for a list of samples in one
+    GPU call.  pred_boxes / gt_boxes: lists (one entry per sample) of (n,7) arrays.  Returns one
+    (prediction_ids, groundtruth_ids, ious) triple per sample, matches in ascending prediction order."""
+    L = _lib.lib()
+    F = len(pred_boxes)
+    if F == 0:
+        return []
+    if len(gt_boxes) != F:
+        raise ValueError("bev_match: one gt entry per sample")
+    pr = [match_records(b) for b in pred_boxes]
+    gr = [match_records(b) for b in gt_boxes]
+    np_, ng = np.array([r.shape[0] for r in pr], np.int64), np.array([r.shape[0] for r in gr], np.int64)
+    if max(np_.max(), ng.max()) > _lib.MAX_MATCH_BOXES:
+        raise _lib.Cm3dError(f"bev_match: more than {_lib.MAX_MATCH_BOXES} boxes in a sample")
+    p_off = np.concatenate([[0], np.cumsum(np_)]).astype(np.int32)
+    g_off = np.concatenate([[0], np.cumsum(ng)]).astype(np.int32)
+    pair_off = np.concatenate([[0], np.cumsum(np_ * ng)]).astype(np.int64)
+    n_pred, n_gt, total = int(p_off[-1]), int(g_off[-1]), int(pair_off[-1])
+    d_p = _t(np.concatenate(pr).reshape(-1, 6) if n_pred else np.zeros((1, 6)), np.float64)
+    d_g = _t(np.concatenate(gr).reshape(-1, 6) if n_gt else np.zeros((1, 6)), np.float64)
+    d_po, d_go, d_pair = _t(p_off), _t(g_off), _t(pair_off)
+    pm, gm = _e(max(n_pred, 1)), _e(max(n_gt, 1))
+    miou = _e(max(n_pred, 1), dtype=torch.float64)
+    status = torch.zeros(1, dtype=torch.int32, device=_dev())
+    ws = _ws(L.cm3d_bev_match_workspace_bytes(total))
+    check(L.cm3d_bev_match(d_p.data_ptr(), d_po.data_ptr(), n_pred, d_g.data_ptr(), d_go.data_ptr(), n_gt, d_pair.data_ptr(), F,
+                           total, float(iou), pm.data_ptr(), gm.data_ptr(), miou.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                           ws.numel(), _st()), "cm3d_bev_match")
+    pm, miou = pm.cpu().numpy()[:n_pred], miou.cpu().numpy()[:n_pred]
+    if int(status.item()) != 0:
+        raise _lib.Cm3dError("cm3d_bev_match: a sample exceeded the box capacity")
+    out = []
+    for f in range(F):
+        m = pm[p_off[f]:p_off[f + 1]]
+        ids = np.flatnonzero(m >= 0)
+        out.append((ids.astype(np.int64), m[ids].astype(np.int64), miou[p_off[f]:p_off[f + 1]][ids]))
+    return out

@@ -43,6 +43,8 @@ extern "C" {
 #define CM3D_MAX_MASKS_PER_FRAME 1024
 #define CM3D_BOX_STRIDE 10       /* doubles per box record, see cm3d_box_nms           */
 #define CM3D_MEDOID_TILE 64      /* columns per medoid tile (one wave)                 */
+#define CM3D_MAX_MATCH_BOXES 1024 /* boxes per sample and side, see cm3d_bev_match    */
+#define CM3D_MATCH_BOX_STRIDE 6  /* doubles per box of cm3d_bev_match                  */
 
 /* status word written by kernels (int32[4] in device memory, zero it per batch):
  *  [0] bit0: point capacity overflow (cm3d_sweep_prep), bit1: hit-index capacity
@@ -236,6 +238,28 @@ int cm3d_centroid_transform(const float *centroid_in, const int32_t *medoid_pos,
 int cm3d_circle_nms(const double *x, const double *y, const double *score, const int32_t *label,
                     const int32_t *frame_off, int32_t n_frames, const double *nms_thr, int32_t n_classes,
                     int32_t *keep, cm3d_stream_t stream);
+
+/* ---- f4: box matching of the SAM3D fusion step ------------------------------------
+ * Replaces `match(pred_boxes, sam3d_boxes, 0.2, Type.TYPE_2D)` of src/nuscenes/linear_matching.py:53-121,
+ * called per sample at :231-259 (src/waymo/linear_matching.py:251-283 alike): waymo_open_dataset's
+ * py_metrics_ops.match with TYPE_HUNGARIAN -- bird's-eye-view IoU of rotated rectangles, quantised to
+ * integers (x 1e6), maximum-weight assignment, pairs with IoU < iou_thr dropped.  All samples in one call.
+ *  pred  double[n_pred][6]  cx, cy, length, width, cos(heading), sin(heading) -- the float32-rounded box
+ *        values of `tf.convert_to_tensor(..., dtype=float)` (:248-249) widened to double; a box with
+ *        length*width == 0 is "no box" (:65) and never matches
+ *  pred_off int32[F+1], gt_off int32[F+1]   sample f owns pred [pred_off[f], pred_off[f+1]) and
+ *        gt (SAM3D) boxes [gt_off[f], gt_off[f+1]); at most CM3D_MAX_MATCH_BOXES per sample and side
+ *        (status bit0 is set and the sample left unmatched otherwise)
+ *  pair_off int64[F+1]      prefix sums of P_f * G_f; total_pairs = pair_off[F]
+ *  pred_match int32[n_pred] OUT: index of the matched gt box inside its sample, or -1
+ *  gt_match   int32[n_gt]   OUT: index of the matched prediction inside its sample, or -1
+ *  match_iou  double[n_pred] OUT: IoU of the match (0 when unmatched)
+ *  status int32[1] (zero it before the call); workspace: cm3d_bev_match_workspace_bytes(total_pairs) */
+int64_t cm3d_bev_match_workspace_bytes(int64_t total_pairs);
+int cm3d_bev_match(const double *pred, const int32_t *pred_off, int32_t n_pred, const double *gt,
+                   const int32_t *gt_off, int32_t n_gt, const int64_t *pair_off, int32_t n_frames,
+                   int64_t total_pairs, double iou_thr, int32_t *pred_match, int32_t *gt_match, double *match_iou,
+                   int32_t *status, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream);
 
 #ifdef __cplusplus
 }

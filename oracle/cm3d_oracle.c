@@ -477,3 +477,141 @@ ORC_API void orc_box_assemble_waymo(const float *centroid_global, const float *p
     out_t[2] = c[2];
     *out_heading = atan2((double)pose_inv[4] * cs + (double)pose_inv[5] * sn, (double)pose_inv[0] * cs + (double)pose_inv[1] * sn);
 }
+
+/* ------------------------------------------------------------------ */
+/* f4: box matching of the SAM3D fusion step (src/nuscenes/linear_matching.py:53-121,231-259;
+ * src/waymo/linear_matching.py alike).  `match(pred, sam3d, 0.2, TYPE_2D)` is waymo_open_dataset's
+ * py_metrics_ops.match with TYPE_HUNGARIAN; its C++ is NOT in the reference checkout (pip dependency
+ * waymo-open-dataset-tf, src/nuscenes/requirements.txt) -> PARITY UNPINNED.  Restated from its published
+ * behaviour: IoU of the two rotated rectangles in the ground plane (convex polygon intersection), weight =
+ * (int)(iou * 1e6) when iou >= the type's threshold else 0, maximum-weight bipartite assignment (Hungarian
+ * method on cost = 1e6 - weight, padded to square with zero-weight edges), pairs with zero weight dropped.
+ * Where several assignments reach the maximum the third-party solver's choice is not known; this
+ * restatement resolves a step's tie by the lowest column index.
+ * box = cx, cy, length, width, cos(heading), sin(heading). */
+static void orc_bev_corners(const double *b, double ox, double oy, double *X, double *Y)
+{
+    const double hl = b[2] * 0.5, hw = b[3] * 0.5, c = b[4], s = b[5];
+    const double dx = b[0] - ox, dy = b[1] - oy;
+    const double lc = hl * c, ls = hl * s, wc = hw * c, wsn = hw * s;
+    X[0] = (dx + lc) - wsn; Y[0] = (dy + ls) + wc;
+    X[1] = (dx - lc) - wsn; Y[1] = (dy - ls) + wc;
+    X[2] = (dx - lc) + wsn; Y[2] = (dy - ls) - wc;
+    X[3] = (dx + lc) + wsn; Y[3] = (dy + ls) - wc;
+}
+
+ORC_API double orc_bev_iou(const double *a, const double *b)
+{
+    const double area_a = a[2] * a[3], area_b = b[2] * b[3];
+    if (!(area_a > 0.0) || !(area_b > 0.0)) return 0.0;
+    {
+        const double dx = b[0] - a[0], dy = b[1] - a[1];
+        const double ra2 = a[2] * a[2] + a[3] * a[3], rb2 = b[2] * b[2] + b[3] * b[3];
+        const double r = 0.5 * (sqrt(ra2) + sqrt(rb2));
+        if (dx * dx + dy * dy > r * r) return 0.0;
+    }
+    double px[12], py[12], qx[12], qy[12], bx[4], by[4];
+    orc_bev_corners(a, a[0], a[1], px, py);
+    orc_bev_corners(b, a[0], a[1], bx, by);
+    int n = 4;
+    for (int e = 0; e < 4 && n > 0; ++e) {      /* Sutherland-Hodgman: keep what lies left of edge e of b */
+        const double x1 = bx[e], y1 = by[e], ex = bx[(e + 1) & 3] - x1, ey = by[(e + 1) & 3] - y1;
+        int k = 0;
+        double prx = px[n - 1], pry = py[n - 1];
+        double dp = ex * (pry - y1) - ey * (prx - x1);
+        for (int i = 0; i < n; ++i) {
+            const double cx = px[i], cy = py[i];
+            const double dc = ex * (cy - y1) - ey * (cx - x1);
+            if ((dc >= 0.0) != (dp >= 0.0)) {
+                const double t = dp / (dp - dc);
+                qx[k] = prx + t * (cx - prx);
+                qy[k] = pry + t * (cy - pry);
+                ++k;
+            }
+            if (dc >= 0.0) { qx[k] = cx; qy[k] = cy; ++k; }
+            prx = cx; pry = cy; dp = dc;
+        }
+        n = k;
+        for (int i = 0; i < n; ++i) { px[i] = qx[i]; py[i] = qy[i]; }
+    }
+    if (n < 3) return 0.0;
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1 == n) ? 0 : i + 1;
+        acc += px[i] * py[j] - px[j] * py[i];
+    }
+    const double inter = 0.5 * fabs(acc);
+    const double uni = (area_a + area_b) - inter;
+    if (!(uni > 0.0)) return 0.0;
+    const double iou = inter / uni;
+    return iou > 1.0 ? 1.0 : iou;
+}
+
+#define ORC_KMAX 1000000
+
+/* One sample: pred (P,6), gt (G,6) -> pred_match[P] (gt index or -1), gt_match[G], match_iou[P]; weight_out
+ * (P*G int32, optional) receives the quantised weights.  Returns the total weight of the assignment. */
+ORC_API int64_t orc_bev_match(const double *pred, int P, const double *gt, int G, double iou_thr, int32_t *pred_match,
+                              int32_t *gt_match, double *match_iou, int32_t *weight_out)
+{
+    for (int i = 0; i < P; ++i) { pred_match[i] = -1; match_iou[i] = 0.0; }
+    for (int j = 0; j < G; ++j) gt_match[j] = -1;
+    if (P <= 0 || G <= 0) return 0;
+    int32_t *W = (int32_t *)malloc(sizeof(int32_t) * (size_t)P * (size_t)G);
+    for (int p = 0; p < P; ++p)
+        for (int g = 0; g < G; ++g) {
+            const double iou = orc_bev_iou(pred + 6 * p, gt + 6 * g);
+            W[(size_t)p * G + g] = iou >= iou_thr ? (int32_t)(iou * (double)ORC_KMAX) : 0;
+        }
+    if (weight_out) memcpy(weight_out, W, sizeof(int32_t) * (size_t)P * (size_t)G);
+    const int tr = P > G;
+    const int n = tr ? G : P, m = tr ? P : G;
+#define ORC_W(i, j) (tr ? W[(size_t)((j) - 1) * G + ((i) - 1)] : W[(size_t)((i) - 1) * G + ((j) - 1)])
+    int64_t *u = calloc((size_t)m + 1, sizeof(int64_t)), *v = calloc((size_t)m + 1, sizeof(int64_t));
+    int64_t *minv = malloc(sizeof(int64_t) * ((size_t)m + 1));
+    int *p = calloc((size_t)m + 1, sizeof(int)), *way = calloc((size_t)m + 1, sizeof(int));
+    unsigned char *used = malloc((size_t)m + 1);
+    const int64_t INF = (int64_t)1 << 50;
+    for (int i = 1; i <= n; ++i) {
+        p[0] = i;
+        int j0 = 0;
+        for (int j = 0; j <= m; ++j) { minv[j] = INF; used[j] = 0; }
+        do {
+            used[j0] = 1;
+            const int i0 = p[j0];
+            int64_t delta = INF;
+            int j1 = 0;
+            for (int j = 1; j <= m; ++j) {
+                if (used[j]) continue;
+                const int64_t cur = (int64_t)(ORC_KMAX - ORC_W(i0, j)) - u[i0] - v[j];
+                if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+                if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+            }
+            for (int j = 0; j <= m; ++j) {
+                if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+                else minv[j] -= delta;
+            }
+            j0 = j1;
+        } while (p[j0] != 0);
+        do {
+            const int j1 = way[j0];
+            p[j0] = p[j1];
+            j0 = j1;
+        } while (j0);
+    }
+    int64_t total = 0;
+    for (int j = 1; j <= m; ++j) {
+        const int i = p[j];
+        if (i == 0) continue;
+        const int w = ORC_W(i, j);
+        if (w <= 0) continue;
+        const int pi = tr ? j - 1 : i - 1, gi = tr ? i - 1 : j - 1;
+        pred_match[pi] = gi;
+        gt_match[gi] = pi;
+        match_iou[pi] = orc_bev_iou(pred + 6 * pi, gt + 6 * gi);
+        total += w;
+    }
+#undef ORC_W
+    free(W); free(u); free(v); free(minv); free(p); free(way); free(used);
+    return total;
+}

@@ -56,6 +56,10 @@ def _load():
     lib.orc_centroid_transform.argtypes = [p, p, p]
     lib.orc_box_assemble_waymo.restype = None
     lib.orc_box_assemble_waymo.argtypes = [p, p, p, f32, i32, p, p]
+    lib.orc_bev_iou.restype = C.c_double
+    lib.orc_bev_iou.argtypes = [p, p]
+    lib.orc_bev_match.restype = i64
+    lib.orc_bev_match.argtypes = [p, i32, p, i32, C.c_double, p, p, p, p]
     lib.orc_circle_nms.restype = i32
     lib.orc_circle_nms.argtypes = [p, p, p, p, i32, p, p]
     return lib
@@ -308,3 +312,26 @@ def stage2_frame_waymo(centroids_vehicle, med, class_id, scores, lane_pts, pose_
     if vi.size:
         keep[vi] = circle_nms(t[vi, 0], t[vi, 1], np.asarray(scores, np.float64)[vi], WAYMO_NMS_GROUP[np.asarray(class_id)[vi]], WAYMO_NMS_THR)
     return dict(valid=valid, keep=keep, translation=t, heading=heading, lane_idx=lane_j, lane_dist=lane_d, yaw=yaw, centroid_global=cg)
+
+
+# ------------------------------------------------------------------ f4: SAM3D fusion matching
+def bev_box(cx, cy, length, width, heading):
+    """Box record of orc_bev_iou / orc_bev_match: cos/sin of the heading are taken on the host."""
+    return np.array([cx, cy, length, width, np.cos(heading), np.sin(heading)], np.float64)
+
+
+def bev_iou(a, b):
+    a, b = np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64)
+    return float(lib().orc_bev_iou(_ptr(a), _ptr(b)))
+
+
+def bev_match(pred, gt, iou_thr=0.2, want_weights=False):
+    """`match(pred, sam3d, iou, TYPE_2D)` of linear_matching.py:53-104 for one sample on (P,6)/(G,6) records:
+    returns pred_match (gt index or -1), gt_match, match_iou, total weight[, weights]."""
+    pred = np.ascontiguousarray(pred, np.float64).reshape(-1, 6)
+    gt = np.ascontiguousarray(gt, np.float64).reshape(-1, 6)
+    P, G = pred.shape[0], gt.shape[0]
+    pm, gm, iou = np.empty(P, np.int32), np.empty(G, np.int32), np.empty(P, np.float64)
+    W = np.zeros((P, G), np.int32)
+    total = lib().orc_bev_match(_ptr(pred), P, _ptr(gt), G, float(iou_thr), _ptr(pm), _ptr(gm), _ptr(iou), _ptr(W))
+    return (pm, gm, iou, int(total), W) if want_weights else (pm, gm, iou, int(total))
