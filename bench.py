@@ -103,6 +103,65 @@ def cpu_baseline_all_cores(config_name, set_args, lane_points, workers, frames_p
             "sample": f"{workers} processes x {frames_per_worker} frames of the same synthetic workload, slowest {dt:.1f} s"}
 
 
+def fusion_bench(n_samples, steps, warmup):
+    """`--fusion N`: the SAM3D fusion matching (reference src/nuscenes/linear_matching.py:231-259) at
+    nuScenes-val scale -- N samples, ~25 lifted boxes against ~45 SAM3D boxes each, one cm3d_bev_match call per step with
+    the box records resident in HBM; the CPU oracle over the same samples beside it.  One JSON line."""
+    import numpy as np
+    from cm3d_amd import _lib, ops
+    rng = np.random.default_rng(1)
+
+    def boxes(n, centre, spread):
+        c = centre + rng.uniform(-spread, spread, (n, 2))
+        return np.stack([c[:, 0], c[:, 1], rng.uniform(-1, 1, n), rng.uniform(1.5, 5.5, n), rng.uniform(0.8, 2.5, n),
+                         rng.uniform(1, 2, n), rng.uniform(-np.pi, np.pi, n)], 1)
+    pr, gr = [], []
+    for _ in range(n_samples):
+        P = int(rng.integers(5, 45))
+        p = boxes(P, rng.uniform(-1, 1, 2) * (700.0, 1500.0), 40.0)
+        g = p.copy()
+        g[:, :2] += rng.normal(0, 0.5, (P, 2)); g[:, 6] += rng.normal(0, 0.2, P)
+        g = np.concatenate([g[rng.random(P) < 0.7], boxes(int(rng.integers(10, 50)), p[0, :2], 40.0)])
+        pr.append(ops.match_records(p)); gr.append(ops.match_records(g))
+    np_, ng = np.array([len(r) for r in pr]), np.array([len(r) for r in gr])
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    p_off, g_off = np.concatenate([[0], np.cumsum(np_)]).astype(np.int32), np.concatenate([[0], np.cumsum(ng)]).astype(np.int32)
+    pair_off = np.concatenate([[0], np.cumsum(np_ * ng)]).astype(np.int64)
+    d_p, d_g, d_po, d_go, d_pair = t(np.concatenate(pr)), t(np.concatenate(gr)), t(p_off), t(g_off), t(pair_off)
+    n_pred, n_gt, total = int(p_off[-1]), int(g_off[-1]), int(pair_off[-1])
+    pm, gm = torch.empty(n_pred, dtype=torch.int32, device=dev), torch.empty(n_gt, dtype=torch.int32, device=dev)
+    iou = torch.empty(n_pred, dtype=torch.float64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    ws = torch.empty(L.cm3d_bev_match_workspace_bytes(total), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        _lib.check(L.cm3d_bev_match(d_p.data_ptr(), d_po.data_ptr(), n_pred, d_g.data_ptr(), d_go.data_ptr(), n_gt, d_pair.data_ptr(),
+                                    n_samples, total, 0.2, pm.data_ptr(), gm.data_ptr(), iou.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), st), "cm3d_bev_match")
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    from oracle import oracle as orc          # the checker, here as the reported CPU baseline
+    t0 = time.perf_counter()
+    exp = [orc.bev_match(a, b, 0.2)[0] for a, b in zip(pr, gr)]
+    dt_cpu = time.perf_counter() - t0
+    same = bool(np.array_equal(np.concatenate(exp), pm.cpu().numpy()))
+    print(json.dumps({"metric": "SAM3D fusion matching samples/sec", "value": round(n_samples / dt, 1), "unit": "samples/s", "n_gpus": 1,
+                      "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "dtype": "f64",
+                      "data": "synthetic", "config": {"workload": f"{n_samples} samples, {n_pred} lifted x {n_gt} SAM3D boxes, {total} pairs"},
+                      "matches": int((pm >= 0).sum().item()), "equals_oracle": same,
+                      "cpu_baseline": {"value": round(n_samples / dt_cpu, 1), "unit": "samples/s", "cores": 1, "kind": "port",
+                                       "sample": f"all {n_samples} samples, {dt_cpu:.2f} s"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +178,11 @@ def main():
                     help="processes of the all-cores CPU baseline (0 = skip; capped at the visible cores)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override a field of the synthetic config (e.g. --set n_masks=80); for experiments")
+    ap.add_argument("--fusion", type=int, default=0, metavar="SAMPLES",
+                    help="time the SAM3D fusion matching (SURVEY 8 f4) on this many samples instead of the lifting path")
     args = ap.parse_args()
+    if args.fusion > 0:
+        return fusion_bench(args.fusion, min(args.steps, 50), min(args.warmup, 5))
 
     rank, world, local_rank = cdist.init_from_env()
     if world != args.gpus:
