@@ -46,6 +46,8 @@ def algorithmic_bytes(hb, sum_hits, mode):
         "k_rle_erode_pack": 4 * int(hb.rle_counts.size) + packed,
         "k_sweep": 4 * hb.raw_stride * n_raw + 16 * n_pts,
     }
+    # sweep preparation folded into the projection launch: raw rows read, cloud written once, masks, hit words
+    alg["k_project_hits_fused"] = alg["k_sweep"] + packed + 4 * n_pts
     masks_in = M * W * H if mode == "dense" else 4 * int(hb.rle_counts.size)
     alg["frame_total"] = alg["project_gather"] + masks_in + packed + 16 * sum_hits + 64 * M
     return alg
@@ -178,6 +180,8 @@ def main():
                     help="processes of the all-cores CPU baseline (0 = skip; capped at the visible cores)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override a field of the synthetic config (e.g. --set n_masks=80); for experiments")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="independent batches kept in flight per GPU (LiftPipeline depth; 1 = one batch at a time)")
     ap.add_argument("--fusion", type=int, default=0, metavar="SAMPLES",
                     help="time the SAM3D fusion matching (SURVEY 8 f4) on this many samples instead of the lifting path")
     args = ap.parse_args()
@@ -198,20 +202,28 @@ def main():
         k, v = kv.split("=", 1)
         over[k] = type(getattr(syn.SyntheticConfig(), k))(float(v)) if not isinstance(getattr(syn.SyntheticConfig(), k), str) else v
     cfg = syn.config(args.config, **over)
+    depth = max(1, args.in_flight)
     t_gen = time.perf_counter()
-    frames = [syn.make_frame(cfg, rank * args.frames + i) for i in range(args.frames)]
-    # one HD-map lane table covering the region all frames of the batch drive in (ego positions are drawn
+    # one HD-map lane table covering the region all frames drive in (ego positions are drawn
     # from (600,1600) +- 200 m, objects up to 55 m further out)
     lanes = [syn.make_lane_table([600.0, 1600.0], args.lane_points, seed=7 + rank, extent=260.0)]
-    frame_lane = [0] * len(frames)
-    hb = lifting.pack_frames(frames, lanes, frame_lane)
+    frame_lane = [0] * args.frames
+    # `depth` independent batches stay in flight (LiftPipeline: one engine + stream each); step k runs on batch k % depth
+    batches = []
+    for slot in range(depth):
+        fr = [syn.make_frame(cfg, (rank * depth + slot) * args.frames + i) for i in range(args.frames)]
+        batches.append((fr, lifting.pack_frames(fr, lanes, frame_lane)))
+    frames, hb = batches[0]
     t_gen = time.perf_counter() - t_gen
 
-    eng = lifting.LiftEngine(dev)
-    eng.upload(hb)
     modes = [args.masks] + ([] if args.no_secondary else [m for m in ("rle", "dense") if m != args.masks])
-    if "dense" in modes:
-        eng.decode_masks_dense()
+    pipe = lifting.LiftPipeline(dev, depth=depth)
+    for slot in range(depth):
+        with torch.cuda.stream(pipe.streams[slot]):
+            pipe.engines[slot].upload(batches[slot][1])
+            if "dense" in modes:
+                pipe.engines[slot].decode_masks_dense()
+    eng = pipe.engines[0]
     torch.cuda.synchronize()
 
     def barrier():
@@ -220,45 +232,40 @@ def main():
 
     results = {}
     for mode in modes:
-        stages = list(eng.STAGES)
+        fused = eng.can_fuse_sweeps()
+        stages = [s for s in eng.STAGES if not (fused and s == "sweeps")]
         ev = {s: [] for s in stages}
-        st = torch.cuda.current_stream(dev).cuda_stream
+
         def lanes_after_grid(s):
             eng.wait_lane_grid()        # the lane-grid build runs on the engine's side stream since stage_begin
             eng.stage_lanes(s)
 
-        calls = {"sweeps": eng.stage_sweeps, "masks": lambda s: eng.stage_masks(s, mode), "project": eng.stage_project,
+        calls = {"sweeps": eng.stage_sweeps, "masks": lambda s: eng.stage_masks(s, mode),
+                 "project": eng.stage_sweep_project if fused else eng.stage_project,
                  "compact": eng.stage_compact, "medoid": eng.stage_medoid, "lanes": lanes_after_grid, "boxes": eng.stage_boxes}
-        for _ in range(args.warmup):
-            eng.run(masks=mode)
+        for k in range(max(args.warmup, depth)):
+            pipe.rerun(k % depth, masks=mode)
+        torch.cuda.synchronize()
         if world > 1 and mode == modes[0]:
             cdist.gather_records(eng.b.box, dst=0)      # untimed: sets up the RCCL channels the final gather uses
         torch.cuda.synchronize()
-        eng.check_status()
+        for e in pipe.engines:
+            e.check_status()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev_every = 1 if args.steps <= 16 else 8        # an event pair costs ~5 us of stream time: sample every 8th step
         for step in range(args.steps):
-            # same order as LiftEngine.run()
-            eng.stage_begin(st)
-            eng.stage_sweeps(st)
-            eng.stage_masks(st, mode)
-            if step % ev_every == 0:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()              # HIP events around the roofline kernel only, on its launch stream
-                eng.stage_project(st)
-                b.record()
-                ev["project"].append((a, b))
-            else:
-                eng.stage_project(st)
-            eng.stage_compact(st)
-            eng.stage_medoid(st)
-            lanes_after_grid(st)
-            eng.stage_boxes(st)
+            pe = None
+            if step % ev_every == 0:    # HIP events around the roofline kernel only, on its launch stream
+                pe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev["project"].append(pe)
+            pipe.rerun(step % depth, masks=mode, project_events=pe)       # LiftEngine.run() on that batch's stream
         gathered = None
         if mode == modes[0]:
             # the single end-of-job exchange: fixed-size box records -> rank 0 (RCCL gather)
+            for s in pipe.streams:
+                torch.cuda.current_stream(dev).wait_stream(s)
             gathered = cdist.gather_records(eng.b.box, dst=0)
         torch.cuda.synchronize()
         barrier()
@@ -268,22 +275,24 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
             dt = float(tmax.item())
-        # per-stage breakdown: a separate, untimed pass with events around every stage
-        for _ in range(max(3, min(args.steps, 10))):
-            eng.stage_begin(st)
-            for s in stages:
-                if s == "project":
+        # per-stage breakdown: a separate, untimed pass over ONE batch alone, with events around every stage
+        alone = []
+        with torch.cuda.stream(pipe.streams[0]):
+            st = pipe.streams[0].cuda_stream
+            for _ in range(max(3, min(args.steps, 10))):
+                eng.stage_begin(st)
+                for s in stages:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
                     calls[s](st)
-                    continue
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                calls[s](st)
-                b.record()
-                ev[s].append((a, b))
+                    b.record()
+                    (alone if s == "project" else ev[s]).append((a, b))
         torch.cuda.synchronize()
         stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) for s in stages}
+        project_alone_ms = float(np.mean([a.elapsed_time(b) for a, b in alone]))
         status = eng.check_status()
-        results[mode] = dict(dt=dt, stage_ms=stage_ms, sum_hits=int(status[2]), n_points=int(status[1]),
+        results[mode] = dict(dt=dt, stage_ms=stage_ms, project_alone_ms=project_alone_ms, fused=fused, sum_hits=int(status[2]),
+                             n_points=int(status[1]),
                              n_boxes=int((eng.b.flags == 3).sum().item()), max_hits=int(eng.b.hit_count.max().item()),
                              n_gathered=None if gathered is None else int(sum(g.shape[0] for g in gathered)))
 
@@ -302,11 +311,21 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": int(alg[kernel_key]),
                 "avg_launch_ms": round(ms, 4), "note": note}
 
-    # north_star's kernel: projection + in-mask gather (k_project_hits, one launch per pass)
-    roofline = roof("k_project_hits", "project", r, "k_project_hits",
-                    "algorithmic bytes = 16 B/point + every bit-packed mask once + 4 B/point hit word (SURVEY 8d); the kernel's "
-                    "bounding-box test lets it skip most mask bytes, so `achieved` exceeds what HBM allows for a full read; "
-                    "traffic_rate = measured HBM bytes / time; the kernel is instruction-issue bound")
+    # north_star's kernel: projection + in-mask gather (one launch per pass), timed by HIP events on its launch stream
+    # inside the timed region -- i.e. while the other batches in flight share the GPU with it
+    if r["fused"]:
+        roofline = roof("k_project_hits_fused", "project", r, "k_project_hits<ONE_PLANE, FUSED>",
+                        "sweep preparation folded in: algorithmic bytes = raw rows read (4 x stride B) + cloud written (16 B/point) + "
+                        "every bit-packed mask once + 4 B/point hit word (SURVEY 8d); the bounding-box test lets the kernel skip most "
+                        "mask bytes, so `achieved` can exceed what HBM allows for a full read; traffic_rate = measured HBM bytes / "
+                        "time; the kernel is instruction-issue / latency bound")
+    else:
+        roofline = roof("k_project_hits", "project", r, "k_project_hits",
+                        "algorithmic bytes = 16 B/point + every bit-packed mask once + 4 B/point hit word (SURVEY 8d); the kernel's "
+                        "bounding-box test lets it skip most mask bytes, so `achieved` exceeds what HBM allows for a full read; "
+                        "traffic_rate = measured HBM bytes / time; the kernel is instruction-issue bound")
+    roofline["batches_in_flight"] = depth
+    roofline["avg_launch_ms_alone"] = round(r["project_alone_ms"], 4)      # the same launch with nothing else on the GPU
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     per_kernel = {}
     if os.path.exists(traffic_file):
@@ -327,11 +346,12 @@ def main():
     mask_kernel = "k_erode_pack" if main_mode == "dense" else "k_rle_erode_pack"
     kernels = {
         "masks": roof(mask_kernel, "masks", r, mask_kernel, "latency-bound (one workgroup per mask); stage time incl. the launch boundary"),
-        "sweeps": roof("k_sweep", "sweeps", r, "k_sweep_xform", "HBM streaming, one pass; stage time incl. the launch boundary"),
-        "stage_ms": {k: round(v, 4) for k, v in r["stage_ms"].items()},
+        "stage_ms_one_batch_alone": {k: round(v, 4) for k, v in dict(r["stage_ms"], project=r["project_alone_ms"]).items()},
     }
     kernels["masks"]["traffic"] = per_kernel.get(mask_kernel)
-    kernels["sweeps"]["traffic"] = per_kernel.get("k_sweep_xform")
+    if not r["fused"]:
+        kernels["sweeps"] = roof("k_sweep", "sweeps", r, "k_sweep_xform", "HBM streaming, one pass; stage time incl. the launch boundary")
+        kernels["sweeps"]["traffic"] = per_kernel.get("k_sweep_xform")
     out = {
         "metric": "pseudo-label frames/sec on nuScenes-shaped sweeps", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(r["dt"] / args.steps * 1e3, 4),
@@ -340,7 +360,8 @@ def main():
                                f"{cfg.n_masks} masks {cfg.width}x{cfg.height}), masks resident as {main_mode}",
                    "frames_per_gpu": args.frames, "points_per_frame": cfg.n_points * cfg.n_sweeps, "masks_per_frame": cfg.n_masks,
                    "mask_size": [cfg.width, cfg.height], "lane_points": args.lane_points, "mask_input": main_mode,
-                   "parallelism": f"frame-sharded x{world}, one RCCL gather of box records"},
+                   "batches_in_flight": depth,
+                   "parallelism": f"frame-sharded x{world}, {depth} independent batches in flight per GPU, one RCCL gather of box records"},
         "roofline": roofline,
         "kernels": kernels,
         "frame_alg_bytes": int(alg["frame_total"] // hb.n_frames),
@@ -354,7 +375,7 @@ def main():
     for mode in modes[1:]:
         o = results[mode]
         out[f"value_{mode}_masks"] = round(frames_total / o["dt"], 1)
-        out[f"stage_ms_{mode}_masks"] = {k: round(v, 4) for k, v in o["stage_ms"].items()}
+        out[f"stage_ms_{mode}_masks"] = {k: round(v, 4) for k, v in dict(o["stage_ms"], project=o["project_alone_ms"]).items()}
     if world == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(frames, lanes, frame_lane, hb, args.cpu_sample)
         workers = min(args.cpu_workers, os.cpu_count() or 1)

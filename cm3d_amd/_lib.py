@@ -18,6 +18,7 @@ BOX_STRIDE = 10
 MEDOID_TILE = 64
 STATUS_WORDS = 4
 MAX_MATCH_BOXES = 1024
+MAX_FUSED_SWEEPS = 16
 MATCH_BOX_STRIDE = 6
 
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -35,6 +36,8 @@ SIGNATURES = {
     "cm3d_project_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "cm3d_project_hits": (_i32, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32,
                                  _p, _p, _p, _p, _i64, _p]),
+    "cm3d_sweep_project_hits": (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _f32, _p, _i32, _p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p,
+                                       _p, _p, _i32, _i32, _i32, _f32, _i32, _p, _p, _p, _p, _i64, _p]),
     "cm3d_compact_hits": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _i64, _p]),
     "cm3d_tile_work_bytes": (_i64, [_i32, _i32]),
     "cm3d_selftest_sqrt": (_i32, [C.c_uint32, C.c_uint32, _p, _p, _p]),

@@ -191,16 +191,132 @@ static __device__ void cone_setup(const float *cm, int W, int H, float min_dist,
 //   bit test, per-mask hit count.
 // ONE_PLANE (<= 32 masks per frame): the hit word of a point lives in a register; otherwise in the thread's own
 // LDS slots, one per plane.
-template <bool ONE_PLANE>
+// FUSED: the kernel reads the RAW sweep rows itself (a2, reference :437-465: ego-box drop, sensor -> ego -> global, the
+// very fma chains of k_sweep_xform), writes the transformed cloud for the medoid / the caller, and lists the dropped rows
+// -- the cloud is then read once from HBM in the whole pass instead of raw + written + read again, and the sweep launch
+// disappears.  Frames with at most PH_MAX_SWEEPS sweeps (cm3d_sweep_project_hits checks).
+#define PH_MAX_SWEEPS 16
+#define PH_DROP_CAP 2048                          // dropped rows a block collects in LDS; beyond: straight to the frame's list
+struct PhSweepIn {
+    const float *raw; int raw_stride; const int32_t *sweep_row_off; const float *sweep_xf; const int32_t *frame_sweep_off;
+    int n_frames, n_sweeps; float halfw; float4 *points_out; int pt_cap; int32_t *pt_off_out, *removed_cnt, *removed_idx;
+};
+
+// raw rows of a chunk (the 4 columns the reference keeps); dead slots read as (1e30, 1e30): never dropped
+template <bool FUSED>
+static __device__ __forceinline__ void ph_load(float4 (&pt)[PH_PT], const float4 *__restrict__ points, const PhSweepIn &sw, int p0,
+                                               int n, int chunk)
+{
+    const float qnan = __int_as_float(0x7FC00000);
+#pragma unroll
+    for (int j = 0; j < PH_PT; ++j) {
+        const int i = chunk * PH_BLOCK_PTS + ph_slot(j);
+        if (FUSED) {
+            pt[j] = make_float4(1e30f, 1e30f, 0.f, 0.f);
+            if (i < n) {
+                const float *p = sw.raw + (size_t)(p0 + i) * sw.raw_stride;
+                pt[j].x = __builtin_nontemporal_load(p); pt[j].y = __builtin_nontemporal_load(p + 1);
+                pt[j].z = __builtin_nontemporal_load(p + 2); pt[j].w = __builtin_nontemporal_load(p + 3);
+            }
+        } else {
+            pt[j] = i < n ? points[p0 + i] : make_float4(qnan, qnan, qnan, 0.f);
+        }
+    }
+}
+
+static __device__ __forceinline__ void ph_xform(const float *xf, float x, float y, float z, float &ox, float &oy, float &oz)
+{
+    // sensor -> ego (rotate then translate), ego -> global (2d_to_3d.py:450-457), as in k_sweep_xform
+    float ax, ay, az;
+    cm3d_rot3(xf, x, y, z, ax, ay, az);
+    ax = ax + xf[9]; ay = ay + xf[10]; az = az + xf[11];
+    cm3d_rot3(xf + 12, ax, ay, az, ox, oy, oz);
+    ox = ox + xf[21]; oy = oy + xf[22]; oz = oz + xf[23];
+}
+
+// raw rows of a chunk -> global-frame points in place (dropped / dead slots become NaN points), stored to the cloud,
+// dropped rows appended to the block's LDS list (or, once that is full, to the frame's list directly)
+static __device__ __forceinline__ void ph_prepare(float4 (&pt)[PH_PT], const PhSweepIn &sw, int f, int sa, int ns, const int *s_srow,
+                                                  int p0, int n, int chunk, int *s_drop, int *s_ndrop)
+{
+    const float qnan = __int_as_float(0x7FC00000);
+    const int base = chunk * PH_BLOCK_PTS;
+    // sweep of the wave's first and last row: equal for all but the waves that hold a sweep boundary
+    int sw_lo = 0, sw_hi = 0;
+    if (ns > 1) {
+        const int r_lo = base + (int)(threadIdx.x >> 6) * (64 * PH_PT), r_hi = min(r_lo + 64 * PH_PT, n) - 1;
+        for (int k = 1; k < ns; ++k) { sw_lo += s_srow[k] <= r_lo; sw_hi += s_srow[k] <= r_hi; }
+    }
+    const bool uni = sw_lo >= sw_hi;
+    const float *xf_u = sw.sweep_xf + (size_t)(sa + __builtin_amdgcn_readfirstlane(sw_lo)) * CM3D_SWEEP_XF_STRIDE;   // scalar loads
+#pragma unroll
+    for (int j = 0; j < PH_PT; ++j) {
+        const int i = base + ph_slot(j);
+        const bool live = i < n;
+        const float x = pt[j].x, y = pt[j].y, z = pt[j].z, w = pt[j].w;
+        const bool drop = live && fabsf(x) < sw.halfw && fabsf(y) < sw.halfw;      // reference drops this row (2d_to_3d.py:442-445)
+        float bx, by, bz;
+        if (uni) {
+            ph_xform(xf_u, x, y, z, bx, by, bz);
+        } else {
+            int k_sw = 0;
+            for (int k = 1; k < ns; ++k) k_sw += s_srow[k] <= i;
+            ph_xform(sw.sweep_xf + (size_t)(sa + k_sw) * CM3D_SWEEP_XF_STRIDE, x, y, z, bx, by, bz);
+        }
+        if (!live || drop) { bx = qnan; by = qnan; bz = qnan; }
+        pt[j] = make_float4(bx, by, bz, w);
+        if (live) sw.points_out[p0 + i] = pt[j];
+        const uint64_t dm = __ballot(drop);
+        if (dm) {
+            const int cnt = (int)__popcll(dm);
+            int pos0 = 0;
+            if (cm3d_lane() == 0) pos0 = atomicAdd(s_ndrop, cnt);
+            pos0 = __builtin_amdgcn_readfirstlane(pos0);
+            const int n_lds = max(0, min(cnt, PH_DROP_CAP - pos0)), n_over = cnt - n_lds;
+            int gbase = 0;
+            if (n_over) {
+                if (cm3d_lane() == 0) gbase = atomicAdd(&sw.removed_cnt[f], n_over);
+                gbase = __builtin_amdgcn_readfirstlane(gbase);
+            }
+            if (drop) {
+                const int r = cm3d_mbcnt(dm);
+                if (r < n_lds) s_drop[pos0 + r] = i;
+                else sw.removed_idx[p0 + gbase + (r - n_lds)] = i;
+            }
+        }
+    }
+}
+
+template <bool ONE_PLANE, bool FUSED>
 __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
-    const float4 *__restrict__ points, const int32_t *__restrict__ pt_off, int n_points_total,
+    const float4 *__restrict__ points, const int32_t *__restrict__ pt_off, const PhSweepIn sw, int n_points_total,
     const float *__restrict__ cams, int n_cams, const int32_t *__restrict__ mask_off,
     const int32_t *__restrict__ mask_cam, const int4 *__restrict__ bbox, const uint32_t *__restrict__ packed,
     int W, int H, int Wp, float min_dist, int nm_cap, int nblk_max, int chunks_per_block, uint32_t *__restrict__ hit_words,
     int32_t *__restrict__ hit_count, int32_t *__restrict__ blk_cnt, int32_t *__restrict__ status)
 {
     const int f = blockIdx.y;
-    const int p0 = pt_off[f], n = pt_off[f + 1] - p0;
+    int p0, n, sa = 0, ns = 0;
+    if (FUSED) {
+        sa = sw.frame_sweep_off[f];
+        ns = sw.frame_sweep_off[f + 1] - sa;
+        p0 = sw.sweep_row_off[sa];
+        n = sw.sweep_row_off[sa + ns] - p0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {              // what k_sweep_xform leaves behind for the later stages
+            sw.pt_off_out[f] = p0;
+            if (f == sw.n_frames - 1) {
+                const int total_rows = sw.sweep_row_off[sw.n_sweeps];
+                sw.pt_off_out[sw.n_frames] = total_rows;
+                status[1] = total_rows;
+                if (total_rows > sw.pt_cap) atomicOr(&status[0], 1);
+                if (sw.frame_sweep_off[0] != 0 || sa + ns != sw.n_sweeps) atomicOr(&status[0], 4);      // sweeps outside every frame
+            }
+        }
+        n = max(0, min(n, sw.pt_cap - p0));
+    } else {
+        p0 = pt_off[f];
+        n = pt_off[f + 1] - p0;
+    }
     const int nblk = (n + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
     if ((int)blockIdx.x >= nblk) return;
     const int m0 = mask_off[f];
@@ -223,12 +339,14 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
 
     // points of the first chunk are requested before the table staging so that both latencies overlap.
     // Slots past the end of the frame hold NaN points: every test below rejects them by itself.
-    const float qnan = __int_as_float(0x7FC00000);
+    __shared__ int s_srow[FUSED ? PH_MAX_SWEEPS + 1 : 1];     // first row of each sweep of the frame (frame-local)
+    __shared__ int s_drop[FUSED ? PH_DROP_CAP : 1];            // dropped rows of this block (frame-local row indices)
+    __shared__ int s_ndrop, s_dropbase;
     float4 pt[PH_PT];
-#pragma unroll
-    for (int j = 0; j < PH_PT; ++j) {
-        const int i0 = (int)blockIdx.x * PH_BLOCK_PTS + ph_slot(j);
-        pt[j] = i0 < n ? points[p0 + i0] : make_float4(qnan, qnan, qnan, 0.f);
+    ph_load<FUSED>(pt, points, sw, p0, n, (int)blockIdx.x);
+    if (FUSED) {
+        if (threadIdx.x <= ns && threadIdx.x <= PH_MAX_SWEEPS) s_srow[threadIdx.x] = sw.sweep_row_off[sa + threadIdx.x] - p0;
+        if (threadIdx.x == 0) s_ndrop = 0;
     }
     for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS)
         s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
@@ -254,6 +372,11 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
         const int base = chunk * PH_BLOCK_PTS;
         int *s_cnt_row = s_cnt + ci * nm_cap;
         static_assert(PH_PT % 2 == 0, "points are handled in pairs");
+        if (FUSED) ph_prepare(pt, sw, f, sa, ns, s_srow, p0, n, chunk, s_drop, &s_ndrop);
+        // FUSED: the next chunk's raw rows (HBM, 20-byte stride) are requested now, into their own registers, and
+        // arrive under the camera loop (887 k against 856 k frames/s with the request at the end of the chunk)
+        float4 nxt[PH_PT];
+        if (FUSED && chunk + (int)gridDim.x < nblk) ph_load<FUSED>(nxt, points, sw, p0, n, chunk + (int)gridDim.x);
         f2 X[PH_NP], Y[PH_NP], Z[PH_NP];
 #pragma unroll
         for (int h = 0; h < PH_NP; ++h) {
@@ -354,12 +477,11 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             }
         }
         // prefetch the next chunk's points (if this block has one) under the count flush
-        if (chunk + (int)gridDim.x < nblk) {
+        if (FUSED) {
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) {
-                const int i1 = (chunk + (int)gridDim.x) * PH_BLOCK_PTS + ph_slot(j);
-                pt[j] = i1 < n ? points[p0 + i1] : make_float4(qnan, qnan, qnan, 0.f);
-            }
+            for (int j = 0; j < PH_PT; ++j) pt[j] = nxt[j];
+        } else if (chunk + (int)gridDim.x < nblk) {
+            ph_load<FUSED>(pt, points, sw, p0, n, chunk + (int)gridDim.x);
         }
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) {
@@ -383,6 +505,15 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             tot += c;
         }
         if (tot) atomicAdd(&hit_count[m0 + k], tot);
+    }
+    if (FUSED) {
+        // the block's dropped rows join the frame's list with ONE global atomic (see k_sweep_xform)
+        const int nd = min(s_ndrop, PH_DROP_CAP);
+        if (nd == 0) return;
+        if (threadIdx.x == 0) s_dropbase = atomicAdd(&sw.removed_cnt[f], nd);
+        __syncthreads();
+        const int dbase = p0 + s_dropbase;
+        for (int i = threadIdx.x; i < nd; i += PH_THREADS) sw.removed_idx[dbase + i] = s_drop[i];
     }
 }
 
@@ -661,16 +792,13 @@ extern "C" int64_t cm3d_project_workspace_bytes(int32_t n_frames, int32_t max_pt
     return (int64_t)n_frames * nblk_max * ph_nm_cap(planes) * (int64_t)sizeof(int32_t);
 }
 
-extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
-                                 int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off,
-                                 const int32_t *mask_cam, const int32_t *bbox, const uint32_t *packed, int32_t n_masks,
-                                 int32_t W, int32_t H, float min_dist, int32_t planes, uint32_t *hit_words,
-                                 int32_t *hit_count, int32_t *status, void *workspace, int64_t workspace_bytes,
-                                 cm3d_stream_t stream)
+static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
+                     int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off, const int32_t *mask_cam,
+                     const int32_t *bbox, const uint32_t *packed, int32_t n_masks, int32_t W, int32_t H, float min_dist,
+                     int32_t planes, uint32_t *hit_words, int32_t *hit_count, int32_t *status, void *workspace,
+                     int64_t workspace_bytes, cm3d_stream_t stream)
 {
-    if (!points || !pt_off || !cams || !mask_off || !mask_cam || !bbox || !packed || !hit_words || !hit_count || !status ||
-        !workspace)
-        return CM3D_ERR_ARG;
+    if (!cams || !mask_off || !mask_cam || !bbox || !packed || !hit_words || !hit_count || !status || !workspace) return CM3D_ERR_ARG;
     if (n_frames <= 0 || max_pts_per_frame <= 0 || n_points_total <= 0 || n_cams <= 0 || n_cams > CM3D_MAX_CAMS ||
         n_masks <= 0 || W <= 1 || H <= 1 || W > 32767 || H > 32767 || planes <= 0)
         return CM3D_ERR_ARG;
@@ -696,25 +824,60 @@ extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int
     }
     const int chunks_per_block = (nblk_max + gx - 1) / gx;
     size_t lds = (size_t)CM3D_MAX_CAMS * planes_cap * sizeof(uint32_t) + (size_t)chunks_per_block * nm_cap * sizeof(int);
+    PhSweepIn none = {};
+    const PhSweepIn sw = fused ? *fused : none;
+#define PH_LAUNCH(ONE, FUSED)                                                                                                    \
+    hipLaunchKernelGGL((k_project_hits<ONE, FUSED>), dim3(gx, n_frames), dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off, \
+                       sw, n_points_total, cams, n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist,     \
+                       nm_cap, nblk_max, chunks_per_block, hit_words, hit_count, (int32_t *)workspace, status)
     if (planes_cap == 1) {
-        hipLaunchKernelGGL(k_project_hits<true>, dim3(gx, n_frames), dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off,
-                           n_points_total, cams, n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, nm_cap,
-                           nblk_max, chunks_per_block, hit_words, hit_count, (int32_t *)workspace, status);
+        if (fused) PH_LAUNCH(true, true); else PH_LAUNCH(true, false);
     } else {
         lds += (size_t)planes_cap * PH_BLOCK_PTS * sizeof(uint32_t);
-        static size_t lds_allowed = 48 * 1024;
-        if (lds > lds_allowed) {
-            if (hipFuncSetAttribute((const void *)k_project_hits<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-                hipSuccess)
-                return CM3D_ERR_LAUNCH;
-            lds_allowed = lds;
+        static size_t lds_allowed[2] = {48 * 1024, 48 * 1024};
+        if (lds > lds_allowed[fused ? 1 : 0]) {
+            const void *fn = fused ? (const void *)k_project_hits<false, true> : (const void *)k_project_hits<false, false>;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CM3D_ERR_LAUNCH;
+            lds_allowed[fused ? 1 : 0] = lds;
         }
-        hipLaunchKernelGGL(k_project_hits<false>, dim3(gx, n_frames), dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off,
-                           n_points_total, cams, n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist, nm_cap,
-                           nblk_max, chunks_per_block, hit_words, hit_count, (int32_t *)workspace, status);
+        if (fused) PH_LAUNCH(false, true); else PH_LAUNCH(false, false);
     }
+#undef PH_LAUNCH
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
+}
+
+extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
+                                 int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off,
+                                 const int32_t *mask_cam, const int32_t *bbox, const uint32_t *packed, int32_t n_masks,
+                                 int32_t W, int32_t H, float min_dist, int32_t planes, uint32_t *hit_words,
+                                 int32_t *hit_count, int32_t *status, void *workspace, int64_t workspace_bytes,
+                                 cm3d_stream_t stream)
+{
+    if (!points || !pt_off) return CM3D_ERR_ARG;
+    return ph_launch(nullptr, points, pt_off, n_frames, max_pts_per_frame, n_points_total, cams, n_cams, mask_off, mask_cam, bbox,
+                     packed, n_masks, W, H, min_dist, planes, hit_words, hit_count, status, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
+                                       int32_t max_sweeps_per_frame, const float *sweep_xf, const int32_t *frame_sweep_off,
+                                       float halfw, float *points, int32_t pt_cap, int32_t *pt_off, int32_t *removed_cnt,
+                                       int32_t *removed_idx, int32_t n_frames, int32_t max_pts_per_frame, int32_t n_points_total,
+                                       const float *cams, int32_t n_cams, const int32_t *mask_off, const int32_t *mask_cam,
+                                       const int32_t *bbox, const uint32_t *packed, int32_t n_masks, int32_t W, int32_t H,
+                                       float min_dist, int32_t planes, uint32_t *hit_words, int32_t *hit_count, int32_t *status,
+                                       void *workspace, int64_t workspace_bytes, cm3d_stream_t stream)
+{
+    if (!raw || !sweep_row_off || !sweep_xf || !frame_sweep_off || !points || !pt_off || !removed_cnt || !removed_idx) return CM3D_ERR_ARG;
+    if (raw_stride < 4 || n_sweeps <= 0 || pt_cap <= 0 || ((uintptr_t)points & 15)) return CM3D_ERR_ARG;
+    if (max_sweeps_per_frame <= 0 || max_sweeps_per_frame > PH_MAX_SWEEPS) return CM3D_ERR_ARG;
+    PhSweepIn sw;
+    sw.raw = raw; sw.raw_stride = raw_stride; sw.sweep_row_off = sweep_row_off; sw.sweep_xf = sweep_xf;
+    sw.frame_sweep_off = frame_sweep_off; sw.n_frames = n_frames; sw.n_sweeps = n_sweeps; sw.halfw = halfw;
+    sw.points_out = (float4 *)points; sw.pt_cap = pt_cap; sw.pt_off_out = pt_off; sw.removed_cnt = removed_cnt;
+    sw.removed_idx = removed_idx;
+    return ph_launch(&sw, points, pt_off, n_frames, max_pts_per_frame, n_points_total, cams, n_cams, mask_off, mask_cam, bbox, packed,
+                     n_masks, W, H, min_dist, planes, hit_words, hit_count, status, workspace, workspace_bytes, stream);
 }
 
 extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, const int32_t *pt_off, int32_t n_frames,

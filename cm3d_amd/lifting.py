@@ -231,6 +231,7 @@ class LiftEngine:
         self.mask_stream = torch.cuda.Stream(device=d)       # mask expansion/erosion overlaps the sweep preparation
         self.masks_done = torch.cuda.Event()
         self.overlap_masks = os.environ.get("CM3D_OVERLAP_MASKS", "0") == "1"
+        self.fused_sweeps = os.environ.get("CM3D_FUSED_SWEEPS", "1") == "1"    # 0: separate sweep and projection launches
         self.prior_wlh = torch.from_numpy(self.classes.prior_wlh).to(d)
         self.is_vehicle = torch.from_numpy(self.classes.is_vehicle).to(d)
         self.nms_thr = torch.from_numpy(self.classes.nms_thr).to(d)
@@ -263,6 +264,7 @@ class LiftEngine:
         b.lane = t(hb.lane); b.lane_off = t(hb.lane_off); b.frame_lane = t(hb.frame_lane); b.ego_xyz = t(hb.ego_xyz)
         b.pt_cap = hb.n_raw_rows
         b.max_pts = int(max(hb.sweep_row_off[hb.frame_sweep_off[1:]] - hb.sweep_row_off[hb.frame_sweep_off[:-1]]))
+        b.max_sweeps = int(np.max(np.diff(hb.frame_sweep_off))) if hb.frame_sweep_off.size > 1 else 0
         b.planes = (nm_max + 31) // 32
         b.idx_cap = int(max(1024, self.hits_per_point * b.pt_cap))
         e = lambda *shape, dtype=torch.int32: torch.empty(*shape, dtype=dtype, device=d)
@@ -364,6 +366,20 @@ class LiftEngine:
                                          self.min_dist, b.planes, _ptr(b.hit_words), _ptr(b.hit_count), _ptr(b.status),
                                          _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_project_hits")
 
+    def can_fuse_sweeps(self):
+        return self.fused_sweeps and 0 < self.b.max_sweeps <= _lib.MAX_FUSED_SWEEPS
+
+    def stage_sweep_project(self, st):
+        """Sweep preparation folded into the projection kernel (cm3d_sweep_project_hits): same outputs as
+        stage_sweeps + stage_project, the cloud crosses HBM once less.  Needs the masks of the batch (stage_masks) first."""
+        b = self.b
+        check(self.lib.cm3d_sweep_project_hits(_ptr(b.raw), b.hb.raw_stride, _ptr(b.sweep_row_off), b.S, b.max_sweeps, _ptr(b.sweep_xf),
+                                               _ptr(b.frame_sweep_off), b.halfw, _ptr(b.points), b.pt_cap, _ptr(b.pt_off),
+                                               _ptr(b.removed_cnt), _ptr(b.removed_idx), b.F, b.max_pts, b.pt_cap, _ptr(b.cams),
+                                               b.hb.n_cams, _ptr(b.mask_off), _ptr(b.mask_cam), _ptr(b.bbox), _ptr(b.packed), b.M, b.W,
+                                               b.H, self.min_dist, b.planes, _ptr(b.hit_words), _ptr(b.hit_count), _ptr(b.status),
+                                               _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_sweep_project_hits")
+
     def stage_compact(self, st):
         b = self.b
         check(self.lib.cm3d_compact_hits(_ptr(b.hit_words), b.planes, _ptr(b.pt_off), b.F, b.max_pts, b.pt_cap, _ptr(b.mask_off),
@@ -404,18 +420,28 @@ class LiftEngine:
 
     STAGES = ("sweeps", "masks", "project", "compact", "medoid", "lanes", "boxes")
 
-    def run(self, masks="dense"):
-        """One pass of the hot path over the resident batch (asynchronous)."""
+    def run(self, masks="dense", project_events=None):
+        """One pass of the hot path over the resident batch (asynchronous).  project_events: optional pair of
+        torch.cuda.Event recorded around the projection launch on the launch stream (bench.py's roofline timing)."""
         st = torch.cuda.current_stream(self.dev).cuda_stream
         self.stage_begin(st)
         if self.overlap_masks:
             self.stage_masks_async(masks)
             self.stage_sweeps(st)
             self.wait_masks()
-        else:
+        elif not self.can_fuse_sweeps():
             self.stage_sweeps(st)
             self.stage_masks(st, masks)
-        self.stage_project(st)
+        else:
+            self.stage_masks(st, masks)
+        if project_events is not None:
+            project_events[0].record()
+        if self.overlap_masks or not self.can_fuse_sweeps():
+            self.stage_project(st)
+        else:
+            self.stage_sweep_project(st)
+        if project_events is not None:
+            project_events[1].record()
         self.stage_compact(st)
         self.stage_medoid(st)
         self.wait_lane_grid()
@@ -472,6 +498,54 @@ class LiftEngine:
         if b.colsum is not None:
             out["colsum"] = b.colsum[:n_idx].cpu().numpy()
         return out
+
+
+class LiftPipeline:
+    """Keeps `depth` independent lift batches in flight: one LiftEngine (own device buffers) per HIP stream, batches
+    issued round-robin.  Frames are independent (SURVEY 8e), so consecutive batches of a job never wait for each other;
+    a pass is a chain of ~12 dependent launches whose tail (scans, lane search, boxes: a few hundred waves) leaves most
+    of the 256 CUs idle, and the next batch's HBM-bound stages run there.  Measured on the C2 batch: 863 k frames/s with
+    one batch in flight, 997 k with two, 1.05-1.08 M with three (four or more: no further gain)."""
+
+    def __init__(self, device="cuda:0", depth=3, **engine_kw):
+        if depth < 1:
+            raise ValueError("depth >= 1")
+        self.dev = torch.device(device)
+        self.engines = [LiftEngine(device, **engine_kw) for _ in range(depth)]
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(depth)]
+        self.masks = [None] * depth
+        self._next = 0
+
+    @property
+    def depth(self):
+        return len(self.engines)
+
+    def submit(self, hb: HostBatch, masks="rle"):
+        """Uploads `hb` into the next slot and issues one pass over it on that slot's stream (asynchronous).
+        Returns the slot; `collect(slot)` must be called before the slot comes round again."""
+        slot = self._next
+        self._next = (slot + 1) % self.depth
+        eng = self.engines[slot]
+        with torch.cuda.stream(self.streams[slot]):
+            eng.upload(hb)
+            if masks == "dense":
+                eng.decode_masks_dense()
+            eng.run(masks=masks)
+        self.masks[slot] = masks
+        return slot
+
+    def rerun(self, slot, masks=None, project_events=None):
+        """Another pass over the batch resident in `slot` (benchmarks)."""
+        with torch.cuda.stream(self.streams[slot]):
+            self.engines[slot].run(masks=masks or self.masks[slot], project_events=project_events)
+
+    def collect(self, slot):
+        """Waits for the slot's stream only and returns (host batch, numpy results)."""
+        self.streams[slot].synchronize()
+        eng = self.engines[slot]
+        with torch.cuda.stream(self.streams[slot]):
+            res = eng.download()
+        return eng.b.hb, res
 
 
 def box_records(hb: HostBatch, res: dict, classes: Optional[ClassTable] = None):

@@ -40,7 +40,16 @@ def lift_scenes(tables, scene_names, mask_dir, classes, device, n_sweeps=3, rati
     """Runs the hot path over the given scenes; returns {sample_token: [box dict, ...]} in sample order."""
     timer = timer if timer is not None else {}
     results = {}
-    eng = lifting.LiftEngine(device, classes=classes)
+    pipe = lifting.LiftPipeline(device, depth=2, classes=classes)      # batch i+1 is read and uploaded while batch i runs
+    pending = []                                                       # slots in flight, oldest first
+
+    def drain(keep):
+        while len(pending) > keep:
+            t1 = time.time()
+            hb, res = pipe.collect(pending.pop(0))
+            timer["gpu lifting"] = timer.get("gpu lifting", 0.0) + time.time() - t1
+            results.update(lifting.box_records(hb, res, classes))
+
     for b0 in range(0, len(scene_names), scenes_per_batch):
         t0 = time.time()
         frames, lanes, frame_lane = [], [], []
@@ -63,14 +72,10 @@ def lift_scenes(tables, scene_names, mask_dir, classes, device, n_sweeps=3, rati
             sel = [i for i in live if (frames[i].width, frames[i].height) == (W, H)]
             t1 = time.time()
             hb = lifting.pack_frames([frames[i] for i in sel], lanes, [frame_lane[i] for i in sel], classes)
-            eng.upload(hb)
-            if masks == "dense":
-                eng.decode_masks_dense()
-            eng.run(masks=masks)
-            torch.cuda.synchronize()
-            res = eng.download()
+            drain(pipe.depth - 1)                                      # the slot about to be reused is free
+            pending.append(pipe.submit(hb, masks))
             timer["gpu lifting"] = timer.get("gpu lifting", 0.0) + time.time() - t1
-            results.update(lifting.box_records(hb, res, classes))
+    drain(0)
     return results
 
 

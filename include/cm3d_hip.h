@@ -137,6 +137,22 @@ int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_fram
                       int32_t *hit_count, int32_t *status, void *workspace, int64_t workspace_bytes,
                       cm3d_stream_t stream);
 
+/* a2 + a4-a7 in one launch: cm3d_sweep_prep folded into cm3d_project_hits.  The kernel reads the raw sweep rows,
+ * applies the ego-box drop and the sensor -> ego -> global chains (2d_to_3d.py:437-465) on the fly, writes the
+ * transformed cloud (`points`, for cm3d_medoid and the caller), pt_off, the dropped-row lists and status[1] exactly as
+ * cm3d_sweep_prep does, and produces hit_words / hit_count exactly as cm3d_project_hits does: same results, one pass
+ * over the cloud less.  max_sweeps_per_frame (host-side knowledge of frame_sweep_off) must be <= 16; use the two
+ * separate calls otherwise.  Arguments as in cm3d_sweep_prep and cm3d_project_hits. */
+#define CM3D_MAX_FUSED_SWEEPS 16
+int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
+                            int32_t max_sweeps_per_frame, const float *sweep_xf, const int32_t *frame_sweep_off,
+                            float halfw, float *points, int32_t pt_cap, int32_t *pt_off, int32_t *removed_cnt,
+                            int32_t *removed_idx, int32_t n_frames, int32_t max_pts_per_frame, int32_t n_points_total,
+                            const float *cams, int32_t n_cams, const int32_t *mask_off, const int32_t *mask_cam,
+                            const int32_t *bbox, const uint32_t *packed, int32_t n_masks, int32_t W, int32_t H,
+                            float min_dist, int32_t planes, uint32_t *hit_words, int32_t *hit_count, int32_t *status,
+                            void *workspace, int64_t workspace_bytes, cm3d_stream_t stream);
+
 /* ---- a7-a8: ordered compaction of the hits ----------------------------------
  * Replaces torch.where + the two .cpu() index-tracking steps at 2d_to_3d.py:606,613-617.
  *  removed_cnt / removed_idx  from cm3d_sweep_prep (both NULL when the points were not produced by it)

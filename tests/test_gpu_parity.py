@@ -384,3 +384,64 @@ def test_graph_replay_equals_eager(oracle):
             assert np.array_equal(eager[k], got[k], equal_nan=True), k
     exp = oracle_batch(oracle, frames, lanes, [0] * 4, hb)
     _compare(hb, got, exp)
+
+
+def test_pipeline_slots_and_unfused_path(oracle):
+    """LiftPipeline (several batches in flight on their own streams, slots reused) gives every batch the oracle's
+    results; the separate sweep + projection launches (CM3D_FUSED_SWEEPS=0, or more than 16 sweeps in a frame) give
+    exactly what the fused launch gives."""
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config("tiny")
+    pipe = lifting.LiftPipeline("cuda:0", depth=2)
+    batches, slots = [], []
+    for k in range(5):
+        frames = [syn.make_frame(cfg, 100 * k + i) for i in range(2 + k % 3)]
+        lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 3000, seed=k)]
+        fl = [0] * len(frames)
+        hb = lifting.pack_frames(frames, lanes, fl)
+        if len(slots) == pipe.depth:
+            s0, (f0, l0, fl0, hb0) = slots.pop(0), batches.pop(0)
+            got_hb, got = pipe.collect(s0)
+            assert got_hb is hb0
+            _compare(hb0, got, oracle_batch(oracle, f0, l0, fl0, hb0))
+        slots.append(pipe.submit(hb, "rle"))
+        batches.append((frames, lanes, fl, hb))
+    while slots:
+        s0, (f0, l0, fl0, hb0) = slots.pop(0), batches.pop(0)
+        _, got = pipe.collect(s0)
+        _compare(hb0, got, oracle_batch(oracle, f0, l0, fl0, hb0))
+    # fused against separate launches, and the many-sweeps fallback against the oracle
+    cfg3 = syn.config("tiny", n_sweeps=3, n_points=2500)
+    frames = [syn.make_frame(cfg3, i) for i in range(3)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 3000, seed=1)]
+    hb = lifting.pack_frames(frames, lanes, [0] * 3)
+    outs = []
+    for fused in (True, False):
+        eng = lifting.LiftEngine()
+        eng.fused_sweeps = fused
+        eng.upload(hb)
+        assert eng.can_fuse_sweeps() == fused
+        eng.run(masks="rle")
+        torch.cuda.synchronize()
+        outs.append(eng.download())
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    _compare(hb, outs[0], oracle_batch(oracle, frames, lanes, [0] * 3, hb))
+    cfg17 = syn.config("tiny", n_sweeps=17, n_points=400)
+    frames = [syn.make_frame(cfg17, i) for i in range(2)]
+    hb = lifting.pack_frames(frames, lanes, [0] * 2)
+    eng = lifting.LiftEngine()
+    eng.upload(hb)
+    assert not eng.can_fuse_sweeps()
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    _compare(hb, eng.download(), oracle_batch(oracle, frames, lanes, [0] * 2, hb))
+    cfg16 = syn.config("tiny", n_sweeps=16, n_points=400)
+    frames = [syn.make_frame(cfg16, i) for i in range(2)]
+    hb = lifting.pack_frames(frames, lanes, [0] * 2)
+    eng.upload(hb)
+    assert eng.can_fuse_sweeps()
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    _compare(hb, eng.download(), oracle_batch(oracle, frames, lanes, [0] * 2, hb))

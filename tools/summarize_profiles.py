@@ -12,7 +12,8 @@ import os
 import shutil
 import sys
 
-STREAM_READERS = {"k_project_hits", "k_erode_pack"}        # float4 / uint4 coalesced point and mask streams
+STREAM_READERS = {"k_project_hits_unfused", "k_erode_pack"}        # float4 / uint4 coalesced point and mask streams
+# (the default pass runs k_project_hits<.., FUSED = true>, which reads the raw sweep rows dword by dword: no correction)
 
 
 def kname(full):
@@ -20,7 +21,10 @@ def kname(full):
     n = full.split("(")[0].strip()
     if n.startswith("void "):
         n = n[5:]
-    return n.split("<")[0]
+    base = n.split("<")[0]
+    if base == "k_project_hits" and n.replace(" ", "").endswith(",false>"):
+        return "k_project_hits_unfused"
+    return base
 
 
 def main(tag):

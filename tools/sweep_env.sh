@@ -6,6 +6,6 @@ for v in "$@"; do
   python - "$v" <<'PY'
 import json, sys
 d = json.load(open(f"/tmp/sweep_{sys.argv[1]}.json"))
-print(sys.argv[1], d["value"], d["kernels"]["stage_ms"])
+print(sys.argv[1], d["value"], d["kernels"]["stage_ms_one_batch_alone"])
 PY
 done

@@ -7,6 +7,6 @@ for envs in "$@"; do
   python - "$envs" "$i" <<'PY'
 import json, sys
 d = json.load(open(f"/tmp/sweepset_{sys.argv[2]}.json"))
-print(sys.argv[1], d["value"], d["kernels"]["stage_ms"])
+print(sys.argv[1], d["value"], d["kernels"]["stage_ms_one_batch_alone"])
 PY
 done
