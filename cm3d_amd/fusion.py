@@ -169,39 +169,96 @@ def grid_search(pred_objects, sam3d_objects, evaluate, out_path, best_path, iou=
 
 
 # ------------------------------------------------------------------ Waymo (src/waymo/linear_matching.py)
-def fuse_waymo(pred, sam3d, alpha, iou=0.2):
-    """src/waymo/linear_matching.py:165-470 on plain records instead of metrics_pb2.Objects: pred / sam3d are
-    lists of dicts {context_name, frame_timestamp_micros, box: [cx,cy,cz,l,w,h,heading], score, id, type}
-    (what cm3d_amd.waymo decodes).  Same three groups as fuse(); headings are used as stored.  Returns the
-    merged list of records."""
-    def group(objs):
-        boxes, supp = {}, {}
-        for o in objs:
-            k = (o["context_name"], o["frame_timestamp_micros"])
-            b = o["box"]
-            boxes.setdefault(k, []).append(np.array([b[0], b[1], b[2] - b[5] / 2, b[3], b[4], b[5], b[6]], dtype=float))
-            supp.setdefault(k, []).append(o)
-        return boxes, supp
-    pb, ps = group(pred)
-    sb, ss = group(sam3d)
-    pm, sm = match_samples(pb, sb, iou)
+def waymo_parse(objs, zero_min_quirk=False):
+    """src/waymo/linear_matching.py:165-247 on decoded Objects (cm3d_amd.waymo.decode_objects): per (context, timestamp)
+    the boxes [cx, cy, bottom_z, length, width, height, heading] and the objects themselves; score range as in
+    parse_results."""
+    boxes, supp = {}, {}
+    max_conf, min_conf = -1e7, 1e7
+    for o in objs:
+        k = (o["context_name"], o["timestamp_micros"])
+        c = o["center"]
+        boxes.setdefault(k, []).append(np.array([c[0], c[1], c[2] - o["height"] / 2, o["length"], o["width"], o["height"], o["heading"]],
+                                                dtype=float))
+        supp.setdefault(k, []).append(o)
+        s = o["score"]
+        if s > max_conf:
+            max_conf = s
+        if s < min_conf and (not zero_min_quirk or s != 0):
+            min_conf = s
+    return boxes, supp, max_conf, min_conf
 
-    def rec(k, b, src, score):
-        return {"context_name": k[0], "frame_timestamp_micros": k[1],
-                "box": [float(b[0]), float(b[1]), float(b[2]) + float(b[5]) / 2, float(b[3]), float(b[4]), float(b[5]), float(b[6])],
-                "score": score, "id": src["id"], "type": src["type"]}
+
+def waymo_alpha_grid(pred_min_conf, pred_max_conf, sam3d_min_conf, sam3d_max_conf, step=0.04):
+    """src/waymo/linear_matching.py:322-328: the grid runs downwards and skips its three largest values."""
+    a = np.arange(pred_min_conf / sam3d_max_conf, pred_max_conf / sam3d_min_conf + step, step, dtype=float)
+    return list(a)[::-1][3:]
+
+
+def fuse_waymo(pb, ps, sb, ss, pm, sm, alpha):
+    """src/waymo/linear_matching.py:335-470 for one alpha: unmatched predictions, unmatched SAM3D boxes (score x alpha,
+    clipped), then per matched pair the box of the higher score under the prediction's id and type.  Returns the
+    encoded metrics_pb2.Object payloads (cm3d_amd.waymo.encode_objects serialises them)."""
+    from . import waymo as wm
+
+    def enc(k, b, src, score):
+        return wm.encode_object([float(b[0]), float(b[1]), float(b[2]) + float(b[5]) / 2], length=float(b[3]), width=float(b[4]),
+                                height=float(b[5]), heading=float(b[6]), type_id=src["type"], score=score, context_name=k[0],
+                                timestamp_micros=k[1], object_id=src["id"])
     out = []
     for k in pb:
-        out += [rec(k, b, ps[k][i], ps[k][i]["score"]) for i, b in enumerate(pb[k]) if i not in pm[k]]
+        out += [enc(k, b, ps[k][i], ps[k][i]["score"]) for i, b in enumerate(pb[k]) if i not in pm[k]]
     for k in sb:
-        out += [rec(k, b, ss[k][i], float(np.clip(ss[k][i]["score"] * alpha, 0, 1))) for i, b in enumerate(sb[k])
-                if i not in sm.get(k, [])]
+        matched = sm.get(k, [])
+        out += [enc(k, b, ss[k][i], float(np.clip(ss[k][i]["score"] * alpha, 0, 1))) for i, b in enumerate(sb[k]) if i not in matched]
     for k in pm:
         for j, pid in enumerate(pm[k]):
             sid = sm[k][j]
             s_score = ss[k][sid]["score"] * alpha
             if s_score > ps[k][pid]["score"]:
-                out.append(rec(k, sb[k][sid], ps[k][pid], float(np.clip(s_score, 0, 1))))
+                out.append(enc(k, sb[k][sid], ps[k][pid], float(np.clip(s_score, 0, 1))))
             else:
-                out.append(rec(k, pb[k][pid], ps[k][pid], ps[k][pid]["score"]))
+                out.append(enc(k, pb[k][pid], ps[k][pid], ps[k][pid]["score"]))
     return out
+
+
+def parse_waymo_metrics(text):
+    """src/waymo/linear_matching.py:484-537: the output of compute_detection_metrics_main -> AP dict; 'Overall' entries
+    are the mean over vehicle, pedestrian and cyclist.  Returns (ap_dict, ap_dict['Overall/L2 mAP'])."""
+    keys = [f"{c}/{l} {m}" for c in ("Vehicle", "Pedestrian", "Sign", "Cyclist", "Overall") for l in ("L1", "L2") for m in ("mAP", "mAPH")]
+    ap = {k: 0 for k in keys}
+    map_splits, maph_splits = text.split('mAP '), text.split('mAPH ')
+    for idx, key in enumerate(keys):
+        split_idx = int(idx / 2) + 1
+        if key.startswith("Overall"):
+            continue
+        ap[key] = float((map_splits if idx % 2 == 0 else maph_splits)[split_idx].split(']')[0])
+    for l in ("L1", "L2"):
+        for m in ("mAP", "mAPH"):
+            ap[f"Overall/{l} {m}"] = (ap[f"Vehicle/{l} {m}"] + ap[f"Pedestrian/{l} {m}"] + ap[f"Cyclist/{l} {m}"]) / 3
+    return ap, ap["Overall/L2 mAP"]
+
+
+def waymo_grid_search(pred_objs, sam3d_objs, evaluate, out_path, best_path, iou=0.2, verbose=True):
+    """src/waymo/linear_matching.py:165-547: match once (GPU), then per alpha write the fused Objects file to out_path, score
+    it with evaluate(out_path) -> Overall/L2 mAP and keep the best in best_path.  Returns (best_alpha, best_score)."""
+    from . import waymo as wm
+    sb, ss, s_max, s_min = waymo_parse(sam3d_objs, zero_min_quirk=True)
+    pb, ps, p_max, p_min = waymo_parse(pred_objs)
+    pm, sm = match_samples(pb, sb, iou)
+    best_alpha, best_score = 0, -1
+    for alpha in waymo_alpha_grid(p_min, p_max, s_min, s_max):
+        blob = wm.encode_objects(fuse_waymo(pb, ps, sb, ss, pm, sm, alpha))
+        os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+        with open(out_path, "wb") as f:
+            f.write(blob)
+        score = float(evaluate(out_path))
+        if score > best_score:
+            best_score, best_alpha = score, alpha
+            with open(best_path, "wb") as f:
+                f.write(blob)
+        if verbose:
+            print(f"Curr Score: {score},  Curr Alpha: {alpha}")
+            print(f"Best Score: {best_score}, Best Alpha: {best_alpha}")
+            print("-" * 80)
+    return best_alpha, best_score

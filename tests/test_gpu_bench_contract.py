@@ -1,0 +1,45 @@
+"""GPU: bench.py prints ONE JSON line with the fields the driver and the tier contract name (small workload)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, "bench.py", *args], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_lifting_bench_line():
+    d = _run("--config", "tiny", "--frames", "8", "--steps", "6", "--warmup", "2", "--cpu-sample", "2", "--cpu-workers", "2",
+             "--lane-points", "2000")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert d["value"] > 0 and abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    assert "workload" in d["config"] and d["config"]["batches_in_flight"] == 3
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["sample"]
+    assert d["value"] > 20 * cb["value"]
+    one = _run("--config", "tiny", "--frames", "8", "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--no-secondary", "--in-flight", "1",
+               "--lane-points", "2000")
+    assert one["config"]["batches_in_flight"] == 1 and one["cpu_baseline"] is None
+
+
+def test_fusion_bench_line():
+    d = _run("--fusion", "300", "--steps", "5", "--warmup", "1")
+    assert d["unit"] == "samples/s" and d["equals_oracle"] is True and d["matches"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
