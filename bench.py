@@ -324,6 +324,17 @@ def main():
                         "algorithmic bytes = 16 B/point + every bit-packed mask once + 4 B/point hit word (SURVEY 8d); the kernel's "
                         "bounding-box test lets it skip most mask bytes, so `achieved` exceeds what HBM allows for a full read; "
                         "traffic_rate = measured HBM bytes / time; the kernel is instruction-issue bound")
+    # the box's own streaming rate beside the nominal peak: device-to-device copy of 1 GiB, read + write bytes
+    src_buf = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    dst_buf = torch.empty_like(src_buf)
+    dst_buf.copy_(src_buf)
+    torch.cuda.synchronize()
+    t_cp = time.perf_counter()
+    for _ in range(5):
+        dst_buf.copy_(src_buf)
+    torch.cuda.synchronize()
+    roofline["measured_copy_GBs"] = round(5 * 2 * src_buf.numel() * 4 / (time.perf_counter() - t_cp) / 1e9, 1)
+    del src_buf, dst_buf
     roofline["batches_in_flight"] = depth
     roofline["avg_launch_ms_alone"] = round(r["project_alone_ms"], 4)      # the same launch with nothing else on the GPU
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
