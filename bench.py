@@ -167,8 +167,8 @@ def fusion_bench(n_samples, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--config", default="c2", help="synthetic config (c1,c2,c4,c5,tiny)")
     ap.add_argument("--masks", default="rle", choices=["rle", "dense"],
