@@ -123,3 +123,20 @@ def test_fusion_entry_point(tmp_path, oracle):
     want, counts = fusion.fuse(pb, ps, sb, ss, pm, sm, best_alpha)
     assert best == json.loads(json.dumps(want))
     assert counts["num_matched_boxes"] == n_matched and f"num_matched_boxes {n_matched}" in r.stdout
+
+
+def test_integration_md_fusion_binding_runs_as_written(oracle):
+    """The `match` stub printed in INTEGRATION.md for linear_matching.py, executed verbatim (library path filled in)."""
+    import re
+    from cm3d_amd import _lib, ops
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, re.S)
+    code = [b for b in blocks if "cm3d_bev_match" in b][0].replace('ctypes.CDLL("libcm3d_hip.so")', f'ctypes.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    rng = np.random.default_rng(31)
+    pred, gt = _rand_boxes(rng, 23, (640.0, 1600.0), 6.0), _rand_boxes(rng, 40, (640.0, 1600.0), 6.0)
+    ids, gids, ious = ns["match"](pred, gt, 0.2)
+    pm, gm, iou, _ = oracle.bev_match(ops.match_records(pred), ops.match_records(gt), 0.2)
+    want = np.flatnonzero(pm >= 0)
+    assert want.size > 3 and np.array_equal(ids, want) and np.array_equal(gids, pm[want]) and np.array_equal(ious, iou[want])
