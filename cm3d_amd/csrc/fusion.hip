@@ -15,7 +15,8 @@
 
 #define BM_KMAX 1000000        // IoU quantisation: weight = (int)(iou * BM_KMAX)
 #define BM_MAX_SIDE CM3D_MAX_MATCH_BOXES
-#define BM_INF (1ll << 50)
+#define BM_INF (1ll << 48)
+#define BM_SMALL 128              // samples up to this size on both sides: k_bev_assign_small<1>, <2>
 
 // Box record: cx, cy, length, width, cos(heading), sin(heading) (float64).
 // Intersection by clipping A against the four edges of B (both counter-clockwise), in coordinates
@@ -122,8 +123,8 @@ static __device__ __forceinline__ long long wave_min_i64(long long v)
 }
 
 // Hungarian method (potentials u on rows, v on columns; rows <= columns, every row gets a column).
-// Cost = BM_KMAX - weight >= 0, so a maximum-weight assignment is found; ties: the lowest column index
-// wins a step (the CPU oracle runs the same steps sequentially, the total weight is checked against an
+// Cost = BM_KMAX - weight >= 0, so a maximum-weight assignment is found; ties: an unassigned column wins a step
+// (the search ends there -- most of a sample's costs are the same "no overlap" value), then the lowest column index (the CPU oracle runs the same steps sequentially, the total weight is checked against an
 // independent solver in tests/).
 __global__ __launch_bounds__(64) void k_bev_assign(const double *__restrict__ pred, const int32_t *__restrict__ pred_off,
                                                    const double *__restrict__ gt, const int32_t *__restrict__ gt_off,
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(64) void k_bev_assign(const double *__restrict__ pr
     const int p0 = pred_off[f], g0 = gt_off[f];
     const int P = pred_off[f + 1] - p0, G = gt_off[f + 1] - g0;
     if (P <= 0 || G <= 0) return;
+    if (P <= BM_SMALL && G <= BM_SMALL) return;                          // k_bev_assign_small's
     if (P > BM_MAX_SIDE || G > BM_MAX_SIDE) {
         if (lane == 0) atomicOr(status, 1);
         return;
@@ -158,17 +160,17 @@ __global__ __launch_bounds__(64) void k_bev_assign(const double *__restrict__ pr
             __syncthreads();
             const int i0 = s_p[j0];
             const long long ui0 = s_u[i0];
-            long long key = (BM_INF << 12);
+            long long key = (BM_INF << 13);
             for (int j = 1 + lane; j <= m; j += 64) {
                 if (s_used[j]) continue;
                 const long long cur = (long long)(BM_KMAX - BM_W(i0, j)) - ui0 - s_v[j];
                 long long mv = s_minv[j];
                 if (cur < mv) { mv = cur; s_minv[j] = cur; s_way[j] = j0; }
-                const long long k = mv * 4096 + j;
+                const long long k = mv * 8192 + (s_p[j] != 0 ? 4096 : 0) + j;      // ties: an unassigned column first, then the lowest
                 key = k < key ? k : key;
             }
             key = wave_min_i64(key);
-            const long long delta = key >> 12;
+            const long long delta = key >> 13;
             const int j1 = (int)(key & 4095);
             __syncthreads();
             for (int j = lane; j <= m; j += 64) {
@@ -200,6 +202,117 @@ __global__ __launch_bounds__(64) void k_bev_assign(const double *__restrict__ pr
 #undef BM_W
 }
 
+// The same method for samples whose larger side has at most 64 * CPL boxes (CPL = 1, 2: nearly all samples): column j
+// lives in lane (j - 1) % 64, slot (j - 1) / 64 (potential, reduced cost, predecessor, assigned row in registers), row r's
+// potential likewise, the sample's weight matrix in LDS when it fits (else read from L2) -- no barrier inside the search.
+// Same steps, same ties, hence the same assignment as k_bev_assign and the oracle; int32 state is enough
+// here (|values| < 2^28).
+#define BM_SMALL_LDS 8192
+template <int CPL>
+static __device__ __forceinline__ int bm_get(const int (&a)[CPL], int idx)        // a[] of element idx (uniform idx)
+{
+    int r = __builtin_amdgcn_readlane(a[0], idx & 63);
+#pragma unroll
+    for (int k = 1; k < CPL; ++k) {
+        const int t = __builtin_amdgcn_readlane(a[k], idx & 63);
+        r = (idx >> 6) == k ? t : r;
+    }
+    return r;
+}
+
+template <int CPL>
+__global__ __launch_bounds__(64) void k_bev_assign_small(const double *__restrict__ pred, const int32_t *__restrict__ pred_off,
+                                                         const double *__restrict__ gt, const int32_t *__restrict__ gt_off,
+                                                         const int64_t *__restrict__ pair_off, const int32_t *__restrict__ weight,
+                                                         int32_t *__restrict__ pred_match, int32_t *__restrict__ gt_match,
+                                                         double *__restrict__ match_iou)
+{
+    __shared__ int s_w[BM_SMALL_LDS];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int p0 = pred_off[f], g0 = gt_off[f];
+    const int P = pred_off[f + 1] - p0, G = gt_off[f + 1] - g0;
+    const int big = P > G ? P : G;
+    if (P <= 0 || G <= 0 || big > 64 * CPL || (CPL > 1 && big <= 64 * (CPL - 1))) return;       // another kernel's sample
+    const int32_t *__restrict__ Wm = weight + pair_off[f];
+    const bool tr = P > G;
+    const int n = tr ? G : P, m = tr ? P : G;
+    const bool in_lds = n * m <= BM_SMALL_LDS;
+    if (in_lds) {                                // LDS image: row-major [n][m] in (row, column) order of the search
+        for (int q = lane; q < n * m; q += 64) {
+            const int i = q / m, j = q - i * m;
+            s_w[q] = tr ? Wm[(int64_t)j * G + i] : Wm[(int64_t)i * G + j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    auto wgt = [&](int i, int j) -> int {        // weight of row i, column j (1-based)
+        if (in_lds) return s_w[(i - 1) * m + (j - 1)];
+        return tr ? Wm[(int64_t)(j - 1) * G + (i - 1)] : Wm[(int64_t)(i - 1) * G + (j - 1)];
+    };
+    const int INF = 1 << 30;
+    int u[CPL], v[CPL], p[CPL], way[CPL];        // slot k: row / column k * 64 + lane + 1
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) { u[k] = 0; v[k] = 0; p[k] = 0; way[k] = 0; }
+    for (int i = 1; i <= n; ++i) {
+        int minv[CPL];
+        bool used[CPL], row_in_tree[CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) { minv[k] = INF; used[k] = false; row_in_tree[k] = false; }
+        int j0 = 0;
+        while (true) {
+            // column j0 joins the tree, with it the row assigned to it
+            const int i0 = j0 == 0 ? i : bm_get<CPL>(p, j0 - 1);
+            const int ui0 = bm_get<CPL>(u, i0 - 1);
+            long long key = ((long long)INF << 9);
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int col = k * 64 + lane + 1;
+                if (col == j0) used[k] = true;
+                if (col == i0) row_in_tree[k] = true;
+                if (col <= m && !used[k]) {
+                    const int cur = (BM_KMAX - wgt(i0, col)) - ui0 - v[k];
+                    if (cur < minv[k]) { minv[k] = cur; way[k] = j0; }
+                    const long long kk = (long long)minv[k] * 512 + (p[k] != 0 ? 256 : 0) + col;   // unassigned column first
+                    key = kk < key ? kk : key;
+                }
+            }
+            key = wave_min_i64(key);
+            const int delta = (int)(key >> 9);
+            const int j1 = __builtin_amdgcn_readfirstlane((int)(key & 255));
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                if (row_in_tree[k]) u[k] += delta;
+                if (used[k]) v[k] -= delta; else minv[k] -= delta;
+            }
+            j0 = j1;
+            if (bm_get<CPL>(p, j0 - 1) == 0) break;
+        }
+        // augment along the predecessor chain (uniform pointer chasing through lane reads)
+        do {
+            const int j1 = bm_get<CPL>(way, j0 - 1);
+            const int pr = j1 == 0 ? i : bm_get<CPL>(p, (j1 == 0 ? 1 : j1) - 1);
+#pragma unroll
+            for (int k = 0; k < CPL; ++k)
+                if (k * 64 + lane + 1 == j0) p[k] = pr;
+            j0 = j1;
+        } while (j0);
+    }
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int col = k * 64 + lane + 1;
+        if (col <= m && p[k] != 0) {
+            const int i = p[k];
+            if (wgt(i, col) > 0) {
+                const int pi = tr ? col - 1 : i - 1, gi = tr ? i - 1 : col - 1;
+                pred_match[p0 + pi] = gi;
+                gt_match[g0 + gi] = pi;
+                match_iou[p0 + pi] = bev_iou(pred + (int64_t)(p0 + pi) * 6, gt + (int64_t)(g0 + gi) * 6);
+            }
+        }
+    }
+}
+
 extern "C" int64_t cm3d_bev_match_workspace_bytes(int64_t total_pairs)
 {
     return (total_pairs > 0 ? total_pairs : 1) * (int64_t)sizeof(int32_t);
@@ -225,6 +338,12 @@ extern "C" int cm3d_bev_match(const double *pred, const int32_t *pred_off, int32
     int32_t *weight = (int32_t *)workspace;
     hipLaunchKernelGGL(k_bev_weights, dim3((unsigned)((total_pairs + 255) / 256)), dim3(256), 0, st, pred, pred_off, gt, gt_off,
                        pair_off, n_frames, total_pairs, iou_thr, weight);
+    CM3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_bev_assign_small<1>, dim3(n_frames), dim3(64), 0, st, pred, pred_off, gt, gt_off, pair_off, weight, pred_match,
+                       gt_match, match_iou);
+    CM3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_bev_assign_small<2>, dim3(n_frames), dim3(64), 0, st, pred, pred_off, gt, gt_off, pair_off, weight, pred_match,
+                       gt_match, match_iou);
     CM3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_bev_assign, dim3(n_frames), dim3(64), 0, st, pred, pred_off, gt, gt_off, pair_off, weight, pred_match,
                        gt_match, match_iou, status);

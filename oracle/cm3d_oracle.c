@@ -487,7 +487,7 @@ ORC_API void orc_box_assemble_waymo(const float *centroid_global, const float *p
  * (int)(iou * 1e6) when iou >= the type's threshold else 0, maximum-weight bipartite assignment (Hungarian
  * method on cost = 1e6 - weight, padded to square with zero-weight edges), pairs with zero weight dropped.
  * Where several assignments reach the maximum the third-party solver's choice is not known; this
- * restatement resolves a step's tie by the lowest column index.
+ * restatement resolves a step's tie by "unassigned column first, then lowest column index".
  * box = cx, cy, length, width, cos(heading), sin(heading). */
 static void orc_bev_corners(const double *b, double ox, double oy, double *X, double *Y)
 {
@@ -585,7 +585,8 @@ ORC_API int64_t orc_bev_match(const double *pred, int P, const double *gt, int G
                 if (used[j]) continue;
                 const int64_t cur = (int64_t)(ORC_KMAX - ORC_W(i0, j)) - u[i0] - v[j];
                 if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
-                if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+                /* ties: an unassigned column first (the search ends there), then the lowest index */
+                if (minv[j] < delta || (minv[j] == delta && p[j] == 0 && p[j1] != 0)) { delta = minv[j]; j1 = j; }
             }
             for (int j = 0; j <= m; ++j) {
                 if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
