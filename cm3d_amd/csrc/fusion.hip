@@ -92,19 +92,30 @@ __global__ __launch_bounds__(256) void k_bev_init(int32_t *__restrict__ pred_mat
     if (t < n_gt) gt_match[t] = -1;
 }
 
-__global__ __launch_bounds__(256) void k_bev_weights(const double *__restrict__ pred, const int32_t *__restrict__ pred_off,
-                                                     const double *__restrict__ gt, const int32_t *__restrict__ gt_off,
-                                                     const int64_t *__restrict__ pair_off, int n_frames, int64_t total_pairs,
-                                                     double thr, int32_t *__restrict__ weight)
+// first sample of every 256-pair block of k_bev_weights (one binary search per block instead of one per pair)
+__global__ __launch_bounds__(256) void k_bev_block_frames(const int64_t *__restrict__ pair_off, int n_frames, int64_t n_blocks,
+                                                          int32_t *__restrict__ blk_frame)
 {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total_pairs) return;
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_blocks) return;
+    const int64_t t = b * 256;
     int lo = 0, hi = n_frames;              // last f with pair_off[f] <= t
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (pair_off[mid] <= t) lo = mid; else hi = mid;
     }
-    const int f = lo;
+    blk_frame[b] = lo;
+}
+
+__global__ __launch_bounds__(256) void k_bev_weights(const double *__restrict__ pred, const int32_t *__restrict__ pred_off,
+                                                     const double *__restrict__ gt, const int32_t *__restrict__ gt_off,
+                                                     const int64_t *__restrict__ pair_off, const int32_t *__restrict__ blk_frame,
+                                                     int n_frames, int64_t total_pairs, double thr, int32_t *__restrict__ weight)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total_pairs) return;
+    int f = blk_frame[blockIdx.x];
+    while (f + 1 < n_frames && pair_off[f + 1] <= t) ++f;      // a block spans few samples
     const int G = gt_off[f + 1] - gt_off[f];
     const int64_t r = t - pair_off[f];
     const int p = (int)(r / G), g = (int)(r - (int64_t)p * G);
@@ -315,7 +326,8 @@ __global__ __launch_bounds__(64) void k_bev_assign_small(const double *__restric
 
 extern "C" int64_t cm3d_bev_match_workspace_bytes(int64_t total_pairs)
 {
-    return (total_pairs > 0 ? total_pairs : 1) * (int64_t)sizeof(int32_t);
+    const int64_t n = total_pairs > 0 ? total_pairs : 1;
+    return (n + (n + 255) / 256) * (int64_t)sizeof(int32_t);           // weights + the first sample of every 256-pair block
 }
 
 extern "C" int cm3d_bev_match(const double *pred, const int32_t *pred_off, int32_t n_pred, const double *gt,
@@ -336,8 +348,13 @@ extern "C" int cm3d_bev_match(const double *pred, const int32_t *pred_off, int32
     }
     if (total_pairs == 0) return CM3D_OK;
     int32_t *weight = (int32_t *)workspace;
-    hipLaunchKernelGGL(k_bev_weights, dim3((unsigned)((total_pairs + 255) / 256)), dim3(256), 0, st, pred, pred_off, gt, gt_off,
-                       pair_off, n_frames, total_pairs, iou_thr, weight);
+    int32_t *blk_frame = weight + total_pairs;
+    const int64_t n_blocks = (total_pairs + 255) / 256;
+    hipLaunchKernelGGL(k_bev_block_frames, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, pair_off, n_frames, n_blocks,
+                       blk_frame);
+    CM3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_bev_weights, dim3((unsigned)n_blocks), dim3(256), 0, st, pred, pred_off, gt, gt_off, pair_off, blk_frame,
+                       n_frames, total_pairs, iou_thr, weight);
     CM3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_bev_assign_small<1>, dim3(n_frames), dim3(64), 0, st, pred, pred_off, gt, gt_off, pair_off, weight, pred_match,
                        gt_match, match_iou);
