@@ -23,6 +23,10 @@
 #define MD_STAGE 512                     // rows of a list staged in a wave's LDS slice at a time (8 KiB)
 #endif
 
+#ifndef MD_LONG_MIN
+#define MD_LONG_MIN 512                  // lists longer than this (> 8 tiles) take the two-pass route (k_medoid_long)
+#endif
+
 typedef float f2 __attribute__((ext_vector_type(2)));      // two rows side by side: v_pk_{add,mul,fma}_f32
 typedef int i2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
@@ -104,7 +108,11 @@ static __device__ __forceinline__ f2 md_pair2(const float4 A, const float4 B, fl
 // adds the distances of `cnt` staged rows to s, in ascending row order.  8 rows per step: the distance chains
 // are independent (ILP, and the LDS reads of a step are issued together), only the adds into s are sequential
 // -- which is what fixes the float32 sum.
-template <bool DIRECT>
+// APPROX: the raw v_sqrt_f32 (within 1 ulp of the root on [1e-30, 1e30), cm3d_selftest_sqrt; 0 below) instead of the
+// correctly rounded root -- the first pass over long lists (k_medoid_long settles them)
+static __device__ __forceinline__ float md_asqrt(float x) { return x < 1.0e-30f ? 0.0f : __builtin_amdgcn_sqrtf(x); }
+
+template <bool DIRECT, bool APPROX = false>
 static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float qx, float qy, float qz, float qn, float s)
 {
 #ifndef MD_U
@@ -140,7 +148,10 @@ static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float
         float lo = fminf(d[0].x, d[0].y), hi = fmaxf(d[0].x, d[0].y);
 #pragma unroll
         for (int u = 1; u < U; ++u) { lo = fminf(lo, fminf(d[u].x, d[u].y)); hi = fmaxf(hi, fmaxf(d[u].x, d[u].y)); }
-        if (__ballot(!(lo >= 1.0e-30f && hi < 1.0e30f))) {
+        if (APPROX) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = (f2){md_asqrt(d[u].x), md_asqrt(d[u].y)};
+        } else if (__ballot(!(lo >= 1.0e-30f && hi < 1.0e30f))) {
 #pragma unroll
             for (int u = 0; u < U; ++u) d[u] = (f2){sqrtf(d[u].x), sqrtf(d[u].y)};
         } else {
@@ -154,7 +165,8 @@ static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float
         const f2 d = md_pair2<DIRECT>(s4[ii], s4[ii + 1], qx, qy, qz, qn);
         const bool two = ii + 1 < cnt;
         const bool bad = !md_sqrt_ok(d.x) || (two && !md_sqrt_ok(d.y));
-        const f2 r = __ballot(bad) ? (f2){sqrtf(d.x), sqrtf(d.y)} : md_sqrt_core2((f2){d.x, two ? d.y : 1.0f});
+        const f2 r = APPROX ? (f2){md_asqrt(d.x), md_asqrt(d.y)}
+                            : (__ballot(bad) ? (f2){sqrtf(d.x), sqrtf(d.y)} : md_sqrt_core2((f2){d.x, two ? d.y : 1.0f}));
         s = s + r.x;
         if (two) s = s + r.y;
     }
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
                                                               const int32_t *__restrict__ hit_row,
                                                               const TileDesc *__restrict__ desc,
                                                               TileBest *__restrict__ tile_best, int tile_cap,
-                                                              float *__restrict__ colsum_opt)
+                                                              float *__restrict__ colsum_opt, float *__restrict__ approx_opt)
 {
     __shared__ float4 s_row_all[MD_WAVES][MD_STAGE];
     const int wave = threadIdx.x >> 6, lane = cm3d_lane();
@@ -193,6 +205,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
         }
         float s = 0.f;
         const bool direct = M <= 25;
+        const bool approx = approx_opt != nullptr && M > MD_LONG_MIN;      // long list: approximate sums now, k_medoid_long later
         // Rows are staged MD_STAGE (512) at a time: all their index loads, then all their point gathers are in
         // flight together (two memory latencies per 512 rows; a 64-row pipeline left the longest lists -- the
         // waves the kernel waits for -- bound by one dependent gather per chunk).
@@ -216,7 +229,12 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int cnt = min(MD_STAGE, M - i0);
-            s = direct ? md_rows<true>(s_row, cnt, qx, qy, qz, qn, s) : md_rows<false>(s_row, cnt, qx, qy, qz, qn, s);
+            s = direct ? md_rows<true>(s_row, cnt, qx, qy, qz, qn, s)
+                       : (approx ? md_rows<false, true>(s_row, cnt, qx, qy, qz, qn, s) : md_rows<false>(s_row, cnt, qx, qy, qz, qn, s));
+        }
+        if (approx) {
+            if (act) approx_opt[off + j] = s;
+            continue;
         }
         if (act && colsum_opt) colsum_opt[off + j] = s;
         // first minimum over the tile's columns (torch.argmin: NaN counts as minimal, first wins)
@@ -243,11 +261,12 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
                                                        const int32_t *__restrict__ hit_off,
                                                        const int32_t *__restrict__ tile_off,
                                                        const int32_t *__restrict__ hit_row, int idx_cap,
-                                                       const TileBest *__restrict__ tile_best, int tile_cap,
+                                                       const TileBest *__restrict__ tile_best, int tile_cap, int two_pass,
                                                        int32_t *__restrict__ medoid_pos, float *__restrict__ centroid)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_masks) return;
+    if (two_pass && hit_off[m + 1] - hit_off[m] > MD_LONG_MIN) return;      // k_medoid_long's
     const int t0 = tile_off[m], t1 = min(tile_off[m + 1], tile_cap);
     int bj = -1;
     float bs = 0.f;
@@ -266,6 +285,119 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
     centroid[3 * m + 0] = cx; centroid[3 * m + 1] = cy; centroid[3 * m + 2] = cz;
 }
 
+// Long lists, second pass.  k_medoid_tiles left A_j, the column sums with v_sqrt_f32 roots in place of the correctly
+// rounded ones.  With t_i the exact and t'_i the approximate terms (|t'_i - t_i| <= 2^-23 t_i, or <= 1e-15 below 1e-30)
+// and both sums accumulated in the same order in float32 (each add rounds by <= 2^-24 of a partial sum, and partial sums
+// of non-negative terms never exceed the final sum), |A_j - S_j| <= E_j = max(A_j, S_j) (M + 1) 2^-23 + M 1e-15; the bound
+// used below is 1.01 (M + 2) 2^-23 A_j + M 1e-15 >= E_j for M < 10^5.  A column can only be the (first) minimum of the
+// exact sums if A_j - E_j <= min_k (A_k + E_k); those few columns -- the points within centimetres of the medoid -- get
+// their exact float32 sums here, 64 at a time, by the same row loop as k_medoid_tiles.  A non-finite A_j, or lists of
+// 10^5 points and more, make every column a candidate.  One wave per mask.
+__global__ __launch_bounds__(64) void k_medoid_long(const float4 *__restrict__ points, const int32_t *__restrict__ pt_off,
+                                                    const int32_t *__restrict__ mask_frame, int n_masks,
+                                                    const int32_t *__restrict__ hit_off, const int32_t *__restrict__ hit_row,
+                                                    int idx_cap, const float *__restrict__ approx,
+                                                    int32_t *__restrict__ medoid_pos, float *__restrict__ centroid)
+{
+    __shared__ float4 s_row[MD_STAGE];
+    __shared__ int s_cand[64];
+    const int m = blockIdx.x, lane = cm3d_lane();
+    const int off = hit_off[m], M = hit_off[m + 1] - off;
+    if (M <= MD_LONG_MIN || off + M > idx_cap) return;
+    const float4 *P = points + pt_off[mask_frame[m]];
+    const float *A = approx + off;
+    const double rel = 1.01 * (double)(M + 2) * 1.1920928955078125e-07, abs_e = (double)M * 1e-15;
+    // threshold = min_k (A_k + E_k); anything non-finite -> every column is a candidate
+    double thr = INFINITY;
+    bool all = M >= 100000;
+    for (int j = lane; j < M; j += 64) {
+        const double a = (double)A[j];
+        if (!(a >= 0.0 && a < 1e300)) all = true;
+        thr = fmin(thr, a + (a * rel + abs_e));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) thr = fmin(thr, __shfl_xor(thr, o, 64));
+    all = __ballot(all) != 0;
+    auto better = [](float s1, int j1, float s2, int j2) {   // is (s1,j1) ahead of (s2,j2)?  (torch.argmin order)
+        const bool n1 = s1 != s1, n2 = s2 != s2;
+        if (n1 != n2) return n1;
+        if (!n1 && s1 != s2) return s1 < s2;
+        return j1 < j2;
+    };
+    float best_s = INFINITY;
+    int best_j = 0x7FFFFFFF;
+    int nc = 0;                                   // candidates waiting in s_cand (uniform)
+    for (int j0 = 0; j0 < M + 64; j0 += 64) {     // one extra round flushes the tail
+        const int j = j0 + lane;
+        bool cand = false;
+        if (j < M) {
+            const double a = (double)A[j];
+            cand = all || (a - (a * rel + abs_e) <= thr);
+        }
+        const uint64_t cm = __ballot(cand);
+        const int add = (int)__popcll(cm);
+        const bool last = j0 >= M;
+        if (nc + add > 64 || (last && nc > 0)) {
+            // exact sums of the waiting candidates: lane l owns column s_cand[l]
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool act = lane < nc;
+            const int cj = act ? s_cand[lane] : 0;
+            float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
+            if (act) {
+                const float4 q = P[hit_row[off + cj]];
+                qx = q.x; qy = q.y; qz = q.z;
+                qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
+            }
+            float s = 0.f;
+            for (int i0 = 0; i0 < M; i0 += MD_STAGE) {
+                __builtin_amdgcn_wave_barrier();
+                float4 g[MD_STAGE / 64];
+#pragma unroll
+                for (int c = 0; c < MD_STAGE / 64; ++c)
+                    if (i0 + c * 64 + lane < M) g[c] = P[hit_row[off + i0 + c * 64 + lane]];
+#pragma unroll
+                for (int c = 0; c < MD_STAGE / 64; ++c) {
+                    if (i0 + c * 64 + lane < M) {
+                        float4 r = g[c];
+                        r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
+                        r.x = -2.0f * r.x; r.y = -2.0f * r.y; r.z = -2.0f * r.z;
+                        md_stage(s_row, c * 64 + lane, r);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                s = md_rows<false>(s_row, min(MD_STAGE, M - i0), qx, qy, qz, qn, s);
+            }
+            float bs = act ? s : INFINITY;
+            int bj = act ? cj : 0x7FFFFFFF;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float os = __shfl_xor(bs, o, 64);
+                const int oj = __shfl_xor(bj, o, 64);
+                if (better(os, oj, bs, bj)) { bs = os; bj = oj; }
+            }
+            if (bj != 0x7FFFFFFF && (best_j == 0x7FFFFFFF || better(bs, bj, best_s, best_j))) { best_s = bs; best_j = bj; }
+            nc = 0;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (cand) s_cand[nc + cm3d_mbcnt(cm)] = j;
+        nc += add;
+    }
+    if (lane == 0) {
+        const int bj = best_j == 0x7FFFFFFF ? -1 : best_j;
+        medoid_pos[m] = bj;
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        if (bj >= 0) {
+            const float4 p = P[hit_row[off + bj]];
+            cx = p.x; cy = p.y; cz = p.z;
+        }
+        centroid[3 * m + 0] = cx; centroid[3 * m + 1] = cy; centroid[3 * m + 2] = cz;
+    }
+}
+
 extern "C" int64_t cm3d_tile_work_bytes(int32_t n_masks, int32_t idx_cap)
 {
     if (n_masks <= 0 || idx_cap <= 0) return 0;
@@ -275,7 +407,8 @@ extern "C" int64_t cm3d_tile_work_bytes(int32_t n_masks, int32_t idx_cap)
 extern "C" int64_t cm3d_medoid_workspace_bytes(int32_t n_masks, int32_t idx_cap)
 {
     if (n_masks <= 0 || idx_cap <= 0) return 0;
-    return md_tile_cap(n_masks, idx_cap) * (int64_t)(sizeof(TileBest) + sizeof(TileDesc));
+    // work list + per-tile results + the first-pass column sums of the long lists
+    return md_tile_cap(n_masks, idx_cap) * (int64_t)(sizeof(TileBest) + sizeof(TileDesc)) + (int64_t)idx_cap * (int64_t)sizeof(float);
 }
 
 extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_frame, int32_t n_masks,
@@ -292,6 +425,10 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     const int tile_cap = (int)(tile_cap64 > 0x7FFFFFFF ? 0x7FFFFFFF : tile_cap64);
     TileDesc *own = (TileDesc *)workspace;
     TileBest *best = (TileBest *)(own + tile_cap);
+    // two passes for long lists unless the caller wants every exact column sum (colsum_opt) or CM3D_MD_TWO_PASS=0
+    static int two_pass_env = -1;
+    if (two_pass_env < 0) { const char *e = getenv("CM3D_MD_TWO_PASS"); two_pass_env = e ? atoi(e) : 1; }
+    float *approx = (two_pass_env && !colsum_opt) ? (float *)(best + tile_cap) : nullptr;
     const TileDesc *desc = (const TileDesc *)tile_work;
     if (!desc) {                                   // no work list from cm3d_compact_hits: build it here
         hipLaunchKernelGGL(k_medoid_desc, dim3(1), dim3(1024), 0, st, n_masks, hit_off, tile_off, idx_cap, tile_cap, own);
@@ -303,11 +440,16 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     if (const char *e = getenv("CM3D_MD_GRID")) gmax = atoi(e);
     if (grid > gmax) grid = gmax;
     hipLaunchKernelGGL(k_medoid_tiles, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
-                       tile_off, hit_row, desc, best, tile_cap, colsum_opt);
+                       tile_off, hit_row, desc, best, tile_cap, colsum_opt, approx);
     CM3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_medoid_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, (const float4 *)points, pt_off, mask_frame,
-                       n_masks, hit_off, tile_off, hit_row, idx_cap, best, tile_cap, medoid_pos, centroid);
+                       n_masks, hit_off, tile_off, hit_row, idx_cap, best, tile_cap, approx ? 1 : 0, medoid_pos, centroid);
     CM3D_CHECK_LAUNCH();
+    if (approx) {
+        hipLaunchKernelGGL(k_medoid_long, dim3(n_masks), dim3(64), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks, hit_off,
+                           hit_row, idx_cap, approx, medoid_pos, centroid);
+        CM3D_CHECK_LAUNCH();
+    }
     return CM3D_OK;
 }
 

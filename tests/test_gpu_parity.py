@@ -447,3 +447,29 @@ def test_pipeline_slots_and_unfused_path(oracle):
     eng.run(masks="rle")
     torch.cuda.synchronize()
     _compare(hb, eng.download(), oracle_batch(oracle, frames, lanes, [0] * 2, hb))
+
+
+def test_long_lists_two_pass_medoid(oracle):
+    """Lists of more than 512 in-mask points take the two-pass medoid (approximate column sums, then exact sums of the few
+    columns that can still be the minimum): positions and centroids must stay bit-identical to the oracle's."""
+    hb, got, exp = _run("tiny", 2, "rle", oracle, n_points=30000, n_sweeps=5, n_masks=14, width=512, height=288, ratio=0.32,
+                        min_area=6000.0, max_area=40000.0, empty_mask_prob=0.0, duplicate_prob=0.3, point_order="firing")
+    sizes = np.diff(exp["hit_off"])
+    assert (sizes > 512).sum() >= 4 and sizes.max() > 1500, sizes
+    assert "colsum" in got            # _run keeps the column sums -> exact path; now the default engine
+    _compare(hb, got, exp)
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config("tiny", n_points=30000, n_sweeps=5, n_masks=14, width=512, height=288, ratio=0.32, min_area=6000.0,
+                     max_area=40000.0, empty_mask_prob=0.0, duplicate_prob=0.3, point_order="firing")
+    frames = [syn.make_frame(cfg, i) for i in range(2)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 4000, seed=1), syn.make_lane_table(frames[-1].ego_xyz[:2], 3000, seed=2)]
+    hb2 = lifting.pack_frames(frames, lanes, [0, 1])
+    eng = lifting.LiftEngine()          # no colsum -> two-pass route for the long lists
+    eng.upload(hb2)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    got2 = eng.download()
+    assert np.array_equal(got2["medoid_pos"], exp["medoid_pos"])
+    assert np.array_equal(got2["centroid"].view(np.uint32), exp["centroid"].view(np.uint32))
+    _compare(hb2, got2, exp)
