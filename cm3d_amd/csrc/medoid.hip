@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
 // Long lists, second pass.  k_medoid_tiles left A_j, the column sums with v_sqrt_f32 roots in place of the correctly
 // rounded ones.  With t_i the exact and t'_i the approximate terms (|t'_i - t_i| <= 2^-23 t_i, or <= 1e-15 below 1e-30)
 // and both sums accumulated in the same order in float32 (each add rounds by <= 2^-24 of a partial sum, and partial sums
-// of non-negative terms never exceed the final sum), |A_j - S_j| <= E_j = max(A_j, S_j) (M + 1) 2^-23 + M 1e-15; the bound
-// used below is 1.01 (M + 2) 2^-23 A_j + M 1e-15 >= E_j for M < 10^5.  A column can only be the (first) minimum of the
+// of non-negative terms never exceed the final sum), |A_j - S_j| <= (2^-23 sum_i t_i + M 1e-15) + M 2^-24 (A_j + S_j) up to
+// factors 1 + O(M 2^-24); solved for A_j this stays below E_j = 1.01 (M + 2) 2^-23 A_j + M 2e-15 for M < 10^5.  A column can only be the (first) minimum of the
 // exact sums if A_j - E_j <= min_k (A_k + E_k); those few columns -- the points within centimetres of the medoid -- get
 // their exact float32 sums here, 64 at a time, by the same row loop as k_medoid_tiles.  A non-finite A_j, or lists of
 // 10^5 points and more, make every column a candidate.  One wave per mask.
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void k_medoid_long(const float4 *__restrict__ p
     if (M <= MD_LONG_MIN || off + M > idx_cap) return;
     const float4 *P = points + pt_off[mask_frame[m]];
     const float *A = approx + off;
-    const double rel = 1.01 * (double)(M + 2) * 1.1920928955078125e-07, abs_e = (double)M * 1e-15;
+    const double rel = 1.01 * (double)(M + 2) * 1.1920928955078125e-07, abs_e = (double)M * 2e-15;
     // threshold = min_k (A_k + E_k); anything non-finite -> every column is a candidate
     double thr = INFINITY;
     bool all = M >= 100000;
