@@ -140,11 +140,11 @@ def get_medoid(points, want_colsum=False):
     hit_off, tile_off = _t(np.array([0, M], np.int32)), _t(np.array([0, ntile], np.int32))
     hit_idx = _t(np.arange(M, dtype=np.int32))
     med, cen = _e(1), _e(1, 3, dtype=torch.float32)
-    colsum = _e(max(M, 1), dtype=torch.float32)
+    colsum = _e(max(M, 1), dtype=torch.float32) if want_colsum else None      # None: lists of > 512 points take the two-pass route
     ws = _ws(L.cm3d_medoid_workspace_bytes(1, max(M, 1)))
     check(L.cm3d_medoid(pts.data_ptr(), pt_off.data_ptr(), mask_frame.data_ptr(), 1, hit_off.data_ptr(), tile_off.data_ptr(),
-                        hit_idx.data_ptr(), max(M, 1), 0, med.data_ptr(), cen.data_ptr(), colsum.data_ptr(), ws.data_ptr(), ws.numel(),
-                        _st()), "cm3d_medoid")
+                        hit_idx.data_ptr(), max(M, 1), 0, med.data_ptr(), cen.data_ptr(), colsum.data_ptr() if want_colsum else 0,
+                        ws.data_ptr(), ws.numel(), _st()), "cm3d_medoid")
     j = int(med.cpu()[0])
     return (j, colsum.cpu().numpy()[:M]) if want_colsum else j
 

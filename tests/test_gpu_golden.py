@@ -194,3 +194,30 @@ def test_projection_division_shortcut_equals_ieee_division():
         bad, benign = (int(v) for v in n_bad.cpu())
         # [1]: numerators below 2^-103, both quotients below 1 in magnitude -- never an accepted pixel
         assert bad == 0, f"{bad} quotients of magnitude >= 1/8 differ (seed {seed}); {benign} tiny ones"
+
+
+def test_two_pass_medoid_on_near_ties(oracle):
+    """Long lists whose column sums are nearly or exactly tied -- the cases where the first (approximate) pass of the
+    two-pass medoid cannot decide and many columns must be settled exactly: points on a circle and on a sphere at
+    global-frame magnitudes, a lattice with many duplicated points, two identical far-apart clusters.  The position must
+    be the one the exact one-pass route (want_colsum) and the oracle find."""
+    from cm3d_amd import ops
+    rng = np.random.default_rng(41)
+    centre = np.array([612.0, 1634.0, 1.5])
+    cases = {}
+    a = np.linspace(0, 2 * np.pi, 700, endpoint=False)
+    cases["circle"] = centre + np.stack([4 * np.cos(a), 4 * np.sin(a), 0 * a], 1)
+    v = rng.normal(size=(1500, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    cases["sphere"] = centre + 3.0 * v
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(3), indexing="ij"), -1).reshape(-1, 3) * 0.25
+    cases["lattice_dups"] = centre + g[rng.integers(0, g.shape[0], 1200)]
+    c1 = rng.normal(0, 0.5, (400, 3))
+    cases["twin_clusters"] = centre + np.concatenate([c1, c1 + [30.0, 0, 0]])
+    cases["cloud_5000"] = centre + rng.normal(0, [2.0, 1.0, 0.5], (5000, 3))
+    for name, pts in cases.items():
+        p32 = pts.astype(np.float32)
+        want = oracle.medoid(np.concatenate([p32, np.zeros((len(p32), 1), np.float32)], 1), np.arange(len(p32)))
+        exact, _ = ops.get_medoid(p32.T, want_colsum=True)
+        got = ops.get_medoid(p32.T)
+        assert exact == want, name
+        assert got == want, name
