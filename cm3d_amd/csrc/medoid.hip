@@ -26,6 +26,8 @@
 #ifndef MD_LONG_MIN
 #define MD_LONG_MIN 512                  // lists longer than this (> 8 tiles) take the two-pass route (k_medoid_long)
 #endif
+#define MD_LONG_MAX 100000               // ... and shorter than this (the error bound of the first pass is derived for M < 10^5)
+static __device__ __forceinline__ bool md_two_pass(int M) { return M > MD_LONG_MIN && M < MD_LONG_MAX; }
 
 typedef float f2 __attribute__((ext_vector_type(2)));      // two rows side by side: v_pk_{add,mul,fma}_f32
 typedef int i2 __attribute__((ext_vector_type(2)));
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
         }
         float s = 0.f;
         const bool direct = M <= 25;
-        const bool approx = approx_opt != nullptr && M > MD_LONG_MIN;      // long list: approximate sums now, k_medoid_long later
+        const bool approx = approx_opt != nullptr && md_two_pass(M);      // long list: approximate sums now, k_medoid_long later
         // Rows are staged MD_STAGE (512) at a time: all their index loads, then all their point gathers are in
         // flight together (two memory latencies per 512 rows; a 64-row pipeline left the longest lists -- the
         // waves the kernel waits for -- bound by one dependent gather per chunk).
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_masks) return;
-    if (two_pass && hit_off[m + 1] - hit_off[m] > MD_LONG_MIN) return;      // k_medoid_long's
+    if (two_pass && md_two_pass(hit_off[m + 1] - hit_off[m])) return;      // k_medoid_long's
     const int t0 = tile_off[m], t1 = min(tile_off[m + 1], tile_cap);
     int bj = -1;
     float bs = 0.f;
@@ -291,8 +293,8 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
 // of non-negative terms never exceed the final sum), |A_j - S_j| <= (2^-23 sum_i t_i + M 1e-15) + M 2^-24 (A_j + S_j) up to
 // factors 1 + O(M 2^-24); solved for A_j this stays below E_j = 1.01 (M + 2) 2^-23 A_j + M 2e-15 for M < 10^5.  A column can only be the (first) minimum of the
 // exact sums if A_j - E_j <= min_k (A_k + E_k); those few columns -- the points within centimetres of the medoid -- get
-// their exact float32 sums here, 64 at a time, by the same row loop as k_medoid_tiles.  A non-finite A_j, or lists of
-// 10^5 points and more, make every column a candidate.  One wave per mask.
+// their exact float32 sums here, 64 at a time, by the same row loop as k_medoid_tiles.  A non-finite A_j makes every
+// column a candidate; lists of 10^5 points and more stay on the one-pass route.  One wave per mask.
 __global__ __launch_bounds__(64) void k_medoid_long(const float4 *__restrict__ points, const int32_t *__restrict__ pt_off,
                                                     const int32_t *__restrict__ mask_frame, int n_masks,
                                                     const int32_t *__restrict__ hit_off, const int32_t *__restrict__ hit_row,
@@ -303,13 +305,13 @@ __global__ __launch_bounds__(64) void k_medoid_long(const float4 *__restrict__ p
     __shared__ int s_cand[64];
     const int m = blockIdx.x, lane = cm3d_lane();
     const int off = hit_off[m], M = hit_off[m + 1] - off;
-    if (M <= MD_LONG_MIN || off + M > idx_cap) return;
+    if (!md_two_pass(M) || off + M > idx_cap) return;
     const float4 *P = points + pt_off[mask_frame[m]];
     const float *A = approx + off;
     const double rel = 1.01 * (double)(M + 2) * 1.1920928955078125e-07, abs_e = (double)M * 2e-15;
     // threshold = min_k (A_k + E_k); anything non-finite -> every column is a candidate
     double thr = INFINITY;
-    bool all = M >= 100000;
+    bool all = false;
     for (int j = lane; j < M; j += 64) {
         const double a = (double)A[j];
         if (!(a >= 0.0 && a < 1e300)) all = true;
