@@ -96,13 +96,17 @@ def frame_from_arrays(frame_num, velo, calib, rles, labels, scores, ratio=RATIO)
 
 def obb_yaw(pts3d):
     """Yaw of a PCA box of the in-mask points: what :855-876 + :1524 extract from Open3D's
-    get_oriented_bounding_box (Open3D 0.15 is not in the reference checkout; its OBB is PCA based but
-    sign / ordering conventions of its eigen-solver are not reproduced -- best effort, parity unpinned).
+    get_oriented_bounding_box (Open3D 0.15 is not in the reference checkout; its OBB is a PCA of the convex-hull
+    vertices, restated here; the sign conventions of its eigen-solver are not reproduced -- best effort, parity unpinned).
     Axis re-ordering by extent and as_euler('zyx')[0] follow the reference."""
+    from scipy.spatial import ConvexHull
     from scipy.spatial.transform import Rotation
     p = np.asarray(pts3d, np.float64)
-    mean = p.mean(0)
-    cov = np.cov((p - mean).T)
+    # Open3D (0.13 - 0.15) runs the PCA on the vertices of the convex hull (Qhull, like scipy's), with the population
+    # covariance; a degenerate cloud makes Qhull fail there as here, and the caller falls back to the identity box (:1481-1484)
+    hull = p[ConvexHull(p).vertices]
+    mean = hull.mean(0)
+    cov = (hull - mean).T @ (hull - mean) / hull.shape[0]
     w, v = np.linalg.eigh(cov)
     Rm = v[:, ::-1].copy()                       # columns: largest variance first
     if np.linalg.det(Rm) < 0:
