@@ -472,12 +472,17 @@ class LiftEngine:
             raise Cm3dError("a frame has too many masks or a cam_num is out of range")
         return s
 
-    def download(self):
+    def download(self, full=True):
         """Synchronises, checks the status word and returns numpy results.  `points` / `pt_off` are returned in
         the reference's form (the aggregated cloud without the ego-box rows, :445-465); on the device the cloud
-        keeps those rows as NaN placeholders (see cm3d_sweep_prep)."""
+        keeps those rows as NaN placeholders (see cm3d_sweep_prep).  full=False: only the per-mask results (boxes, flags,
+        medoids, lane matches, list offsets) -- a few hundred KB instead of the cloud and the index lists."""
         b = self.b
         s = self.check_status()
+        if not full:
+            return dict(hit_off=b.hit_off.cpu().numpy(), medoid_pos=b.medoid_pos.cpu().numpy(), centroid=b.centroid.cpu().numpy(),
+                        lane_idx=b.lane_idx.cpu().numpy(), lane_dist=b.lane_dist.cpu().numpy(),
+                        centroid_global=b.centroid_g.cpu().numpy(), box=b.box.cpu().numpy(), flags=b.flags.cpu().numpy())
         n_rows, n_idx = int(s[1]), int(s[2])
         pt_off_rows = b.pt_off.cpu().numpy()
         pts_rows = b.points[:n_rows].cpu().numpy()
@@ -539,12 +544,13 @@ class LiftPipeline:
         with torch.cuda.stream(self.streams[slot]):
             self.engines[slot].run(masks=masks or self.masks[slot], project_events=project_events)
 
-    def collect(self, slot):
-        """Waits for the slot's stream only and returns (host batch, numpy results)."""
+    def collect(self, slot, full=True):
+        """Waits for the slot's stream only and returns (host batch, numpy results); full=False: per-mask results only
+        (LiftEngine.download)."""
         self.streams[slot].synchronize()
         eng = self.engines[slot]
         with torch.cuda.stream(self.streams[slot]):
-            res = eng.download()
+            res = eng.download(full=full)
         return eng.b.hb, res
 
 

@@ -46,7 +46,7 @@ def lift_scenes(tables, scene_names, mask_dir, classes, device, n_sweeps=3, rati
     def drain(keep):
         while len(pending) > keep:
             t1 = time.time()
-            hb, res = pipe.collect(pending.pop(0))
+            hb, res = pipe.collect(pending.pop(0), full=False)      # box records need the per-mask results only
             timer["gpu lifting"] = timer.get("gpu lifting", 0.0) + time.time() - t1
             results.update(lifting.box_records(hb, res, classes))
 

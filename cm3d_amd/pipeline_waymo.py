@@ -70,7 +70,7 @@ def lift_scene(eng, frames, lane_table, classes, masks="rle"):
             eng.decode_masks_dense()
         eng.run(masks=masks)
         torch.cuda.synchronize()
-        res = eng.download()
+        res = eng.download(full=False)      # objects need boxes and flags only
         objs.append((hb, res, [(f.context_name, f.timestamp_micros) for f in fs]))
     encoded = []
     for hb, res, meta in objs:
