@@ -21,8 +21,9 @@ def test_nuscenes_entry_point_end_to_end(tmp_path, oracle):
     os.remove(os.path.join(mask_dir, names[1], "2_masks.pkl"))
     out_dir = tmp_path / "outputs"
     env = dict(os.environ, CM3D_VER_NAME="v1.0-synth", CM3D_INPUT_PATH=dataroot, CM3D_INPUT_DIR=mask_dir, CM3D_OUTPUT_DIR=str(out_dir))
-    for script in ("2d_to_3d.py", "2d_to_3d_new.py"):
-        r = subprocess.run([sys.executable, script, "--ratio", str(cfg.ratio), "--missing-ok"], cwd=os.path.join(ROOT, "src", "nuscenes"),
+    # the second run prepares its batches in two reader processes (one scene per batch: CM3D_SCENES_PER_BATCH)
+    for script, extra in (("2d_to_3d.py", []), ("2d_to_3d_new.py", ["--workers", "2", "--scenes-per-batch", "1"])):
+        r = subprocess.run([sys.executable, script, "--ratio", str(cfg.ratio), "--missing-ok"] + extra, cwd=os.path.join(ROOT, "src", "nuscenes"),
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert "wrote 6 samples." in r.stdout

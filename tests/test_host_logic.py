@@ -147,3 +147,31 @@ def test_shard_helpers():
     assert b[0][0] == 0 and b[-1][1] == len(sizes) and all(x[1] == y[0] for x, y in zip(b, b[1:]))
     loads = [sum(sizes[a:c]) for a, c in b]
     assert max(loads) <= 1.5 * sum(sizes) / 4
+
+
+def test_prepare_scene_batch_in_reader_processes(tmp_path):
+    """pipeline_nuscenes.prepare_scene_batch (file reads + RLE strings + packing; no GPU) gives the same host batches in
+    spawned reader processes as in this process."""
+    import multiprocessing as mp
+    import numpy as np
+    from cm3d_amd import nusc_io, pipeline_nuscenes as pn, synthetic as syn
+    cfg = syn.config("tiny")
+    dataroot, mask_dir, names = nusc_io.write_synthetic_dataset(str(tmp_path), cfg, n_scenes=2, frames_per_scene=2)
+    tasks = [("v1.0-synth", dataroot, mask_dir, [n], 3, cfg.ratio, False, None) for n in names]
+    here = [pn.prepare_scene_batch(t) for t in tasks]
+    with mp.get_context("spawn").Pool(2) as pool:
+        there = list(pool.imap(pn.prepare_scene_batch, [t + (True,) for t in tasks]))       # sweeps through shared memory
+    keep = []
+    for (tok_a, hbs_a, _), (tok_b, hbs_b, _) in zip(here, there):
+        assert tok_a == tok_b and len(tok_a) == 2 and len(hbs_a) == len(hbs_b) == 1
+        a, b = hbs_a[0], hbs_b[0]
+        assert isinstance(b.raw, tuple)
+        pn._attach_raw(b, keep)
+        assert a.tokens == b.tokens and a.labels == b.labels and (a.width, a.height, a.n_cams) == (b.width, b.height, b.n_cams)
+        for k in ("raw", "sweep_row_off", "sweep_xf", "frame_sweep_off", "cams", "mask_off", "mask_cam", "rle_counts", "rle_off", "class_id",
+                  "score", "lane", "lane_off", "frame_lane", "ego_xyz"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), k
+        b.raw = None
+    names_in_shm = [s.name for s in keep]
+    pn._release(keep)
+    assert len(names_in_shm) == 2 and not any(os.path.exists("/dev/shm/" + n.lstrip("/")) for n in names_in_shm)
