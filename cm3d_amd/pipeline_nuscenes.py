@@ -169,6 +169,8 @@ def main(argv=None):
 
     total_start = time.time()
     rank, world, local_rank = cdist.init_from_env()
+    if os.environ.get("CM3D_SINGLE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box (with CM3D_DIST_BACKEND=gloo)
+        local_rank = 0
     device = f"cuda:{local_rank}"
     timer = {"io": 0.0, "gpu lifting": 0.0, "gather": 0.0, "total": 0.0}
     tables = nusc_io.NuscTables(args.version, args.dataroot)

@@ -166,3 +166,25 @@ def test_g7_tiny_scene_json(tmp_path):
             assert np.allclose(a["translation"], b["translation"], rtol=0, atol=1e-4) and np.allclose(a["rotation"], b["rotation"], rtol=0, atol=1e-4)
             n += 1
     assert n > 5
+
+
+def test_nuscenes_entry_point_two_ranks(tmp_path):
+    """The N>1 path of the entry point: two ranks (gloo, both on the one GPU of the box) shard the scenes, rank 0 gathers
+    and writes; the file must equal the single-process one."""
+    from cm3d_amd import nusc_io, synthetic as syn
+    cfg = syn.config("tiny")
+    dataroot, mask_dir, names = nusc_io.write_synthetic_dataset(str(tmp_path), cfg, n_scenes=3, frames_per_scene=2)
+    base = dict(os.environ, CM3D_VER_NAME="v1.0-synth", CM3D_INPUT_PATH=dataroot, CM3D_INPUT_DIR=mask_dir)
+    cwd = os.path.join(ROOT, "src", "nuscenes")
+    r = subprocess.run([sys.executable, "2d_to_3d.py", "--ratio", str(cfg.ratio)], cwd=cwd, env=dict(base, CM3D_OUTPUT_DIR=str(tmp_path / "one")),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(base, CM3D_OUTPUT_DIR=str(tmp_path / "two"), CM3D_DIST_BACKEND="gloo", CM3D_SINGLE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29721", "2d_to_3d.py", "--ratio", str(cfg.ratio), "--scenes-per-batch", "1"], cwd=cwd, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one = json.load(open(tmp_path / "one" / "pseudolabels_minival.json"))
+    two = json.load(open(tmp_path / "two" / "pseudolabels_minival.json"))
+    assert list(one["results"]) == list(two["results"]) and len(one["results"]) == 6
+    assert one == two and sum(len(v) for v in one["results"].values()) > 10
