@@ -140,3 +140,18 @@ def test_integration_md_fusion_binding_runs_as_written(oracle):
     pm, gm, iou, _ = oracle.bev_match(ops.match_records(pred), ops.match_records(gt), 0.2)
     want = np.flatnonzero(pm >= 0)
     assert want.size > 3 and np.array_equal(ids, want) and np.array_equal(gids, pm[want]) and np.array_equal(ious, iou[want])
+
+
+def test_bev_match_ties_and_kernel_boundaries(oracle):
+    """Tie-heavy samples (duplicated boxes: many equal weights, many equally good assignments) at the sizes where the
+    solver changes kernels (64 / 128 boxes per side): the three device kernels and the oracle must take the same steps."""
+    rng = np.random.default_rng(33)
+    preds, gts = [], []
+    for P, G in [(63, 64), (64, 64), (65, 64), (64, 65), (127, 128), (128, 128), (129, 128), (128, 129), (40, 200), (200, 40), (130, 131)]:
+        base = _rand_boxes(rng, 12, (100.0, -50.0), 8.0)
+        p = base[rng.integers(0, 12, P)].copy()
+        g = base[rng.integers(0, 12, G)].copy()
+        g[rng.random(G) < 0.3, :2] += 0.25                     # some shifted copies: a second weight level
+        preds.append(p); gts.append(g)
+    assert _check(oracle, preds, gts) > 400
+    assert _check(oracle, preds, gts, thr=0.9) > 100
