@@ -434,6 +434,7 @@ def test_pipeline_slots_and_unfused_path(oracle):
     frames = [syn.make_frame(cfg17, i) for i in range(2)]
     hb = lifting.pack_frames(frames, lanes, [0] * 2)
     eng = lifting.LiftEngine()
+    eng.fused_sweeps = True              # (whatever CM3D_FUSED_SWEEPS says) 17 sweeps in a frame: the engine must fall back
     eng.upload(hb)
     assert not eng.can_fuse_sweeps()
     eng.run(masks="rle")
