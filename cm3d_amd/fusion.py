@@ -27,19 +27,28 @@ def heading_of(rotation):
     return R.from_quat(rotation).as_euler('xyz', degrees=False)[0]
 
 
+def headings_of(rotations):
+    """heading_of for a list of quaternions in one call (same scipy routine, element-wise identical)."""
+    from scipy.spatial.transform import Rotation as R
+    return R.from_quat(np.asarray(rotations, dtype=float)).as_euler('xyz', degrees=False)[:, 0]
+
+
 def parse_results(results, zero_min_quirk=False):
     """:157-190 (SAM3D, zero_min_quirk=True) / :196-227 (pred): results[sample] -> per-sample lists of
     [x, y, bottom_z, size0, size1, size2, heading] and [attribute_name, score, velocity, detection_name];
     also the score range (a zero SAM3D score does not lower the minimum, :186-190)."""
     box_dict, supp_dict = {}, {}
     max_conf, min_conf = -1e7, 1e7
+    # all headings of the file in one scipy call (the per-box call of the reference costs ~25 us x 10^6 boxes)
+    quats = [obj["rotation"] for sample in results for obj in results[sample]]
+    headings = iter(headings_of(quats)) if quats else iter(())
     for sample in results:
         box_dict.setdefault(sample, [])
         supp_dict.setdefault(sample, [])
         for obj in results[sample]:
             box_dict[sample].append(np.array([
                 obj["translation"][0], obj["translation"][1], obj["translation"][2] - obj["size"][2] / 2,
-                obj["size"][0], obj["size"][1], obj["size"][2], heading_of(obj["rotation"])], dtype=float))
+                obj["size"][0], obj["size"][1], obj["size"][2], next(headings)], dtype=float))
             supp_dict[sample].append([obj["attribute_name"], obj["detection_score"], obj["velocity"], obj["detection_name"]])
             s = obj["detection_score"]
             if s > max_conf:
