@@ -53,5 +53,7 @@ def test_random_shapes_against_oracle(oracle):
             raise AssertionError(f"shape {s}: {over}, {n_frames} frames, masks={masks}: {e}") from e
         tot["frames"] += n_frames; tot["points"] += int(exp["pt_off"][-1]); tot["masks"] += hb.n_masks
         tot["hits"] += int(exp["hit_idx"].size); tot["boxes"] += int((exp["flags"] == 3).sum())
+        if (s + 1) % 50 == 0:
+            print(f"campaign: {s + 1} / {n_seeds} shapes equal so far", flush=True)     # a long run must not look hung
     print(f"campaign: {n_seeds} shapes, {tot}")
     assert tot["hits"] > 0
