@@ -175,3 +175,25 @@ def test_prepare_scene_batch_in_reader_processes(tmp_path):
     names_in_shm = [s.name for s in keep]
     pn._release(keep)
     assert len(names_in_shm) == 2 and not any(os.path.exists("/dev/shm/" + n.lstrip("/")) for n in names_in_shm)
+
+
+def test_two_pass_medoid_error_bound_holds_numerically():
+    """The bound k_medoid_long relies on (cm3d_amd/csrc/medoid.hip): float32 sums accumulated in the same
+    order, terms perturbed by at most one ulp (all up, all down, or at random -- worse than any real v_sqrt_f32), and terms
+    below 1e-15 replaced by zero, differ by at most E = 1.01 (M + 2) 2^-23 A + 2 M 1e-15."""
+    rng = np.random.default_rng(12)
+    for M in (513, 5000, 60000):
+        for scale in (0.05, 3.0, 60.0):
+            t = np.sqrt(rng.uniform(0, scale, M).astype(np.float32) ** 2).astype(np.float32)
+            t[rng.integers(0, M, M // 50)] = 0.0                                   # the diagonal and duplicates
+            tiny = rng.integers(0, M, M // 100)
+            t[tiny] = np.float32(5e-16)                                            # roots of d2 < 1e-30
+            S = np.cumsum(t, dtype=np.float32)[-1]
+            for mode in ("up", "down", "rand"):
+                d = {"up": np.ones(M), "down": -np.ones(M), "rand": rng.choice([-1.0, 0.0, 1.0], M)}[mode]
+                tp = np.where(d > 0, np.nextafter(t, np.float32(np.inf)), np.where(d < 0, np.nextafter(t, np.float32(-np.inf)), t))
+                tp = np.maximum(tp, 0).astype(np.float32)
+                tp[tiny] = 0.0
+                A = np.cumsum(tp, dtype=np.float32)[-1]
+                E = 1.01 * (M + 2) * 2.0 ** -23 * float(A) + 2.0 * M * 1e-15
+                assert abs(float(A) - float(S)) <= E, (M, scale, mode, float(A), float(S), E)
