@@ -3,7 +3,9 @@
 nuScenes-shaped sweeps).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N>1 without RANK in the environment: bench.py starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+  --master-addr 127.0.0.1 ... bench.py <same flags>` itself, as a child process and before anything touches the GPU,
+  relays rank 0's JSON line and exits with the child's code.  Under torchrun (RANK set) WORLD_SIZE must equal --gpus.
 
 A step = one pass of the whole path (a2 sweep prep, a1+a3 mask expansion/erosion, a4-a8
 projection + in-mask gather + ordered compaction, a9 medoid, a10 lane NN, a11-a15 boxes + NMS)
@@ -31,26 +33,78 @@ from cm3d_amd import dist as cdist, lifting, synthetic as syn  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def algorithmic_bytes(hb, sum_hits, mode):
-    """SURVEY.md 8(d).  Returns per-kernel algorithmic bytes of ONE pass over the batch."""
+def packed_rect_bytes(bbox, Wp):
+    """Bytes of the bit-packed masks that exist at all: the RLE path writes, and the projection can only read, the words
+    of each eroded mask's bounding rectangle.  bbox: (M,4) int32 x0,y0,x1,y1 inclusive, x0>x1 when empty."""
+    b = np.asarray(bbox, np.int64)
+    ok = (b[:, 2] >= b[:, 0]) & (b[:, 3] >= b[:, 1])
+    words = np.where(ok, ((b[:, 2] >> 5) - (b[:, 0] >> 5) + 1) * (b[:, 3] - b[:, 1] + 1), 0)
+    return int(4 * words.sum())
+
+
+def compulsory_bytes(hb, planes, sum_hits, mode, fused, cloud_stored, rect_bytes):
+    """Bytes every launch MUST move across HBM (per-unit figure x units of one launch).  Nothing here is a
+    byte the kernels skip: the full bit-packed masks of SURVEY 8(d) (n*ceil(W*H/8) per frame) are never written nor read
+    as a whole -- only `rect_bytes` of them exist -- so they are NOT part of any figure called achieved / frac."""
     F, M = hb.n_frames, hb.n_masks
     W, H = hb.width, hb.height
-    packed = M * ((W + 31) // 32) * 4 * H
-    n_raw = hb.n_raw_rows
-    n_pts = n_raw      # upper bound; the ego-box filter removes ~0.2 %
-    alg = {
-        # ALG_PG = 16 N + n*ceil(W*H/8) + 4*sum(M_i) + 4*(n+1), summed over the frames of the batch
-        "project_gather": 16 * n_pts + packed + 4 * sum_hits + 4 * (M + F),
-        "k_project_hits": 16 * n_pts + packed + 4 * n_pts,
-        "k_erode_pack": M * W * H + packed,
-        "k_rle_erode_pack": 4 * int(hb.rle_counts.size) + packed,
-        "k_sweep": 4 * hb.raw_stride * n_raw + 16 * n_pts,
+    rows = hb.n_raw_rows
+    raw = 4 * hb.raw_stride * rows
+    cloud = 16 * rows
+    hitw = 4 * rows * planes
+    runs = 4 * int(hb.rle_counts.size)
+    by = {
+        # projection launch: raw rows in (fused) or the prepared cloud in, hit words out, cloud out when it is kept.
+        # The mask words a launch fetches (a subset of rect_bytes, mostly L2 hits) are extra traffic, not counted.
+        "k_project_hits": (raw if fused else cloud) + hitw + (cloud if (fused and cloud_stored) else 0),
+        "k_sweep_xform": raw + cloud,
+        "k_rle_erode_pack": runs + rect_bytes,
+        "k_erode_pack": M * W * H + M * ((W + 31) // 32) * 4 * H,           # dense path: really streams both
+        "k_compact_hits": hitw + 8 * sum_hits + (12 * sum_hits if not cloud_stored else 0),
+        "k_medoid": 16 * sum_hits,
+        "boxes": 80 * M,
     }
-    # sweep preparation folded into the projection launch: raw rows read, cloud written once, masks, hit words
-    alg["k_project_hits_fused"] = alg["k_sweep"] + packed + 4 * n_pts
+    masks = by["k_erode_pack"] if mode == "dense" else by["k_rle_erode_pack"]
+    by["pass_total"] = (by["k_project_hits"] + (0 if fused else by["k_sweep_xform"]) + masks + by["k_compact_hits"] +
+                        by["k_medoid"] + by["boxes"])
+    return by
+
+
+def survey_8d_bytes(hb, sum_hits, mode):
+    """SURVEY.md 8(d)'s ALG_PG / ALG_FRAME of the batch, kept for reference only (they price a full read of every
+    bit-packed mask, which this design avoids): reported under `survey_8d`, never as a roofline fraction."""
+    F, M = hb.n_frames, hb.n_masks
+    W, H = hb.width, hb.height
+    packed = M * ((W + 7) // 8) * H
+    n_pts = hb.n_raw_rows
+    pg = 16 * n_pts + packed + 4 * sum_hits + 4 * (M + F)
     masks_in = M * W * H if mode == "dense" else 4 * int(hb.rle_counts.size)
-    alg["frame_total"] = alg["project_gather"] + masks_in + packed + 16 * sum_hits + 64 * M
-    return alg
+    return {"ALG_PG_per_frame": pg // F, "ALG_FRAME_per_frame": (pg + masks_in + packed + 16 * sum_hits + 64 * M) // F}
+
+
+def visible_cores():
+    """Cores this process may use: the scheduler affinity, cut by the cgroup CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
 
 
 def cpu_baseline(frames, lanes, frame_lane, hb, n_sample):
@@ -164,7 +218,45 @@ def fusion_bench(n_samples, steps, warmup):
                                        "sample": f"all {n_samples} samples, {dt_cpu:.2f} s"}}))
 
 
-def main():
+def self_launch(args, argv):
+    """`--gpus N` without torchrun: start the N ranks as a child process (nothing in this process has touched the GPU:
+    importing torch does not initialise HIP), relay its output -- rank 0's JSON line -- and return its exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
+def rehearse_launch(args):
+    """`--rehearse-launch`: the launch + rendezvous + the single record exchange, and nothing else -- no kernels, so it
+    also runs without a GPU (gloo).  Rank 0 prints one JSON line with the rank count the process group saw."""
+    rank, world, local_rank = cdist.init_from_env()
+    rec = torch.full((3 + rank, 10), float(rank), dtype=torch.float64)
+    if world > 1 and torch.distributed.get_backend() == "nccl":
+        rec = rec.to(f"cuda:{local_rank}")
+    got = cdist.gather_records(rec, dst=0)
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0:
+        ok = len(got) == world and all(g.shape[0] == 3 + r and bool((g == r).all()) for r, g in enumerate(got))
+        print(json.dumps({"metric": "pseudo-label frames/sec on nuScenes-shaped sweeps", "value": None, "unit": "frames/s", "n_gpus": world,
+                          "rehearsal": True, "ranks_in_group": torch.distributed.get_world_size() if world > 1 else 1,
+                          "backend": torch.distributed.get_backend() if world > 1 else None, "gather_ok": bool(ok)}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -176,22 +268,33 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=48, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--lane-points", type=int, default=50000)
     ap.add_argument("--no-secondary", action="store_true", help="skip the second mask mode")
-    ap.add_argument("--cpu-workers", type=int, default=16,
-                    help="processes of the all-cores CPU baseline (0 = skip; capped at the visible cores)")
+    ap.add_argument("--cpu-workers", type=int, default=-1,
+                    help="processes of the all-cores CPU baseline (-1 = every core this job may use; 0 = skip)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override a field of the synthetic config (e.g. --set n_masks=80); for experiments")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="independent batches kept in flight per GPU (LiftPipeline depth; 1 = one batch at a time)")
+    ap.add_argument("--keep-cloud", action="store_true", help="also materialise the transformed cloud (16 B/row more HBM traffic)")
     ap.add_argument("--fusion", type=int, default=0, metavar="SAMPLES",
                     help="time the SAM3D fusion matching (SURVEY 8 f4) on this many samples instead of the lifting path")
-    args = ap.parse_args()
+    ap.add_argument("--rehearse-launch", action="store_true", help="launch, rendezvous and the record exchange only (no GPU needed)")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args, argv)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        print(f"error: --gpus {args.gpus} but WORLD_SIZE={env_world}: start bench.py with --gpus equal to the number of ranks "
+              "(or without torchrun: it launches the ranks itself)", file=sys.stderr)
+        return 2
+    if args.rehearse_launch:
+        return rehearse_launch(args)
     if args.fusion > 0:
-        return fusion_bench(args.fusion, min(args.steps, 50), min(args.warmup, 5))
+        fusion_bench(args.fusion, min(args.steps, 50), min(args.warmup, 5))
+        return 0
 
     rank, world, local_rank = cdist.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     if os.environ.get("CM3D_SINGLE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box (with CM3D_DIST_BACKEND=gloo)
         local_rank = 0
     dev = torch.device(f"cuda:{local_rank}")
@@ -217,7 +320,7 @@ def main():
     t_gen = time.perf_counter() - t_gen
 
     modes = [args.masks] + ([] if args.no_secondary else [m for m in ("rle", "dense") if m != args.masks])
-    pipe = lifting.LiftPipeline(dev, depth=depth)
+    pipe = lifting.LiftPipeline(dev, depth=depth, keep_cloud=args.keep_cloud)
     for slot in range(depth):
         with torch.cuda.stream(pipe.streams[slot]):
             pipe.engines[slot].upload(batches[slot][1])
@@ -294,36 +397,42 @@ def main():
         results[mode] = dict(dt=dt, stage_ms=stage_ms, project_alone_ms=project_alone_ms, fused=fused, sum_hits=int(status[2]),
                              n_points=int(status[1]),
                              n_boxes=int((eng.b.flags == 3).sum().item()), max_hits=int(eng.b.hit_count.max().item()),
+                             rect_bytes=packed_rect_bytes(eng.b.bbox.cpu().numpy(), eng.b.Wp),
                              n_gathered=None if gathered is None else int(sum(g.shape[0] for g in gathered)))
 
     if rank != 0:
-        return
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return 0
     main_mode = modes[0]
     r = results[main_mode]
     frames_total = args.frames * world * args.steps
     value = frames_total / r["dt"]
-    alg = algorithmic_bytes(hb, r["sum_hits"], main_mode)
+    cloud_stored = eng.b.points is not None
+    by = compulsory_bytes(hb, eng.b.planes, r["sum_hits"], main_mode, r["fused"], cloud_stored, r["rect_bytes"])
 
-    def roof(kernel_key, stage_key, res, kernel_name, note):
-        ms = res["stage_ms"][stage_key]
-        ach = alg[kernel_key] / (ms * 1e-3) / 1e9
+    def rate(nbytes, ms):
+        return nbytes / (ms * 1e-3) / 1e9
+
+    def roof(kernel_key, ms, kernel_name, note):
+        ach = rate(by[kernel_key], ms)
         return {"kernel": kernel_name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": int(alg[kernel_key]),
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(by[kernel_key]),
                 "avg_launch_ms": round(ms, 4), "note": note}
 
-    # north_star's kernel: projection + in-mask gather (one launch per pass), timed by HIP events on its launch stream
+    # north_star's kernel: projection + in-mask test (one launch per pass), timed by HIP events on its launch stream
     # inside the timed region -- i.e. while the other batches in flight share the GPU with it
-    if r["fused"]:
-        roofline = roof("k_project_hits_fused", "project", r, "k_project_hits<ONE_PLANE, FUSED>",
-                        "sweep preparation folded in: algorithmic bytes = raw rows read (4 x stride B) + cloud written (16 B/point) + "
-                        "every bit-packed mask once + 4 B/point hit word (SURVEY 8d); the bounding-box test lets the kernel skip most "
-                        "mask bytes, so `achieved` can exceed what HBM allows for a full read; traffic_rate = measured HBM bytes / "
-                        "time; the kernel is instruction-issue / latency bound")
-    else:
-        roofline = roof("k_project_hits", "project", r, "k_project_hits",
-                        "algorithmic bytes = 16 B/point + every bit-packed mask once + 4 B/point hit word (SURVEY 8d); the kernel's "
-                        "bounding-box test lets it skip most mask bytes, so `achieved` exceeds what HBM allows for a full read; "
-                        "traffic_rate = measured HBM bytes / time; the kernel is instruction-issue bound")
+    rows = hb.n_raw_rows
+    per_row = (4 * hb.raw_stride if r["fused"] else 16) + 4 * eng.b.planes + (16 if (r["fused"] and cloud_stored) else 0)
+    roofline = roof("k_project_hits", r["stage_ms"]["project"], "k_project_hits<ONE_PLANE, FUSED, STRIDE>" if r["fused"] else "k_project_hits",
+                    f"bytes that must cross HBM per launch = {per_row} B/row x {rows} rows: "
+                    + (f"raw sweep rows read ({4 * hb.raw_stride} B/row)" if r["fused"] else "prepared cloud read (16 B/row)")
+                    + f" + hit words written (4 B/row/plane, {eng.b.planes} plane(s))"
+                    + (" + transformed cloud written (16 B/row)" if (r["fused"] and cloud_stored) else "")
+                    + "; the bit-packed mask words the launch gathers (bounding-box gated, mostly L2 hits) and the per-frame tables "
+                      "are extra traffic and NOT counted, so `frac` cannot be inflated by bytes the kernel skips")
+    roofline["rows_per_launch"] = rows
+    roofline["bytes_per_row"] = per_row
     # the box's own streaming rate beside the nominal peak: device-to-device copy of 1 GiB, read + write bytes
     src_buf = torch.empty(1 << 28, dtype=torch.float32, device=dev)
     dst_buf = torch.empty_like(src_buf)
@@ -337,32 +446,31 @@ def main():
     del src_buf, dst_buf
     roofline["batches_in_flight"] = depth
     roofline["avg_launch_ms_alone"] = round(r["project_alone_ms"], 4)      # the same launch with nothing else on the GPU
+    roofline["frac_alone"] = round(rate(by["k_project_hits"], r["project_alone_ms"]) / HBM_PEAK_GBS, 4)
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     per_kernel = {}
     if os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
             # the PMC passes were taken on the default workload; a different batch gets no traffic figure
-            if args.frames == int(tr.get("frames_per_gpu", 256)) and not args.set:
+            if args.frames == int(tr.get("frames_per_gpu", 256)) and not args.set and not args.keep_cloud:
                 per_kernel = tr.get(f"{args.config}_{main_mode}", {})
                 roofline["traffic"] = per_kernel.get("k_project_hits")
-            if roofline["traffic"]:
-                # what HBM actually moved per launch / time: the honest distance from the HBM roof (the kernel is
-                # bound by instruction issue; `frac` above is SURVEY 8(d)'s algorithmic figure)
-                rate = roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9
-                roofline["traffic_rate"] = round(rate, 1)
-                roofline["traffic_frac"] = round(rate / HBM_PEAK_GBS, 4)
         except (OSError, ValueError):
             pass
     mask_kernel = "k_erode_pack" if main_mode == "dense" else "k_rle_erode_pack"
     kernels = {
-        "masks": roof(mask_kernel, "masks", r, mask_kernel, "latency-bound (one workgroup per mask); stage time incl. the launch boundary"),
+        "masks": roof(mask_kernel, r["stage_ms"]["masks"], mask_kernel,
+                      "run lengths read + the words of every eroded mask's bounding rectangle written (what the kernel stores); "
+                      "latency-bound, one workgroup per mask; stage time incl. the launch boundary" if main_mode == "rle" else
+                      "dense uint8 masks read + bit-packed masks written; stage time incl. the launch boundary"),
         "stage_ms_one_batch_alone": {k: round(v, 4) for k, v in dict(r["stage_ms"], project=r["project_alone_ms"]).items()},
     }
     kernels["masks"]["traffic"] = per_kernel.get(mask_kernel)
     if not r["fused"]:
-        kernels["sweeps"] = roof("k_sweep", "sweeps", r, "k_sweep_xform", "HBM streaming, one pass; stage time incl. the launch boundary")
+        kernels["sweeps"] = roof("k_sweep_xform", r["stage_ms"]["sweeps"], "k_sweep_xform", "HBM streaming, one pass; stage time incl. the launch boundary")
         kernels["sweeps"]["traffic"] = per_kernel.get("k_sweep_xform")
+    pass_rate = by["pass_total"] * (value / world / args.frames) / 1e9       # bytes of one pass x passes per second per GPU
     out = {
         "metric": "pseudo-label frames/sec on nuScenes-shaped sweeps", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(r["dt"] / args.steps * 1e3, 4),
@@ -371,15 +479,19 @@ def main():
                                f"{cfg.n_masks} masks {cfg.width}x{cfg.height}), masks resident as {main_mode}",
                    "frames_per_gpu": args.frames, "points_per_frame": cfg.n_points * cfg.n_sweeps, "masks_per_frame": cfg.n_masks,
                    "mask_size": [cfg.width, cfg.height], "lane_points": args.lane_points, "mask_input": main_mode,
-                   "batches_in_flight": depth,
+                   "batches_in_flight": depth, "cloud_materialised": cloud_stored,
                    "parallelism": f"frame-sharded x{world}, {depth} independent batches in flight per GPU, one RCCL gather of box records"},
+        "ranks_in_group": torch.distributed.get_world_size() if world > 1 else 1,
         "roofline": roofline,
         "kernels": kernels,
-        "frame_alg_bytes": int(alg["frame_total"] // hb.n_frames),
-        # the whole pass against the HBM roof: SURVEY 8(d)'s end-to-end algorithmic bytes per frame x frames/s
-        "pass_roofline": {"bound": "hbm", "achieved": round(alg["frame_total"] / hb.n_frames * value / world / 1e9, 1), "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": round(alg["frame_total"] / hb.n_frames * value / world / 1e9 / HBM_PEAK_GBS, 4),
-                          "note": "per GPU; ALG_FRAME with the masks read in the form they are resident in"},
+        # the whole pass against the HBM roof: bytes every stage must move (compulsory_bytes) x passes/s, per GPU
+        "pass_roofline": {"bound": "hbm", "achieved": round(pass_rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(pass_rate / HBM_PEAK_GBS, 4), "bytes_per_pass": int(by["pass_total"]),
+                          "note": "per GPU; a pass is a chain of dependent launches, most of them latency- or VALU-bound (medoid, "
+                                  "lane search): the fraction says how far the WHOLE path is from streaming its compulsory bytes"},
+        "survey_8d": dict(survey_8d_bytes(hb, r["sum_hits"], main_mode),
+                          note="SURVEY 8(d)'s per-frame figures, which price a full read of every bit-packed mask; this design never "
+                               "moves those bytes, so they are reference numbers only and enter no fraction"),
         "boxes_per_step": r["n_boxes"], "in_mask_points_per_step": r["sum_hits"], "max_points_in_a_mask": r["max_hits"],
         "gen_seconds": round(t_gen, 1),
     }
@@ -389,17 +501,24 @@ def main():
         out[f"stage_ms_{mode}_masks"] = {k: round(v, 4) for k, v in dict(o["stage_ms"], project=o["project_alone_ms"]).items()}
     if world == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(frames, lanes, frame_lane, hb, args.cpu_sample)
-        workers = min(args.cpu_workers, os.cpu_count() or 1)
+        cores = visible_cores()
+        workers = cores if args.cpu_workers < 0 else min(args.cpu_workers, cores)
+        # every worker imports torch + numpy (~0.4 GB resident): stay far below the box's host-memory cap
+        workers = min(workers, 192)
         if workers > 1:
             try:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.config, args.set, args.lane_points, workers,
-                                                                       max(8, args.cpu_sample // 4))
+                                                                       max(4, min(16, args.cpu_sample // 4)))
+                out["cpu_baseline_all_cores"]["sample"] += f"; host has {os.cpu_count()} cores, {cores} usable by this job (affinity / cgroup quota)"
             except Exception as exc:        # a reported extra: never let it break the bench line
                 out["cpu_baseline_all_cores"] = {"error": repr(exc)}
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

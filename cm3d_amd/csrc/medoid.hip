@@ -196,12 +196,14 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
         // uniform control flow
         const int off = __builtin_amdgcn_readfirstlane(d.off), M = __builtin_amdgcn_readfirstlane(d.M);
         const int jt = __builtin_amdgcn_readfirstlane(d.jt);
-        const float4 *P = points + pt_off[mask_frame[__builtin_amdgcn_readfirstlane(d.m)]];
+        // hit_row == NULL: `points` is the per-hit coordinate array of cm3d_compact_hits, laid out like the index lists
+        const float4 *P = hit_row ? points + pt_off[mask_frame[__builtin_amdgcn_readfirstlane(d.m)]] : points;
+        auto fetch = [&](int q) { return hit_row ? P[hit_row[q]] : P[q]; };
         const int j = jt * 64 + lane;
         const bool act = j < M;
         float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
         if (act) {
-            const float4 q = P[hit_row[off + j]];
+            const float4 q = fetch(off + j);
             qx = q.x; qy = q.y; qz = q.z;
             qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
         }
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
             float4 g[MD_STAGE / 64];
 #pragma unroll
             for (int c = 0; c < MD_STAGE / 64; ++c)
-                if (i0 + c * 64 + lane < M) g[c] = P[hit_row[off + i0 + c * 64 + lane]];
+                if (i0 + c * 64 + lane < M) g[c] = fetch(off + i0 + c * 64 + lane);
 #pragma unroll
             for (int c = 0; c < MD_STAGE / 64; ++c) {
                 if (i0 + c * 64 + lane < M) {
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
     medoid_pos[m] = bj;
     float cx = 0.f, cy = 0.f, cz = 0.f;
     if (bj >= 0 && hit_off[m] + bj < idx_cap) {
-        const float4 p = points[pt_off[mask_frame[m]] + hit_row[hit_off[m] + bj]];
+        const float4 p = hit_row ? points[pt_off[mask_frame[m]] + hit_row[hit_off[m] + bj]] : points[hit_off[m] + bj];
         cx = p.x; cy = p.y; cz = p.z;
     }
     centroid[3 * m + 0] = cx; centroid[3 * m + 1] = cy; centroid[3 * m + 2] = cz;
@@ -306,7 +308,8 @@ __global__ __launch_bounds__(64) void k_medoid_long(const float4 *__restrict__ p
     const int m = blockIdx.x, lane = cm3d_lane();
     const int off = hit_off[m], M = hit_off[m + 1] - off;
     if (!md_two_pass(M) || off + M > idx_cap) return;
-    const float4 *P = points + pt_off[mask_frame[m]];
+    const float4 *P = hit_row ? points + pt_off[mask_frame[m]] : points;
+    auto fetch = [&](int q) { return hit_row ? P[hit_row[q]] : P[q]; };
     const float *A = approx + off;
     const double rel = 1.01 * (double)(M + 2) * 1.1920928955078125e-07, abs_e = (double)M * 2e-15;
     // threshold = min_k (A_k + E_k); anything non-finite -> every column is a candidate
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(64) void k_medoid_long(const float4 *__restrict__ p
             const int cj = act ? s_cand[lane] : 0;
             float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
             if (act) {
-                const float4 q = P[hit_row[off + cj]];
+                const float4 q = fetch(off + cj);
                 qx = q.x; qy = q.y; qz = q.z;
                 qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
             }
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(64) void k_medoid_long(const float4 *__restrict__ p
                 float4 g[MD_STAGE / 64];
 #pragma unroll
                 for (int c = 0; c < MD_STAGE / 64; ++c)
-                    if (i0 + c * 64 + lane < M) g[c] = P[hit_row[off + i0 + c * 64 + lane]];
+                    if (i0 + c * 64 + lane < M) g[c] = fetch(off + i0 + c * 64 + lane);
 #pragma unroll
                 for (int c = 0; c < MD_STAGE / 64; ++c) {
                     if (i0 + c * 64 + lane < M) {
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(64) void k_medoid_long(const float4 *__restrict__ p
         medoid_pos[m] = bj;
         float cx = 0.f, cy = 0.f, cz = 0.f;
         if (bj >= 0) {
-            const float4 p = P[hit_row[off + bj]];
+            const float4 p = fetch(off + bj);
             cx = p.x; cy = p.y; cz = p.z;
         }
         centroid[3 * m + 0] = cx; centroid[3 * m + 1] = cy; centroid[3 * m + 2] = cz;
@@ -418,8 +421,8 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
                            const int32_t *tile_work, int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
                            int64_t workspace_bytes, cm3d_stream_t stream)
 {
-    if (!points || !pt_off || !mask_frame || !hit_off || !tile_off || !hit_row || !medoid_pos || !centroid || !workspace)
-        return CM3D_ERR_ARG;
+    if (!points || !hit_off || !tile_off || !medoid_pos || !centroid || !workspace) return CM3D_ERR_ARG;
+    if (hit_row && (!pt_off || !mask_frame)) return CM3D_ERR_ARG;           // hit_row == NULL: `points` is the hit_xyz array
     if (n_masks <= 0 || idx_cap <= 0) return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_medoid_workspace_bytes(n_masks, idx_cap)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;

@@ -1,27 +1,80 @@
-// a4-a8: projection, in-image test, in-mask test, ordered compaction.
-//   reference: src/nuscenes/2d_to_3d.py:553-620 (per mask: clone the cloud, 2x translate/rotate,
-//   view_points utils/pcd.py:262-284, 5-way in-image test, floor, mask gather with the
+// a2 + a4-a8: sweep preparation, projection, in-image test, in-mask test, ordered compaction.
+//   reference: src/nuscenes/2d_to_3d.py:437-465 (sweep loop) and :553-620 (per mask: clone the cloud, 2x
+//   translate/rotate, view_points utils/pcd.py:262-284, 5-way in-image test, floor, mask gather with the
 //   floor(u)!=0 && floor(v)!=0 quirk, torch.where, two .cpu() index-tracking steps).
-// Here every point is read ONCE (float4, coalesced), projected into every camera of its frame,
-// and tested against the bit-packed eroded masks of that camera (bounding-box test first, so
-// only points that can hit a mask touch mask memory).  Results leave as one hit word per point
-// per 32 masks plus one count per (1024-point block, mask); an exclusive scan of those counts
-// (k_hit_offsets) gives every block its exact output offset, and k_compact_hits writes the ascending index
-// lists with wave ballot + mbcnt prefixes (no atomics on the output order, deterministic).
-// HBM-bound: algorithmic bytes = 16 N + n*ceil(W*H/8) + 4*sum(M) + 4(n+1) per frame.
+// Every row is read ONCE, projected into every camera of its frame that can see it, and tested against the bit-packed
+// eroded masks of that camera (bounding-box test first, so only points that can hit a mask touch mask memory).
+// Layout of the work: a WAVE owns "wave-chunks" of 256 consecutive rows, lane l the 4 consecutive rows 4l..4l+3 -- so a
+// lane's rows are one contiguous run of bytes (4 x raw_stride dwords: `raw_stride` 16-byte loads, nothing fetched twice)
+// and its four hit words one 16-byte store.  Waves never talk to each other: per-frame tables (visibility cones, masks
+// sorted by camera with their bounding boxes, row ranges) are built once per frame by k_frame_tables, staged into LDS
+// behind the only workgroup barrier, and every wave writes its own results:
+//   hit_words  one 32-bit word per row per 32 masks
+//   wc_cnt     one count per (wave-chunk, mask); their exclusive scan (k_hit_offsets) gives every wave-chunk its exact
+//              output offset, and k_compact_hits writes the ascending index lists with ballot + mbcnt ranks
+//              (no atomics on the output order: deterministic)
+//   removed_bits  one bit per row the reference drops (ego box, :442-445)
+// The transformed cloud is optional (`points` may be NULL): the medoid stage only needs the in-mask points, and
+// k_compact_hits re-derives their coordinates from the raw rows (same fma chains, same bits) into hit_xyz.
+// HBM bytes per row that MUST move: 4*raw_stride read + 4 per plane written (+16 when the cloud is kept).
 #include "common.h"
 #include "worklist.h"
 #include <cstdlib>
 
-#define PH_THREADS 256
-#define PH_PT 4                                   // points per thread
-#define PH_BLOCK_PTS (PH_THREADS * PH_PT)
-#define PH_MB 4                                   // masks of a camera handled together in the mask loop
+#ifdef CM3D_DIAG
+// Diagnostic build only (make diag -> libcm3d_hip_diag.so; tools/ph_diag.py): ablation switches and per-phase
+// s_memtime sums of k_project_hits.  Nothing of this exists in the product library.
+__device__ int g_ph_diag;                         // bit1 no mask loop, bit2 no camera loop, bit3 synthetic rows, bit4 stamps
+__device__ unsigned long long g_ph_stamp[8];
+static __device__ __forceinline__ unsigned long long ph_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PH_DIAG(bit) (diag & (bit))
+#define PH_STAMP(k)                                                     \
+    do {                                                                \
+        if (diag & 16) { const unsigned long long t_ = ph_now(); acc[k] += t_ - t_prev; t_prev = t_; } \
+    } while (0)
+extern "C" int cm3d_diag_set(int flags)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ph_diag), &flags, sizeof(int)) != hipSuccess) return CM3D_ERR_LAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ph_stamp), z, sizeof(z)) != hipSuccess) return CM3D_ERR_LAUNCH;
+    return CM3D_OK;
+}
+extern "C" int cm3d_diag_read(unsigned long long *out_host)
+{
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_ph_stamp), 8 * sizeof(unsigned long long)) == hipSuccess ? CM3D_OK : CM3D_ERR_LAUNCH;
+}
+#else
+#define PH_DIAG(bit) 0
+#define PH_STAMP(k) do { } while (0)
+#endif
 
-// Block-local slot of a thread's j-th point: wave w owns the 256 consecutive points [256 w, 256 w + 256)
-// (LiDAR points are stored ring by ring, so a wave then sees one short arc and few cameras); for a fixed j
-// the 64 lanes read 64 consecutive points (1 KiB, coalesced).  Order inside a block = (wave, j, lane).
-static __device__ __forceinline__ int ph_slot(int j) { return (int)(threadIdx.x >> 6) * (64 * PH_PT) + j * 64 + (int)(threadIdx.x & 63); }
+#define PH_THREADS 256
+#define PH_WAVES (PH_THREADS / 64)
+#define PH_PT 4                                   // consecutive rows per lane
+#define PH_WC (64 * PH_PT)                        // rows per wave-chunk
+#define PH_MB 4                                   // masks of a camera handled together in the mask loop
+#define PH_MAX_SWEEPS CM3D_MAX_FUSED_SWEEPS
+
+// Frame table: one record of FT_WORDS 32-bit words per frame in the workspace, written by k_frame_tables.
+//   [0] p0 first row  [1] n rows  [2] m0 first mask  [3] nm masks (clamped to the caller's planes)
+//   [4] sa first sweep [5] ns sweeps  [6] first word of the frame's removed-row bits  [7] nwc wave-chunks
+//   [8..16]  cam_first[0..8]: masks of camera c = entries [cam_first[c], cam_first[c+1]) of the frame's sorted list
+//   [24..40] frame-local first row of each sweep (fused path; ns <= PH_MAX_SWEEPS)
+//   [64..127] visibility cones, 8 floats per camera
+#define FT_WORDS 128
+#define FT_CAMFIRST 8
+#define FT_SROW 24
+#define FT_CONE 64
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));        // 16 bytes at dword alignment
+typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
 
 typedef float f2 __attribute__((ext_vector_type(2)));     // two points side by side: v_pk_{add,mul,fma}_f32
 #define PK_FMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
@@ -183,45 +236,111 @@ static __device__ void cone_setup(const float *cm, int W, int H, float min_dist,
     out[7] = 1.f + tt * tt * 1.01f;
 }
 
-// grid (G, F).  A block walks 1024-point chunks of one frame (chunk = blockIdx.x, += gridDim.x),
-// 4 points per thread (4 independent mask gathers in flight).  Per-frame tables (camera records, visibility
-// cones, per-camera mask sets) are staged into LDS once per block.  Per wave and chunk:
-//   for every camera that can see any of the wave's points (cone test): project the 4 points (pixel codes stay
-//   in registers), then for every mask of that camera: bounding-box test, one mask word per candidate point,
-//   bit test, per-mask hit count.
-// ONE_PLANE (<= 32 masks per frame): the hit word of a point lives in a register; otherwise in the thread's own
-// LDS slots, one per plane.
-// FUSED: the kernel reads the RAW sweep rows itself (a2, reference :437-465: ego-box drop, sensor -> ego -> global, the
-// very fma chains of k_sweep_xform), writes the transformed cloud for the medoid / the caller, and lists the dropped rows
-// -- the cloud is then read once from HBM in the whole pass instead of raw + written + read again, and the sweep launch
-// disappears.  Frames with at most PH_MAX_SWEEPS sweeps (cm3d_sweep_project_hits checks).
-#define PH_MAX_SWEEPS 16
-#define PH_DROP_CAP 2048                          // dropped rows a block collects in LDS; beyond: straight to the frame's list
 struct PhSweepIn {
     const float *raw; int raw_stride; const int32_t *sweep_row_off; const float *sweep_xf; const int32_t *frame_sweep_off;
-    int n_frames, n_sweeps; float halfw; float4 *points_out; int pt_cap; int32_t *pt_off_out, *removed_cnt, *removed_idx;
+    int n_frames, n_sweeps; float halfw; float4 *points_out; int pt_cap; int32_t *pt_off_out; uint32_t *removed_bits;
 };
 
-// raw rows of a chunk (the 4 columns the reference keeps); dead slots read as (1e30, 1e30): never dropped
-template <bool FUSED>
-static __device__ __forceinline__ void ph_load(float4 (&pt)[PH_PT], const float4 *__restrict__ points, const PhSweepIn &sw, int p0,
-                                               int n, int chunk)
+// workspace of the projection / compaction pair
+struct PhWs { int4 *ment; int32_t *ft; int32_t *wc_drop; int32_t *wc_cnt; };
+static inline int ph_nm_cap(int planes)
 {
-    const float qnan = __int_as_float(0x7FC00000);
-#pragma unroll
-    for (int j = 0; j < PH_PT; ++j) {
-        const int i = chunk * PH_BLOCK_PTS + ph_slot(j);
-        if (FUSED) {
-            pt[j] = make_float4(1e30f, 1e30f, 0.f, 0.f);
-            if (i < n) {
-                const float *p = sw.raw + (size_t)(p0 + i) * sw.raw_stride;
-                pt[j].x = __builtin_nontemporal_load(p); pt[j].y = __builtin_nontemporal_load(p + 1);
-                pt[j].z = __builtin_nontemporal_load(p + 2); pt[j].w = __builtin_nontemporal_load(p + 3);
+    int c = planes * 32;
+    return c > CM3D_MAX_MASKS_PER_FRAME ? CM3D_MAX_MASKS_PER_FRAME : c;
+}
+static inline int64_t ph_ws_layout(int n_frames, int max_pts_per_frame, int planes, void *base, PhWs *out)
+{
+    const int64_t nwc_max = (max_pts_per_frame + PH_WC - 1) / PH_WC, nm_cap = ph_nm_cap(planes);
+    int64_t off = 0;
+    char *b = (char *)base;
+    if (out) out->ment = (int4 *)(b + off);
+    off += (int64_t)n_frames * nm_cap * 16;
+    if (out) out->ft = (int32_t *)(b + off);
+    off += (int64_t)n_frames * FT_WORDS * 4;
+    if (out) out->wc_drop = (int32_t *)(b + off);
+    off += ((int64_t)n_frames * nwc_max * 4 + 15) & ~(int64_t)15;
+    if (out) out->wc_cnt = (int32_t *)(b + off);
+    off += (int64_t)n_frames * nwc_max * nm_cap * 4;
+    return off;
+}
+
+// One wave per frame: row / mask ranges, visibility cones, and the frame's masks sorted by camera with their bounding
+// boxes (empty masks and masks of an out-of-range camera are left out: they can get no point).  Also what the sweep
+// kernel leaves behind for the later stages in the fused form (pt_off, status[1]).
+__global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fused, const int32_t *__restrict__ pt_off, int n_frames,
+                                                     const float *__restrict__ cams, int n_cams,
+                                                     const int32_t *__restrict__ mask_off, const int32_t *__restrict__ mask_cam,
+                                                     const int4 *__restrict__ bbox, int W, int H, float min_dist, int nm_cap,
+                                                     int max_pts_per_frame, int32_t *__restrict__ ft_all, int4 *__restrict__ ment_all,
+                                                     int32_t *__restrict__ status)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
+    int32_t *ft = ft_all + (size_t)f * FT_WORDS;
+    int p0, n, sa = 0, ns = 0;
+    if (fused) {
+        sa = sw.frame_sweep_off[f];
+        ns = sw.frame_sweep_off[f + 1] - sa;
+        p0 = sw.sweep_row_off[sa];
+        n = sw.sweep_row_off[sa + ns] - p0;
+        if (lane == 0) {
+            sw.pt_off_out[f] = p0;
+            if (f == n_frames - 1) {
+                const int total_rows = sw.sweep_row_off[sw.n_sweeps];
+                sw.pt_off_out[n_frames] = total_rows;
+                status[1] = total_rows;
+                if (total_rows > sw.pt_cap) atomicOr(&status[0], 1);
+                if (sw.frame_sweep_off[0] != 0 || sa + ns != sw.n_sweeps) atomicOr(&status[0], 4);      // sweeps outside every frame
             }
-        } else {
-            pt[j] = i < n ? points[p0 + i] : make_float4(qnan, qnan, qnan, 0.f);
+        }
+        n = max(0, min(n, sw.pt_cap - p0));
+        if (lane <= ns && lane <= PH_MAX_SWEEPS) ft[FT_SROW + lane] = sw.sweep_row_off[sa + lane] - p0;
+    } else {
+        p0 = pt_off[f];
+        n = pt_off[f + 1] - p0;
+    }
+    if (n > max_pts_per_frame) {             // more rows than the workspace was sized for: stay inside it, report
+        if (lane == 0) atomicOr(&status[0], 1);
+        n = max_pts_per_frame;
+    }
+    n = max(n, 0);
+    const int m0 = mask_off[f];
+    int nm = mask_off[f + 1] - m0;
+    if (nm > nm_cap) {                       // more masks than the caller's `planes` allows
+        if (lane == 0) atomicOr(&status[0], 4);
+        nm = nm_cap;
+    }
+    nm = max(nm, 0);
+    if (lane == 0) {
+        ft[0] = p0; ft[1] = n; ft[2] = m0; ft[3] = nm; ft[4] = sa; ft[5] = ns;
+        ft[6] = (p0 >> 5) + 8 * f;          // frames never overlap: sum ceil(n_g / 32) <= (p0 >> 5) + f, and a chunk owns 8 whole words
+        ft[7] = (n + PH_WC - 1) / PH_WC;
+    }
+    if (lane < CM3D_MAX_CAMS) {
+        float *cone = reinterpret_cast<float *>(ft + FT_CONE) + 8 * lane;
+        if (lane < n_cams) cone_setup(cams + ((size_t)f * n_cams + lane) * CM3D_CAM_STRIDE, W, H, min_dist, cone);
+        else { cone[6] = INFINITY; cone[7] = 0.f; }
+    }
+    int4 *ment = ment_all + (size_t)f * nm_cap;
+    int run = 0;
+    for (int c = 0; c < n_cams; ++c) {
+        if (lane == 0) ft[FT_CAMFIRST + c] = run;
+        for (int k0 = 0; k0 < nm; k0 += 64) {
+            const int k = k0 + lane;
+            bool v = false;
+            int4 bb = make_int4(0, 0, -1, -1);
+            if (k < nm) {
+                const int cam = mask_cam[m0 + k];
+                bb = bbox[m0 + k];
+                v = cam == c && bb.z >= bb.x && bb.w >= bb.y;
+                if (c == 0 && (cam < 0 || cam >= n_cams)) atomicOr(&status[0], 4);           // such a mask gets no points
+            }
+            const uint64_t mk = __ballot(v);
+            if (v) ment[run + cm3d_mbcnt(mk)] = make_int4(bb.x | (k << 16), bb.y, bb.z - bb.x, bb.w - bb.y);
+            run += (int)__popcll(mk);
         }
     }
+    if (lane == 0)
+        for (int c = n_cams; c <= CM3D_MAX_CAMS; ++c) ft[FT_CAMFIRST + c] = run;
 }
 
 static __device__ __forceinline__ void ph_xform(const float *xf, float x, float y, float z, float &ox, float &oy, float &oz)
@@ -234,168 +353,172 @@ static __device__ __forceinline__ void ph_xform(const float *xf, float x, float 
     ox = ox + xf[21]; oy = oy + xf[22]; oz = oz + xf[23];
 }
 
-// raw rows of a chunk -> global-frame points in place (dropped / dead slots become NaN points), stored to the cloud,
-// dropped rows appended to the block's LDS list (or, once that is full, to the frame's list directly)
-static __device__ __forceinline__ void ph_prepare(float4 (&pt)[PH_PT], const PhSweepIn &sw, int f, int sa, int ns, const int *s_srow,
-                                                  int p0, int n, int chunk, int *s_drop, int *s_ndrop)
+// The 4 rows of this lane: x, y, z, w of row j at v[j*S .. j*S+3], S = row stride in registers (5 for 5-column rows,
+// else 4).  STRIDE > 0: full chunks come as STRIDE 16-byte loads per lane (rows 4l..4l+3 are 4*STRIDE consecutive dwords);
+// STRIDE == 0 (any other row stride) and the last, partial chunk of a frame: row by row.  Slots past the end of the frame
+// read as (1e30, 1e30, 0, 0): never dropped, and turned into NaN points by the caller.
+template <int STRIDE>
+struct PhRows { static constexpr int S = STRIDE == 5 ? 5 : 4; float v[4 * S]; };
+
+template <int STRIDE>
+static __device__ __forceinline__ void ph_load_rows(PhRows<STRIDE> &r, const float *__restrict__ src, int stride, size_t row0, int nvalid,
+                                                    int lane, int diag = 0)
 {
-    const float qnan = __int_as_float(0x7FC00000);
-    const int base = chunk * PH_BLOCK_PTS;
-    // sweep of the wave's first and last row: equal for all but the waves that hold a sweep boundary
-    int sw_lo = 0, sw_hi = 0;
-    if (ns > 1) {
-        const int r_lo = base + (int)(threadIdx.x >> 6) * (64 * PH_PT), r_hi = min(r_lo + 64 * PH_PT, n) - 1;
-        for (int k = 1; k < ns; ++k) { sw_lo += s_srow[k] <= r_lo; sw_hi += s_srow[k] <= r_hi; }
-    }
-    const bool uni = sw_lo >= sw_hi;
-    const float *xf_u = sw.sweep_xf + (size_t)(sa + __builtin_amdgcn_readfirstlane(sw_lo)) * CM3D_SWEEP_XF_STRIDE;   // scalar loads
+    constexpr int S = PhRows<STRIDE>::S;
+    if (PH_DIAG(8)) {
 #pragma unroll
-    for (int j = 0; j < PH_PT; ++j) {
-        const int i = base + ph_slot(j);
-        const bool live = i < n;
-        const float x = pt[j].x, y = pt[j].y, z = pt[j].z, w = pt[j].w;
-        const bool drop = live && fabsf(x) < sw.halfw && fabsf(y) < sw.halfw;      // reference drops this row (2d_to_3d.py:442-445)
-        float bx, by, bz;
-        if (uni) {
-            ph_xform(xf_u, x, y, z, bx, by, bz);
-        } else {
-            int k_sw = 0;
-            for (int k = 1; k < ns; ++k) k_sw += s_srow[k] <= i;
-            ph_xform(sw.sweep_xf + (size_t)(sa + k_sw) * CM3D_SWEEP_XF_STRIDE, x, y, z, bx, by, bz);
+        for (int j = 0; j < PH_PT; ++j) {
+            const int i = (int)row0 + 4 * lane + j;
+            r.v[j * S] = (float)(i & 1023) * 0.05f - 20.f; r.v[j * S + 1] = (float)((i >> 10) & 63) * 0.5f - 8.f;
+            r.v[j * S + 2] = -1.f; r.v[j * S + 3] = 0.f;
         }
-        if (!live || drop) { bx = qnan; by = qnan; bz = qnan; }
-        pt[j] = make_float4(bx, by, bz, w);
-        if (live) sw.points_out[p0 + i] = pt[j];
-        const uint64_t dm = __ballot(drop);
-        if (dm) {
-            const int cnt = (int)__popcll(dm);
-            int pos0 = 0;
-            if (cm3d_lane() == 0) pos0 = atomicAdd(s_ndrop, cnt);
-            pos0 = __builtin_amdgcn_readfirstlane(pos0);
-            const int n_lds = max(0, min(cnt, PH_DROP_CAP - pos0)), n_over = cnt - n_lds;
-            int gbase = 0;
-            if (n_over) {
-                if (cm3d_lane() == 0) gbase = atomicAdd(&sw.removed_cnt[f], n_over);
-                gbase = __builtin_amdgcn_readfirstlane(gbase);
+        return;
+    }
+    if (STRIDE > 0 && nvalid >= PH_WC) {
+        const f4u *p = reinterpret_cast<const f4u *>(src + (row0 + (size_t)(4 * lane)) * STRIDE);
+#pragma unroll
+        for (int q = 0; q < STRIDE; ++q) {
+            const f4u t = __builtin_nontemporal_load(p + q);
+            r.v[4 * q] = t.x; r.v[4 * q + 1] = t.y; r.v[4 * q + 2] = t.z; r.v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PH_PT; ++j) {
+            float x = 1e30f, y = 1e30f, z = 0.f, w = 0.f;
+            if (4 * lane + j < nvalid) {
+                const float *p = src + (row0 + (size_t)(4 * lane + j)) * stride;
+                x = __builtin_nontemporal_load(p); y = __builtin_nontemporal_load(p + 1);
+                z = __builtin_nontemporal_load(p + 2); w = __builtin_nontemporal_load(p + 3);
             }
-            if (drop) {
-                const int r = cm3d_mbcnt(dm);
-                if (r < n_lds) s_drop[pos0 + r] = i;
-                else sw.removed_idx[p0 + gbase + (r - n_lds)] = i;
-            }
+            r.v[j * S] = x; r.v[j * S + 1] = y; r.v[j * S + 2] = z; r.v[j * S + 3] = w;
+            if (S == 5) r.v[j * S + 4] = 0.f;
         }
     }
 }
 
-template <bool ONE_PLANE, bool FUSED>
+// sweep of frame-local row i (ns > 1): srow = the frame table's sweep starts
+static __device__ __forceinline__ int ph_sweep_of(const int32_t *srow, int ns, int i)
+{
+    int k_sw = 0;
+    for (int k = 1; k < ns; ++k) k_sw += srow[k] <= i;
+    return k_sw;
+}
+
+// grid (G, F), 4 waves per workgroup.  Workgroup bx of frame f owns the wave-chunks [nwc bx / G, nwc (bx+1) / G) of the frame,
+// split into four contiguous runs, one per wave.  Per wave-chunk:
+//   raw rows (requested one chunk ahead) -> ego-box drop + sensor -> ego -> global (FUSED) -> [cloud store] -> removed bits
+//   for every camera that can see any of the wave's points (cone test): project the 4 rows of every lane (pixel codes stay
+//   in registers), then for every mask of that camera: bounding-box test, one mask word per candidate point, bit test,
+//   hit count  -> hit words, per-(chunk, mask) counts.
+// ONE_PLANE (<= 32 masks per frame): the hit word of a row and the count of a mask live in registers (count of mask k in
+// lane k); otherwise in the wave's own LDS slice.
+// FUSED: `src` = raw sweep rows (a2, reference :437-465); otherwise `src` = a prepared float4 cloud (STRIDE 4) whose
+// dropped rows are NaN points.
+template <bool ONE_PLANE, bool FUSED, int STRIDE>
 __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
-    const float4 *__restrict__ points, const int32_t *__restrict__ pt_off, const PhSweepIn sw, int n_points_total,
-    const float *__restrict__ cams, int n_cams, const int32_t *__restrict__ mask_off,
-    const int32_t *__restrict__ mask_cam, const int4 *__restrict__ bbox, const uint32_t *__restrict__ packed,
-    int W, int H, int Wp, float min_dist, int nm_cap, int nblk_max, int chunks_per_block, uint32_t *__restrict__ hit_words,
-    int32_t *__restrict__ hit_count, int32_t *__restrict__ blk_cnt, int32_t *__restrict__ status)
+    const float *__restrict__ src, int src_stride, const float *__restrict__ sweep_xf, float halfw, float4 *__restrict__ points_out,
+    uint32_t *__restrict__ removed_bits, const int32_t *__restrict__ ft_all, const int4 *__restrict__ ment_all,
+    const float *__restrict__ cams, int n_cams, const uint32_t *__restrict__ packed, int W, int H, int Wp, float min_dist, int nm_cap,
+    int nwc_max, int n_points_total, uint32_t *__restrict__ hit_words, int32_t *__restrict__ hit_count, int32_t *__restrict__ wc_cnt)
 {
     const int f = blockIdx.y;
-    int p0, n, sa = 0, ns = 0;
-    if (FUSED) {
-        sa = sw.frame_sweep_off[f];
-        ns = sw.frame_sweep_off[f + 1] - sa;
-        p0 = sw.sweep_row_off[sa];
-        n = sw.sweep_row_off[sa + ns] - p0;
-        if (blockIdx.x == 0 && threadIdx.x == 0) {              // what k_sweep_xform leaves behind for the later stages
-            sw.pt_off_out[f] = p0;
-            if (f == sw.n_frames - 1) {
-                const int total_rows = sw.sweep_row_off[sw.n_sweeps];
-                sw.pt_off_out[sw.n_frames] = total_rows;
-                status[1] = total_rows;
-                if (total_rows > sw.pt_cap) atomicOr(&status[0], 1);
-                if (sw.frame_sweep_off[0] != 0 || sa + ns != sw.n_sweeps) atomicOr(&status[0], 4);      // sweeps outside every frame
-            }
-        }
-        n = max(0, min(n, sw.pt_cap - p0));
-    } else {
-        p0 = pt_off[f];
-        n = pt_off[f + 1] - p0;
-    }
-    const int nblk = (n + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
-    if ((int)blockIdx.x >= nblk) return;
-    const int m0 = mask_off[f];
-    int nm = mask_off[f + 1] - m0;
-    if (nm > nm_cap) {                       // more masks than the caller's `planes` allows
-        if (threadIdx.x == 0) atomicOr(&status[0], 4);
-        nm = nm_cap;
-    }
-    const int planes = (nm + 31) >> 5;
+#ifdef CM3D_DIAG
+    const int diag = g_ph_diag;
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+    if (diag & 16) t_prev = ph_now();
+#endif
+    const int32_t *ft = ft_all + (size_t)f * FT_WORDS;              // uniform: scalar loads
+    const int p0 = ft[0], n = ft[1], m0 = ft[2], nm = ft[3], sa = ft[4], ns = ft[5], bits_off = ft[6], nwc = ft[7];
+    const int b_lo = (int)((long long)nwc * blockIdx.x / gridDim.x), b_hi = (int)((long long)nwc * (blockIdx.x + 1) / gridDim.x);
+    if (b_lo >= b_hi) return;                                       // the whole workgroup
+    const int lane = cm3d_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c_lo = b_lo + (b_hi - b_lo) * wave / PH_WAVES, c_hi = b_lo + (b_hi - b_lo) * (wave + 1) / PH_WAVES;
+    const int planes = (nm + 31) >> 5, planes_cap = (nm_cap + 31) >> 5;
 
     __shared__ float s_cam[CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
-    __shared__ float s_cone[CM3D_MAX_CAMS][8];           // conservative visibility cone per camera
-    // dynamic LDS: masks of every camera as bit sets [n_cams][planes_cap], counts [chunks_per_block][nm_cap] (one
-    // row per chunk this block walks), and (several planes only) hit words [planes][PH_BLOCK_PTS]
+    __shared__ float s_cone[CM3D_MAX_CAMS][8];
+    __shared__ int s_first[CM3D_MAX_CAMS + 1];
+    // dynamic LDS (several planes only), one slice per wave: hit words [planes_cap][PH_WC], counts [nm_cap]
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    const int planes_cap = (nm_cap + 31) >> 5;
-    uint32_t *s_cmask = reinterpret_cast<uint32_t *>(s_dyn);
-    int *s_cnt = reinterpret_cast<int *>(s_cmask + CM3D_MAX_CAMS * planes_cap);
-    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cnt + chunks_per_block * nm_cap);
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_dyn) + (size_t)wave * planes_cap * PH_WC;
+    int *s_cnt = reinterpret_cast<int *>(reinterpret_cast<uint32_t *>(s_dyn) + (size_t)PH_WAVES * planes_cap * PH_WC) + wave * nm_cap;
 
-    // points of the first chunk are requested before the table staging so that both latencies overlap.
-    // Slots past the end of the frame hold NaN points: every test below rejects them by itself.
-    __shared__ int s_srow[FUSED ? PH_MAX_SWEEPS + 1 : 1];     // first row of each sweep of the frame (frame-local)
-    __shared__ int s_drop[FUSED ? PH_DROP_CAP : 1];            // dropped rows of this block (frame-local row indices)
-    __shared__ int s_ndrop, s_dropbase;
-    float4 pt[PH_PT];
-    ph_load<FUSED>(pt, points, sw, p0, n, (int)blockIdx.x);
-    if (FUSED) {
-        if (threadIdx.x <= ns && threadIdx.x <= PH_MAX_SWEEPS) s_srow[threadIdx.x] = sw.sweep_row_off[sa + threadIdx.x] - p0;
-        if (threadIdx.x == 0) s_ndrop = 0;
-    }
-    for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS)
-        s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
-    for (int q = threadIdx.x; q < CM3D_MAX_CAMS * planes_cap; q += PH_THREADS) s_cmask[q] = 0u;
-    for (int k = threadIdx.x; k < chunks_per_block * nm_cap; k += PH_THREADS) s_cnt[k] = 0;
-    __syncthreads();
-    for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
-        const int c = mask_cam[m0 + k];
-        if (c < 0 || c >= n_cams) atomicOr(&status[0], 4);           // such a mask gets no points
-        else atomicOr(&s_cmask[c * planes_cap + (k >> 5)], 1u << (k & 31));
-    }
-    // visibility cones from the staged records (LDS reads; no dependent global loads)
-    if (threadIdx.x < n_cams) cone_setup(s_cam + threadIdx.x * CM3D_CAM_STRIDE, W, H, min_dist, s_cone[threadIdx.x]);
-    __syncthreads();
+    // the first chunk's rows are requested before the table staging so that both latencies overlap
+    PhRows<STRIDE> cur;
+    if (c_lo < c_hi) ph_load_rows<STRIDE>(cur, src, src_stride, (size_t)p0 + (size_t)c_lo * PH_WC, min(PH_WC, n - c_lo * PH_WC), lane, PH_DIAG(8));
+    for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS) s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
+    if (threadIdx.x < CM3D_MAX_CAMS * 8) (&s_cone[0][0])[threadIdx.x] = reinterpret_cast<const float *>(ft + FT_CONE)[threadIdx.x];
+    if (threadIdx.x <= CM3D_MAX_CAMS) s_first[threadIdx.x] = ft[FT_CAMFIRST + threadIdx.x];
+    __syncthreads();                                                // the only one: from here on the waves are on their own
+    PH_STAMP(0);                                                    // setup
 
+    const int4 *ment = ment_all + (size_t)f * nm_cap;
     const size_t mask_words = (size_t)H * Wp;
-    const int lane = cm3d_lane();
-    // The waves of a block walk its chunks without meeting: the per-(chunk, mask) counts collect in LDS rows and are
-    // flushed once, behind the only barrier after the loop (a barrier per chunk made every wave wait for the
-    // slowest one of each chunk).
-    int ci = 0;
-    for (int chunk = blockIdx.x; chunk < nblk; chunk += gridDim.x, ++ci) {
-        const int base = chunk * PH_BLOCK_PTS;
-        int *s_cnt_row = s_cnt + ci * nm_cap;
-        static_assert(PH_PT % 2 == 0, "points are handled in pairs");
-        if (FUSED) ph_prepare(pt, sw, f, sa, ns, s_srow, p0, n, chunk, s_drop, &s_ndrop);
-        // FUSED: the next chunk's raw rows (HBM, 20-byte stride) are requested now, into their own registers, and
-        // arrive under the camera loop (887 k against 856 k frames/s with the request at the end of the chunk)
-        float4 nxt[PH_PT];
-        if (FUSED && chunk + (int)gridDim.x < nblk) ph_load<FUSED>(nxt, points, sw, p0, n, chunk + (int)gridDim.x);
+    const float qnan = __int_as_float(0x7FC00000);
+    constexpr int S = PhRows<STRIDE>::S;
+    int acc_cnt = 0;                                                // ONE_PLANE: lane k = hits of mask k over this wave's chunks
+    for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+        const int cb = chunk * PH_WC;
+        const int nvalid = min(PH_WC, n - cb);                      // uniform
+        // the next chunk's rows are requested now, into their own registers, and arrive under the camera loop
+        PhRows<STRIDE> nxt;
+        if (chunk + 1 < c_hi) ph_load_rows<STRIDE>(nxt, src, src_stride, (size_t)p0 + (size_t)cb + PH_WC, min(PH_WC, n - cb - PH_WC), lane, PH_DIAG(8));
+        float px_[PH_PT], py_[PH_PT], pz_[PH_PT];
+        if (FUSED) {
+            // sweep of the chunk's first and last row: equal for all but the chunks that hold a sweep boundary
+            const int32_t *srow = ft + FT_SROW;
+            int sw_lo = 0, sw_hi = 0;
+            if (ns > 1) { sw_lo = ph_sweep_of(srow, ns, cb); sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1); }
+            const bool uni = sw_lo >= sw_hi;
+            const float *xf_u = sweep_xf + (size_t)(sa + sw_lo) * CM3D_SWEEP_XF_STRIDE;                    // scalar loads
+            uint32_t nib = 0;
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) {
+                const int i = cb + 4 * lane + j;
+                const bool live = 4 * lane + j < nvalid;
+                const float x = cur.v[j * S], y = cur.v[j * S + 1], z = cur.v[j * S + 2];
+                const bool drop = live && fabsf(x) < halfw && fabsf(y) < halfw;      // reference drops this row (2d_to_3d.py:442-445)
+                float bx, by, bz;
+                if (uni) ph_xform(xf_u, x, y, z, bx, by, bz);
+                else ph_xform(sweep_xf + (size_t)(sa + ph_sweep_of(srow, ns, i)) * CM3D_SWEEP_XF_STRIDE, x, y, z, bx, by, bz);
+                if (!live || drop) { bx = qnan; by = qnan; bz = qnan; }
+                px_[j] = bx; py_[j] = by; pz_[j] = bz;
+                nib |= (drop ? 1u : 0u) << j;
+                if (points_out && live) points_out[(size_t)p0 + i] = make_float4(bx, by, bz, cur.v[j * S + 3]);
+            }
+            if (__ballot(nib != 0u)) {
+                // this chunk's 8 words of the frame's removed-row bits (zeroed by cm3d_batch_begin): lane l holds bits 4(l&7)..+3 of word l>>3
+                uint32_t vv = nib << (4 * (lane & 7));
+                vv |= (uint32_t)__shfl_xor((int)vv, 1, 64); vv |= (uint32_t)__shfl_xor((int)vv, 2, 64); vv |= (uint32_t)__shfl_xor((int)vv, 4, 64);
+                if ((lane & 7) == 0) removed_bits[(size_t)bits_off + 8 * chunk + (lane >> 3)] = vv;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) {
+                const bool live = 4 * lane + j < nvalid;
+                px_[j] = live ? cur.v[j * S] : qnan; py_[j] = live ? cur.v[j * S + 1] : qnan; pz_[j] = live ? cur.v[j * S + 2] : qnan;
+            }
+        }
+        PH_STAMP(1);                                                // rows arrive, transform, [cloud store]
         f2 X[PH_NP], Y[PH_NP], Z[PH_NP];
 #pragma unroll
         for (int h = 0; h < PH_NP; ++h) {
-            X[h] = (f2){pt[2 * h].x, pt[2 * h + 1].x};
-            Y[h] = (f2){pt[2 * h].y, pt[2 * h + 1].y};
-            Z[h] = (f2){pt[2 * h].z, pt[2 * h + 1].z};
+            X[h] = (f2){px_[2 * h], px_[2 * h + 1]};
+            Y[h] = (f2){py_[2 * h], py_[2 * h + 1]};
+            Z[h] = (f2){pz_[2 * h], pz_[2 * h + 1]};
         }
         uint32_t bits[PH_PT];
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) bits[j] = 0;
+        int mycnt = 0;                                              // ONE_PLANE: lane k = hits of mask k in this chunk
         if (!ONE_PLANE) {
-            for (int pl = 0; pl < planes; ++pl)
-#pragma unroll
-                for (int j = 0; j < PH_PT; ++j) s_bits[pl * PH_BLOCK_PTS + ph_slot(j)] = 0u;      // this thread's own slots
+            for (int pl = 0; pl < planes; ++pl) *reinterpret_cast<uint4 *>(&s_bits[pl * PH_WC + 4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+            for (int k = lane; k < nm; k += 64) s_cnt[k] = 0;
         }
 #pragma unroll 1
-        for (int c = 0; c < n_cams; ++c) {
+        for (int c = 0; c < (PH_DIAG(4) ? 0 : n_cams); ++c) {
             // conservative pre-test (a superset of the exact in-image test): is any of this wave's points
-            // inside the camera's visibility cone?  A wave's 4 x 64 points are consecutive in the sweep, i.e. a
+            // inside the camera's visibility cone?  A wave's 256 rows are consecutive in the sweep, i.e. a
             // short arc of the scan, and most cameras are rejected here for the whole wave.
             //   inside  <=>  sdist - c6 >= 0  and  c7 * sdist^2 - r2 >= 0   (NaN compares false)
             const float *cn = s_cone[c];
@@ -414,127 +537,137 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
 #pragma unroll
                 for (int h = 1; h < PH_NP; ++h) inside = fmaxf(inside, fmaxf(m[h].x, m[h].y));
             }
+            PH_STAMP(2);                                            // cone tests
             if (!__ballot(inside >= 0.0f)) continue;
-            const int ns = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 54]);
-            const int fl = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 55]);
+            const int cns = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 54]);
+            const int cfl = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 55]);
             const float *cm = s_cam + c * CM3D_CAM_STRIDE;
             int px[PH_PT];
-            if (ns == 2 && fl == 5) project_quad<2, 5>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);          // nuScenes
-            else if (ns == 1 && fl == 1) project_quad<1, 1>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);     // Waymo
-            else if (ns == 3 && fl == 10) project_quad<3, 10>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);   // KITTI
-            else project_quad<-1, 0>(cm, ns, fl, X, Y, Z, min_dist, W, H, px);
+            if (cns == 2 && cfl == 5) project_quad<2, 5>(cm, cns, cfl, X, Y, Z, min_dist, W, H, px);          // nuScenes
+            else if (cns == 1 && cfl == 1) project_quad<1, 1>(cm, cns, cfl, X, Y, Z, min_dist, W, H, px);     // Waymo
+            else if (cns == 3 && cfl == 10) project_quad<3, 10>(cm, cns, cfl, X, Y, Z, min_dist, W, H, px);   // KITTI
+            else project_quad<-1, 0>(cm, cns, cfl, X, Y, Z, min_dist, W, H, px);
             int pxall = px[0];
 #pragma unroll
             for (int j = 1; j < PH_PT; ++j) pxall &= px[j];
-            if (!__ballot(pxall >= 0)) continue;                 // no point of the wave in this image
+            PH_STAMP(3);                                            // projection
+            if (!__ballot(pxall >= 0) || PH_DIAG(2)) continue;      // no point of the wave in this image
             // px = iv << 16 | iu; px = -1 gives iv = -1
 #define PX_IU(j) (px[j] & 0xFFFF)
 #define PX_IV(j) (px[j] >> 16)
-            // the masks of this camera, PH_MB at a time: all bounding boxes, then all mask words of the batch are
-            // requested before the first one is used (one memory round trip per batch instead of one per mask)
-            for (int pl = 0; pl < planes; ++pl) {
-                uint32_t mm = __builtin_amdgcn_readfirstlane(s_cmask[c * planes_cap + pl]);
-                while (mm) {
-                    int kb[PH_MB];
+            // the masks of this camera (sorted entries: bounding box + mask number), PH_MB at a time: all entries, then all
+            // mask words of the batch are requested before the first one is used (one memory round trip per batch)
+            const int e1 = __builtin_amdgcn_readfirstlane(s_first[c + 1]);
+            for (int e = __builtin_amdgcn_readfirstlane(s_first[c]); e < e1; e += PH_MB) {
+                int4 en[PH_MB];
 #pragma unroll
-                    for (int b = 0; b < PH_MB; ++b) {
-                        kb[b] = mm ? __builtin_ctz(mm) : -1;
-                        mm = mm ? (mm & (mm - 1)) : 0u;
+                for (int b = 0; b < PH_MB; ++b) en[b] = ment[min(e + b, e1 - 1)];                  // uniform: scalar loads
+                uint32_t word[PH_MB][PH_PT];
+                int kb[PH_MB];
+#pragma unroll
+                for (int b = 0; b < PH_MB; ++b) {
+#pragma unroll
+                    for (int j = 0; j < PH_PT; ++j) word[b][j] = 0u;
+                    const int ex = __builtin_amdgcn_readfirstlane(en[b].x), y0 = __builtin_amdgcn_readfirstlane(en[b].y);
+                    const int rx = __builtin_amdgcn_readfirstlane(en[b].z), ry = __builtin_amdgcn_readfirstlane(en[b].w);
+                    const int x0 = ex & 0xFFFF;
+                    kb[b] = e + b < e1 ? (ex >> 16) : -1;
+                    if (kb[b] < 0) continue;                        // past the camera's last mask (wave-uniform)
+                    const uint32_t *mw = packed + (size_t)(m0 + kb[b]) * mask_words;
+#pragma unroll
+                    for (int j = 0; j < PH_PT; ++j) {
+                        // iv = -1 < y0 fails the unsigned range test by itself
+                        const bool cand = ((unsigned)(PX_IU(j) - x0) <= (unsigned)rx) & ((unsigned)(PX_IV(j) - y0) <= (unsigned)ry);
+                        if (cand) word[b][j] = mw[(size_t)PX_IV(j) * Wp + (PX_IU(j) >> 5)];
                     }
-                    int4 bb[PH_MB];
+                }
 #pragma unroll
-                    for (int b = 0; b < PH_MB; ++b) bb[b] = bbox[m0 + pl * 32 + max(kb[b], 0)];      // uniform: scalar loads
-                    uint32_t word[PH_MB][PH_PT];
+                for (int b = 0; b < PH_MB; ++b) {
+                    if (kb[b] < 0) continue;
+                    int cnt = 0;
 #pragma unroll
-                    for (int b = 0; b < PH_MB; ++b) {
-#pragma unroll
-                        for (int j = 0; j < PH_PT; ++j) word[b][j] = 0u;
-                        const int x0 = __builtin_amdgcn_readfirstlane(bb[b].x), y0 = __builtin_amdgcn_readfirstlane(bb[b].y);
-                        const int rx = __builtin_amdgcn_readfirstlane(bb[b].z) - x0, ry = __builtin_amdgcn_readfirstlane(bb[b].w) - y0;
-                        if (kb[b] < 0 || (rx | ry) < 0) continue;          // no such mask / empty mask (wave-uniform)
-                        const uint32_t *mw = packed + (size_t)(m0 + pl * 32 + kb[b]) * mask_words;
-#pragma unroll
-                        for (int j = 0; j < PH_PT; ++j) {
-                            // iv = -1 < y0 fails the unsigned range test by itself
-                            const bool cand = ((unsigned)(PX_IU(j) - x0) <= (unsigned)rx) & ((unsigned)(PX_IV(j) - y0) <= (unsigned)ry);
-                            if (cand) word[b][j] = mw[(size_t)PX_IV(j) * Wp + (PX_IU(j) >> 5)];
-                        }
+                    for (int j = 0; j < PH_PT; ++j) {
+                        const bool hit = (word[b][j] >> (px[j] & 31)) & 1u;          // word = 0 for a non-candidate
+                        if (ONE_PLANE) bits[j] |= (hit ? 1u : 0u) << kb[b];
+                        else if (hit) s_bits[(kb[b] >> 5) * PH_WC + 4 * lane + j] |= 1u << (kb[b] & 31);
+                        cnt += (int)__popcll(__ballot(hit));
                     }
-#pragma unroll
-                    for (int b = 0; b < PH_MB; ++b) {
-                        if (kb[b] < 0) continue;
-                        int cnt = 0;
-#pragma unroll
-                        for (int j = 0; j < PH_PT; ++j) {
-                            const bool hit = (word[b][j] >> (px[j] & 31)) & 1u;          // word = 0 for a non-candidate
-                            if (ONE_PLANE) bits[j] |= (hit ? 1u : 0u) << kb[b];
-                            else if (hit) s_bits[pl * PH_BLOCK_PTS + ph_slot(j)] |= 1u << kb[b];
-                            cnt += __popcll(__ballot(hit));
-                        }
-                        if (cnt && lane == 0) atomicAdd(&s_cnt_row[pl * 32 + kb[b]], cnt);
+                    if (cnt) {
+                        if (ONE_PLANE) mycnt += lane == kb[b] ? cnt : 0;
+                        else if (lane == 0) s_cnt[kb[b]] += cnt;
                     }
                 }
             }
+            PH_STAMP(4);                                            // mask loop of one camera
         }
-        // prefetch the next chunk's points (if this block has one) under the count flush
-        if (FUSED) {
+        PH_STAMP(2);
+        // results of the chunk: hit words (16 bytes per lane and plane), per-mask counts
+        int32_t *cnt_row = wc_cnt + ((size_t)f * nwc_max + chunk) * nm_cap;
+        if (ONE_PLANE) {
+            uint32_t *hw = hit_words + (size_t)p0 + cb + 4 * lane;
+            if (nvalid >= PH_WC) {
+                *reinterpret_cast<u4u *>(hw) = (u4u){bits[0], bits[1], bits[2], bits[3]};
+            } else {
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) pt[j] = nxt[j];
-        } else if (chunk + (int)gridDim.x < nblk) {
-            ph_load<FUSED>(pt, points, sw, p0, n, chunk + (int)gridDim.x);
-        }
-#pragma unroll
-        for (int j = 0; j < PH_PT; ++j) {
-            const int idx = base + ph_slot(j);
-            if (idx < n) {
-                if (ONE_PLANE) hit_words[(size_t)p0 + idx] = bits[j];
-                else
-                    for (int pl = 0; pl < planes; ++pl)
-                        hit_words[(size_t)pl * n_points_total + p0 + idx] = s_bits[pl * PH_BLOCK_PTS + ph_slot(j)];
+                for (int j = 0; j < PH_PT; ++j)
+                    if (4 * lane + j < nvalid) hw[j] = bits[j];
             }
+            if (lane < 32) cnt_row[lane] = mycnt;
+            acc_cnt += mycnt;
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int pl = 0; pl < planes; ++pl) {
+                const uint4 w4 = *reinterpret_cast<const uint4 *>(&s_bits[pl * PH_WC + 4 * lane]);
+                uint32_t *hw = hit_words + (size_t)pl * n_points_total + p0 + cb + 4 * lane;
+                if (nvalid >= PH_WC) {
+                    *reinterpret_cast<u4u *>(hw) = (u4u){w4.x, w4.y, w4.z, w4.w};
+                } else {
+                    const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int j = 0; j < PH_PT; ++j)
+                        if (4 * lane + j < nvalid) hw[j] = wv[j];
+                }
+            }
+            for (int k = lane; k < nm; k += 64) {
+                const int cv = s_cnt[k];
+                cnt_row[k] = cv;
+                if (cv) atomicAdd(&hit_count[m0 + k], cv);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        cur = nxt;
+        PH_STAMP(5);                                                // result stores
     }
-    __syncthreads();
-    // per-(chunk, mask) counts: exact output offsets come from their exclusive scan (k_hit_offsets)
-    for (int k = threadIdx.x; k < nm; k += PH_THREADS) {
-        int tot = 0;
-        int r = 0;
-        for (int chunk = blockIdx.x; chunk < nblk; chunk += gridDim.x, ++r) {
-            const int c = s_cnt[r * nm_cap + k];
-            blk_cnt[((size_t)f * nblk_max + chunk) * nm_cap + k] = c;
-            tot += c;
-        }
-        if (tot) atomicAdd(&hit_count[m0 + k], tot);
-    }
-    if (FUSED) {
-        // the block's dropped rows join the frame's list with ONE global atomic (see k_sweep_xform)
-        const int nd = min(s_ndrop, PH_DROP_CAP);
-        if (nd == 0) return;
-        if (threadIdx.x == 0) s_dropbase = atomicAdd(&sw.removed_cnt[f], nd);
-        __syncthreads();
-        const int dbase = p0 + s_dropbase;
-        for (int i = threadIdx.x; i < nd; i += PH_THREADS) sw.removed_idx[dbase + i] = s_drop[i];
-    }
+    if (ONE_PLANE && lane < nm && acc_cnt) atomicAdd(&hit_count[m0 + lane], acc_cnt);
+#ifdef CM3D_DIAG
+    if ((diag & 16) && lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_ph_stamp[k], k == 7 ? 1ull : acc[k]);
+#endif
 }
 
 // One workgroup per frame: exclusive scans of hit_count and of the medoid tile counts for the frame's masks
 // (the frame's base = sum over all earlier masks, recomputed by every workgroup -- n_masks loads from L2 are
-// cheaper than a launch boundary), then every mask's per-block counts turned into exclusive output offsets,
-// in place.  Status bookkeeping by the last workgroup.
+// cheaper than a launch boundary), then every mask's per-chunk counts turned into exclusive output offsets, in place
+// (32 masks x 32 runs of chunks at a time: run sums, their prefix through LDS, second pass writes), and the number of
+// dropped rows before every chunk.  Status bookkeeping by the last workgroup.
 __global__ __launch_bounds__(1024) void k_hit_offsets(const int32_t *__restrict__ hit_count, int n_masks,
-                                                      const int32_t *__restrict__ pt_off, const int32_t *__restrict__ mask_off,
-                                                      int n_frames, int nm_cap, int nblk_max, int32_t *__restrict__ hit_off,
-                                                      int32_t *__restrict__ tile_off, int32_t *blk_cnt, int idx_cap,
+                                                      const int32_t *__restrict__ ft_all, const int32_t *__restrict__ mask_off,
+                                                      int n_frames, int nm_cap, int nwc_max, int32_t *__restrict__ hit_off,
+                                                      int32_t *__restrict__ tile_off, int32_t *wc_cnt, int32_t *__restrict__ wc_drop,
+                                                      const uint32_t *__restrict__ removed_bits, int idx_cap,
                                                       int32_t *__restrict__ status)
 {
     __shared__ int s_part[16];
     __shared__ int s_red[2][16];
+    __shared__ int s_base[CM3D_MAX_MASKS_PER_FRAME];
+    __shared__ int s_seg[32][33];
     const int f = blockIdx.x, t = threadIdx.x;
+    const int32_t *ft = ft_all + (size_t)f * FT_WORDS;
     const int m0 = mask_off[f];
     const int m1 = f == n_frames - 1 ? n_masks : mask_off[f + 1];
-    const int nm = min(mask_off[f + 1] - m0, nm_cap);
-    const int n = pt_off[f + 1] - pt_off[f];
-    const int nblk = (n + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
+    const int nm = ft[3], nwc = ft[7], bits_off = ft[6];
     // base offsets of the frame
     int a = 0, b = 0;
     for (int i = t; i < m0; i += 1024) {
@@ -557,26 +690,66 @@ __global__ __launch_bounds__(1024) void k_hit_offsets(const int32_t *__restrict_
         const int ex = cm3d_block1024_excl_scan(v, s_part, tot);
         const int tex = cm3d_block1024_excl_scan(tl, s_part, ttot);
         if (live) { hit_off[m0 + k] = carry + ex; tile_off[m0 + k] = tcarry + tex; }
-        if (k < nm) {
-            // block by block: count -> exclusive offset (loads of 8 blocks in flight)
-            int run = carry + ex;
-            int32_t *p = blk_cnt + (size_t)f * nblk_max * nm_cap + k;
-            int bi = 0;
-            for (; bi + 8 <= nblk; bi += 8) {
-                int c[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) c[u] = p[(size_t)(bi + u) * nm_cap];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { p[(size_t)(bi + u) * nm_cap] = run; run += c[u]; }
-            }
-            for (; bi < nblk; ++bi) {
-                const int c = p[(size_t)bi * nm_cap];
-                p[(size_t)bi * nm_cap] = run;
-                run += c;
-            }
-        }
+        if (k < nm) s_base[k] = carry + ex;
         carry += tot; tcarry += ttot;
         __syncthreads();
+    }
+    // per-chunk counts -> exclusive output offsets: thread (seg, q) sums / rewrites the chunks [seg cps, (seg+1) cps) of mask 32 pl + q
+    const int seg = t >> 5, q = t & 31;
+    const int cps = (nwc + 31) >> 5, c0 = min(nwc, seg * cps), c1 = min(nwc, c0 + cps);
+    for (int pl = 0; pl * 32 < nm; ++pl) {
+        const int k = pl * 32 + q;
+        int32_t *p = wc_cnt + (size_t)f * nwc_max * nm_cap + k;
+        int sum = 0;
+        if (k < nm) {
+            int c = c0;
+            for (; c + 8 <= c1; c += 8) {
+                int v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(c + u) * nm_cap];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += v[u];
+            }
+            for (; c < c1; ++c) sum += p[(size_t)c * nm_cap];
+        }
+        s_seg[seg][q] = sum;
+        __syncthreads();
+        if (k < nm) {
+            int run = s_base[k];
+            for (int s2 = 0; s2 < seg; ++s2) run += s_seg[s2][q];
+            int c = c0;
+            for (; c + 8 <= c1; c += 8) {
+                int v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(c + u) * nm_cap];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { p[(size_t)(c + u) * nm_cap] = run; run += v[u]; }
+            }
+            for (; c < c1; ++c) {
+                const int v = p[(size_t)c * nm_cap];
+                p[(size_t)c * nm_cap] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+    }
+    // dropped rows before every chunk (the emitted index of a point is its row minus the dropped rows before it)
+    if (removed_bits) {
+        int dcarry = 0;
+        for (int cb = 0; cb < nwc; cb += 1024) {
+            const int c = cb + t;
+            int v = 0;
+            if (c < nwc) {
+                const uint32_t *w = removed_bits + (size_t)bits_off + 8 * c;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += __popc(w[u]);
+            }
+            int tot;
+            const int ex = cm3d_block1024_excl_scan(v, s_part, tot);
+            if (c < nwc) wc_drop[(size_t)f * nwc_max + c] = dcarry + ex;
+            dcarry += tot;
+            __syncthreads();
+        }
     }
     if (f == n_frames - 1 && t == 0) {
         hit_off[n_masks] = carry;
@@ -587,17 +760,20 @@ __global__ __launch_bounds__(1024) void k_hit_offsets(const int32_t *__restrict_
     }
 }
 
-// grid (nblk_max, F): the same 1024 points and the same thread<->point map as k_project_hits.
-// Order inside a block is (wave, j, lane); per present mask bit: counts per wave through LDS, then
-// ballot + mbcnt positions on top of the block's exclusive offset.
+// grid (ceil(nwc_max / 4), F [+ 1]): one WAVE per wave-chunk, the same lane <-> row map as k_project_hits (lane l owns rows
+// 4l..4l+3, so ascending row order = (lane, j) order).  Per present mask bit: four ballots, rank = hits in lower lanes +
+// own hits in earlier rows, on top of the chunk's exclusive offset.  Every hit also gets its coordinates (hit_xyz, for the
+// medoid): gathered from the cloud when there is one, else re-derived from the raw row with the projection kernel's very
+// fma chains.  No workgroup barrier on this path.
+struct PhXyzSrc { const float *raw; int raw_stride; const float *sweep_xf; const float4 *points; };
+
 __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__restrict__ hit_words, int n_points_total,
-                                                             const int32_t *__restrict__ pt_off,
-                                                             const int32_t *__restrict__ mask_off, int nm_cap, int nblk_max,
-                                                             const int32_t *__restrict__ blk_base,
-                                                             const int32_t *__restrict__ removed_cnt,
-                                                             const int32_t *__restrict__ removed_idx,
-                                                             int32_t *__restrict__ hit_idx, int32_t *__restrict__ hit_row, int idx_cap,
-                                                             int n_frames, int n_masks, const int32_t *__restrict__ hit_off,
+                                                             const int32_t *__restrict__ ft_all, int nm_cap, int nwc_max,
+                                                             const int32_t *__restrict__ wc_base, const int32_t *__restrict__ wc_drop,
+                                                             const uint32_t *__restrict__ removed_bits, const PhXyzSrc xs,
+                                                             int32_t *__restrict__ hit_idx, int32_t *__restrict__ hit_row,
+                                                             float4 *__restrict__ hit_xyz, int idx_cap, int n_frames, int n_masks,
+                                                             const int32_t *__restrict__ hit_off,
                                                              const int32_t *__restrict__ tile_off, int tile_cap,
                                                              TileDesc *__restrict__ tile_work)
 {
@@ -611,98 +787,115 @@ __global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__r
                                       (int)gridDim.x);
         return;
     }
-    const int f = (int)blockIdx.y - row0, chunk = blockIdx.x;
-    const int p0 = pt_off[f], n = pt_off[f + 1] - p0;
-    const int base = chunk * PH_BLOCK_PTS;
-    if (base >= n) return;
-    const int m0 = mask_off[f];
-    const int nm = min(mask_off[f + 1] - m0, nm_cap);
+    const int f = (int)blockIdx.y - row0;
+    const int lane = cm3d_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int chunk = blockIdx.x * PH_WAVES + wave;
+    const int32_t *ft = ft_all + (size_t)f * FT_WORDS;
+    const int p0 = ft[0], n = ft[1], nm = ft[3], sa = ft[4], ns = ft[5], bits_off = ft[6];
+    const int cb = chunk * PH_WC;
+    if (cb >= n) return;
+    const int nvalid = min(PH_WC, n - cb);
     const int planes = (nm + 31) >> 5;
-    const int wave = threadIdx.x >> 6, lane = cm3d_lane();
-    // the hit words and the block's output offsets of plane 0 are requested first: their latency overlaps the
-    // dropped-row bookkeeping below
-    const int run_first = lane < min(nm, 32) ? blk_base[((size_t)f * nblk_max + chunk) * nm_cap + lane] : 0;
-    int idx[PH_PT];
-    uint32_t w_first[PH_PT];
+    // hit words of plane 0 and the chunk's output offsets are requested first
+    auto load_words = [&](int plane, uint32_t (&w)[PH_PT]) {
+        const uint32_t *hw = hit_words + (size_t)plane * n_points_total + p0 + cb + 4 * lane;
+        if (nvalid >= PH_WC) {
+            const u4u t = *reinterpret_cast<const u4u *>(hw);
+            w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+        } else {
 #pragma unroll
-    for (int j = 0; j < PH_PT; ++j) {
-        idx[j] = base + ph_slot(j);
-        w_first[j] = idx[j] < n ? hit_words[(size_t)p0 + idx[j]] : 0u;
-    }
-    // rows the sweep preparation dropped (ego box): the emitted index of a point is its row index minus the
-    // number of dropped rows before it, i.e. its index in the reference's compacted cloud
-    __shared__ uint32_t s_rm[PH_BLOCK_PTS / 32];      // dropped rows of this block, one bit per row
-    __shared__ int s_rm_before;                       // dropped rows of the frame before this block
-    __shared__ int s_rm_pre[PH_BLOCK_PTS / 32];
-    const int n_rm = removed_cnt ? removed_cnt[f] : 0;
-    if (n_rm > 0) {
-        if (threadIdx.x < PH_BLOCK_PTS / 32) s_rm[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) s_rm_before = 0;
-        __syncthreads();
-        int before = 0;
-        for (int q = threadIdx.x; q < n_rm; q += PH_THREADS) {
-            const int r = removed_idx[p0 + q];
-            if (r < base) ++before;
-            else if (r < base + PH_BLOCK_PTS) atomicOr(&s_rm[(r - base) >> 5], 1u << ((r - base) & 31));
+            for (int j = 0; j < PH_PT; ++j) w[j] = 4 * lane + j < nvalid ? hw[j] : 0u;
         }
-        before = cm3d_wave_sum(before);
-        if (cm3d_lane() == 0 && before) atomicAdd(&s_rm_before, before);
-        __syncthreads();
-        if (threadIdx.x < PH_BLOCK_PTS / 32) {       // exclusive prefix over the bitmap words
-            int pre = 0;
-            for (int wq = 0; wq < (int)threadIdx.x; ++wq) pre += __popc(s_rm[wq]);
-            s_rm_pre[threadIdx.x] = pre;
-        }
-        __syncthreads();
-    }
-    __shared__ int s_c[PH_THREADS / 64][32];
-    for (int plane = 0; plane < planes; ++plane) {
-        const uint32_t *hw = hit_words + (size_t)plane * n_points_total + p0;
+    };
+    uint32_t w0[PH_PT];
+    load_words(0, w0);
+    const int32_t *base_row = wc_base + ((size_t)f * nwc_max + chunk) * nm_cap;
+    const int run_first = lane < min(nm, 32) ? base_row[lane] : 0;
+    uint32_t rowany[PH_PT] = {w0[0], w0[1], w0[2], w0[3]};
+    for (int pl = 1; pl < planes; ++pl) {
         uint32_t w[PH_PT];
-        uint32_t any = 0;
+        load_words(pl, w);
 #pragma unroll
-        for (int j = 0; j < PH_PT; ++j) { w[j] = plane == 0 ? w_first[j] : (idx[j] < n ? hw[idx[j]] : 0u); any |= w[j]; }
-        const uint32_t orw = cm3d_wave_or(any);
-        int mycnt = 0;                         // lane b < 32: hits of mask bit b in this wave's 256 points
+        for (int j = 0; j < PH_PT; ++j) rowany[j] |= w[j];
+    }
+    if (!__ballot((rowany[0] | rowany[1] | rowany[2] | rowany[3]) != 0u)) return;        // no hit in this chunk
+    // rows the sweep preparation dropped (ego box): dropped rows before each of this lane's rows
+    int dropped[PH_PT] = {0, 0, 0, 0};
+    if (removed_bits) {
+        const int dbase = wc_drop[(size_t)f * nwc_max + chunk];
+        const uint32_t wv = lane < 8 ? removed_bits[(size_t)bits_off + 8 * chunk + lane] : 0u;
+        if (__ballot(wv != 0u) | (uint64_t)(dbase != 0)) {
+            int pc = __popc(wv), inc = pc;                       // lanes 0..7: inclusive prefix over the chunk's 8 words
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { const int tt = __shfl_up(inc, o, 64); if (lane >= o) inc += tt; }
+            const int pre = __shfl(inc - pc, lane >> 3, 64);
+            const uint32_t myw = (uint32_t)__shfl((int)wv, lane >> 3, 64);
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) dropped[j] = dbase + pre + __popc(myw & ((1u << (4 * (lane & 7) + j)) - 1u));
+        }
+    }
+    // coordinates of this lane's rows that lie in any mask
+    float4 xyz[PH_PT];
+#pragma unroll
+    for (int j = 0; j < PH_PT; ++j) xyz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hit_xyz) {
+        if (xs.points) {
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j)
+                if (rowany[j]) xyz[j] = xs.points[(size_t)p0 + cb + 4 * lane + j];
+        } else {
+            const int32_t *srow = ft + FT_SROW;
+            int sw_lo = 0, sw_hi = 0;
+            if (ns > 1) { sw_lo = ph_sweep_of(srow, ns, cb); sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1); }
+            const bool uni = sw_lo >= sw_hi;
+            const float *xf_u = xs.sweep_xf + (size_t)(sa + sw_lo) * CM3D_SWEEP_XF_STRIDE;
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) {
+                if (!rowany[j]) continue;
+                const int i = cb + 4 * lane + j;
+                const float *p = xs.raw + ((size_t)p0 + i) * xs.raw_stride;
+                const float x = p[0], y = p[1], z = p[2];
+                float bx, by, bz;
+                if (uni) ph_xform(xf_u, x, y, z, bx, by, bz);
+                else ph_xform(xs.sweep_xf + (size_t)(sa + ph_sweep_of(srow, ns, i)) * CM3D_SWEEP_XF_STRIDE, x, y, z, bx, by, bz);
+                xyz[j] = make_float4(bx, by, bz, p[3]);
+            }
+        }
+    }
+    for (int plane = 0; plane < planes; ++plane) {
+        uint32_t w[PH_PT];
+        if (plane == 0) {
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) w[j] = w0[j];
+        } else {
+            load_words(plane, w);
+        }
+        const uint32_t orw = cm3d_wave_or(w[0] | w[1] | w[2] | w[3]);
+        if (!orw) continue;
+        int run = 0;                         // lane b < 32: output offset of mask bit b for this chunk
+        if (lane < 32) {
+            const int k = plane * 32 + lane;
+            run = plane == 0 ? run_first : (k < nm ? base_row[k] : 0);
+        }
         for (uint32_t r = orw; r; r &= r - 1) {
             const int b = __builtin_ctz(r);
-            int c = 0;
+            uint64_t mk[PH_PT];
+            int lower = 0;
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) c += __popcll(__ballot((w[j] >> b) & 1u));
-            if (lane == b) mycnt = c;
-        }
-        __syncthreads();               // previous plane's readers are done with s_c
-        if (lane < 32) s_c[wave][lane] = mycnt;
-        __syncthreads();
-        if (orw) {
-            // lane b < 32: running output position of mask bit b, starting at this wave's first point
-            int run = 0;
-            if (lane < 32) {
-                const int k = plane * 32 + lane;
-                run = plane == 0 ? run_first : (k < nm ? blk_base[((size_t)f * nblk_max + chunk) * nm_cap + k] : 0);
-                for (int w2 = 0; w2 < wave; ++w2) run += s_c[w2][lane];
-            }
-            for (uint32_t r = orw; r; r &= r - 1) {
-                const int b = __builtin_ctz(r);
+            for (int j = 0; j < PH_PT; ++j) { mk[j] = __ballot((w[j] >> b) & 1u); lower += cm3d_mbcnt(mk[j]); }
+            const int basepos = __builtin_amdgcn_readlane(run, b);
+            int own = 0;
 #pragma unroll
-                for (int j = 0; j < PH_PT; ++j) {
-                    const bool mine = (w[j] >> b) & 1u;
-                    const uint64_t mk = __ballot(mine);
-                    const int basepos = __builtin_amdgcn_readlane(run, b);
-                    if (mine) {
-                        const int pos = basepos + cm3d_mbcnt(mk);
-                        if (pos >= 0 && pos < idx_cap) {
-                            int dropped = 0;
-                            if (n_rm > 0) {
-                                const int loc = idx[j] - base;
-                                dropped = s_rm_before + s_rm_pre[loc >> 5] +
-                                          __popc(s_rm[loc >> 5] & ((1u << (loc & 31)) - 1u));
-                            }
-                            hit_idx[pos] = idx[j] - dropped;
-                            hit_row[pos] = idx[j];
-                        }
+            for (int j = 0; j < PH_PT; ++j) {
+                if ((w[j] >> b) & 1u) {
+                    const int pos = basepos + lower + own;
+                    ++own;
+                    if (pos >= 0 && pos < idx_cap) {
+                        const int i = cb + 4 * lane + j;
+                        hit_idx[pos] = i - dropped[j];
+                        if (hit_row) hit_row[pos] = i;
+                        if (hit_xyz) hit_xyz[pos] = xyz[j];
                     }
-                    if (lane == b) run += __popcll(mk);
                 }
             }
         }
@@ -760,36 +953,54 @@ extern "C" int cm3d_selftest_div(uint64_t seed, uint64_t count, uint64_t *n_bad,
 }
 
 __global__ void k_batch_begin(int32_t *__restrict__ status, int32_t *__restrict__ hit_count, int n_masks,
-                              int32_t *__restrict__ removed_cnt, int n_frames)
+                              uint32_t *__restrict__ removed_bits, long long removed_words)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < CM3D_STATUS_WORDS) status[i] = 0;
-    if (i < n_masks) hit_count[i] = 0;
-    if (removed_cnt && i < n_frames) removed_cnt[i] = 0;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+    if (i0 < CM3D_STATUS_WORDS) status[i0] = 0;
+    for (long long i = i0; i < n_masks; i += step) hit_count[i] = 0;
+    for (long long i = i0; i < removed_words; i += step) removed_bits[i] = 0u;
 }
 
-extern "C" int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, int32_t *removed_cnt, int32_t n_frames,
+extern "C" int64_t cm3d_removed_words(int32_t n_rows, int32_t n_frames)
+{
+    if (n_rows < 0 || n_frames <= 0) return 0;
+    return ((int64_t)n_rows >> 5) + 8 * (int64_t)n_frames + 8;
+}
+
+extern "C" int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, uint32_t *removed_bits, int64_t removed_words,
                                 cm3d_stream_t stream)
 {
-    if (!status || !hit_count || n_masks <= 0 || (removed_cnt && n_frames <= 0)) return CM3D_ERR_ARG;
-    const int n = n_masks > n_frames ? n_masks : n_frames;
-    hipLaunchKernelGGL(k_batch_begin, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, status, hit_count, n_masks, removed_cnt,
-                       removed_cnt ? n_frames : 0);
+    if (!status || !hit_count || n_masks <= 0 || (removed_bits && removed_words <= 0)) return CM3D_ERR_ARG;
+    const long long n = removed_bits && removed_words > n_masks ? removed_words : n_masks;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_batch_begin, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, status, hit_count, n_masks, removed_bits,
+                       removed_bits ? (long long)removed_words : 0ll);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
-}
-
-static inline int ph_nm_cap(int planes)
-{
-    int c = planes * 32;
-    return c > CM3D_MAX_MASKS_PER_FRAME ? CM3D_MAX_MASKS_PER_FRAME : c;
 }
 
 extern "C" int64_t cm3d_project_workspace_bytes(int32_t n_frames, int32_t max_pts_per_frame, int32_t planes)
 {
     if (n_frames <= 0 || max_pts_per_frame <= 0 || planes <= 0) return 0;
-    const int64_t nblk_max = (max_pts_per_frame + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
-    return (int64_t)n_frames * nblk_max * ph_nm_cap(planes) * (int64_t)sizeof(int32_t);
+    return ph_ws_layout(n_frames, max_pts_per_frame, planes, nullptr, nullptr);
+}
+
+// workgroups the projection launch aims at: every CU filled once with resident workgroups (no second round with a
+// partly filled chip), each wave walking a contiguous run of wave-chunks
+static int ph_target_blocks()
+{
+    static int target = 0;
+    if (!target) {
+        if (const char *e = getenv("CM3D_PH_BLOCKS")) target = atoi(e);
+        if (target <= 0) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
+            target = cus * 5;
+        }
+    }
+    return target;
 }
 
 static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
@@ -802,46 +1013,53 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
     if (n_frames <= 0 || max_pts_per_frame <= 0 || n_points_total <= 0 || n_cams <= 0 || n_cams > CM3D_MAX_CAMS ||
         n_masks <= 0 || W <= 1 || H <= 1 || W > 32767 || H > 32767 || planes <= 0)
         return CM3D_ERR_ARG;
-    if (workspace_bytes < cm3d_project_workspace_bytes(n_frames, max_pts_per_frame, planes)) return CM3D_ERR_WORKSPACE;
+    if (workspace_bytes < cm3d_project_workspace_bytes(n_frames, max_pts_per_frame, planes) || ((uintptr_t)workspace & 15)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    PhWs ws;
+    ph_ws_layout(n_frames, max_pts_per_frame, planes, workspace, &ws);
     const int Wp = (W + 31) / 32;
-    const int nblk_max = (max_pts_per_frame + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
+    const int nwc_max = (max_pts_per_frame + PH_WC - 1) / PH_WC;
     const int nm_cap = ph_nm_cap(planes);
-    // enough blocks to fill the chip (256 CUs x 6 resident), each walking a few chunks of its frame so that the
-    // per-block table staging is amortised (measured on C2: 2304 -> 81 us, 4608 -> 83 us, 1536 -> 89 us)
-    int gx = nblk_max;
-    static long long max_blocks = 0;             // beyond that blocks walk several chunks
-    if (!max_blocks) { const char *e = getenv("CM3D_PH_MAXBLK"); max_blocks = e ? atoll(e) : 2304; }
-    if ((long long)gx * n_frames > max_blocks) gx = (int)((max_blocks + n_frames - 1) / n_frames);
-    if (gx > nblk_max) gx = nblk_max;
-    if (gx < 1) gx = 1;
     const int planes_cap = (nm_cap + 31) / 32;
-    {   // the per-chunk count rows of a block live in LDS: at most 16 KiB of them (with 1024 masks per frame the
-        // per-thread hit words already take 128 KiB of the 160)
-        const int max_cpb = 4096 / nm_cap > 1 ? 4096 / nm_cap : 1;
-        const int gx_min = (nblk_max + max_cpb - 1) / max_cpb;
-        if (gx < gx_min) gx = gx_min;
-    }
-    const int chunks_per_block = (nblk_max + gx - 1) / gx;
-    size_t lds = (size_t)CM3D_MAX_CAMS * planes_cap * sizeof(uint32_t) + (size_t)chunks_per_block * nm_cap * sizeof(int);
     PhSweepIn none = {};
     const PhSweepIn sw = fused ? *fused : none;
-#define PH_LAUNCH(ONE, FUSED)                                                                                                    \
-    hipLaunchKernelGGL((k_project_hits<ONE, FUSED>), dim3(gx, n_frames), dim3(PH_THREADS), lds, st, (const float4 *)points, pt_off, \
-                       sw, n_points_total, cams, n_cams, mask_off, mask_cam, (const int4 *)bbox, packed, W, H, Wp, min_dist,     \
-                       nm_cap, nblk_max, chunks_per_block, hit_words, hit_count, (int32_t *)workspace, status)
+    hipLaunchKernelGGL(k_frame_tables, dim3(n_frames), dim3(64), 0, st, sw, fused ? 1 : 0, pt_off, n_frames, cams, n_cams, mask_off, mask_cam,
+                       (const int4 *)bbox, W, H, min_dist, nm_cap, max_pts_per_frame, ws.ft, ws.ment, status);
+    CM3D_CHECK_LAUNCH();
+    int gx = (ph_target_blocks() + n_frames - 1) / n_frames;
+    const int gx_max = (nwc_max + PH_WAVES - 1) / PH_WAVES;          // at least one wave-chunk per wave
+    if (gx > gx_max) gx = gx_max;
+    if (gx < 1) gx = 1;
+    size_t lds = 0;
+    const float *src = fused ? sw.raw : points;
+    const int stride = fused ? sw.raw_stride : 4;
+#define PH_LAUNCH(ONE, FUSED, STRIDE)                                                                                            \
+    hipLaunchKernelGGL((k_project_hits<ONE, FUSED, STRIDE>), dim3(gx, n_frames), dim3(PH_THREADS), lds, st, src, stride, sw.sweep_xf, \
+                       sw.halfw, sw.points_out, sw.removed_bits, ws.ft, ws.ment, cams, n_cams, packed, W, H, Wp, min_dist, nm_cap, \
+                       nwc_max, n_points_total, hit_words, hit_count, ws.wc_cnt)
+#define PH_LAUNCH_S(ONE)                                                                                                         \
+    do {                                                                                                                         \
+        if (!fused) PH_LAUNCH(ONE, false, 4);                                                                                    \
+        else if (stride == 5) PH_LAUNCH(ONE, true, 5);                                                                           \
+        else if (stride == 4) PH_LAUNCH(ONE, true, 4);                                                                           \
+        else PH_LAUNCH(ONE, true, 0);                                                                                            \
+    } while (0)
     if (planes_cap == 1) {
-        if (fused) PH_LAUNCH(true, true); else PH_LAUNCH(true, false);
+        PH_LAUNCH_S(true);
     } else {
-        lds += (size_t)planes_cap * PH_BLOCK_PTS * sizeof(uint32_t);
-        static size_t lds_allowed[2] = {48 * 1024, 48 * 1024};
-        if (lds > lds_allowed[fused ? 1 : 0]) {
-            const void *fn = fused ? (const void *)k_project_hits<false, true> : (const void *)k_project_hits<false, false>;
+        lds = (size_t)PH_WAVES * ((size_t)planes_cap * PH_WC * sizeof(uint32_t) + (size_t)nm_cap * sizeof(int));
+        static size_t lds_allowed[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+        const int which = !fused ? 0 : (stride == 5 ? 1 : (stride == 4 ? 2 : 3));
+        if (lds > lds_allowed[which]) {
+            const void *fn = which == 0 ? (const void *)k_project_hits<false, false, 4>
+                             : which == 1 ? (const void *)k_project_hits<false, true, 5>
+                             : which == 2 ? (const void *)k_project_hits<false, true, 4> : (const void *)k_project_hits<false, true, 0>;
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CM3D_ERR_LAUNCH;
-            lds_allowed[fused ? 1 : 0] = lds;
+            lds_allowed[which] = lds;
         }
-        if (fused) PH_LAUNCH(false, true); else PH_LAUNCH(false, false);
+        PH_LAUNCH_S(false);
     }
+#undef PH_LAUNCH_S
 #undef PH_LAUNCH
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
@@ -861,49 +1079,52 @@ extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int
 
 extern "C" int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
                                        int32_t max_sweeps_per_frame, const float *sweep_xf, const int32_t *frame_sweep_off,
-                                       float halfw, float *points, int32_t pt_cap, int32_t *pt_off, int32_t *removed_cnt,
-                                       int32_t *removed_idx, int32_t n_frames, int32_t max_pts_per_frame, int32_t n_points_total,
+                                       float halfw, float *points, int32_t pt_cap, int32_t *pt_off, uint32_t *removed_bits,
+                                       int32_t n_frames, int32_t max_pts_per_frame, int32_t n_points_total,
                                        const float *cams, int32_t n_cams, const int32_t *mask_off, const int32_t *mask_cam,
                                        const int32_t *bbox, const uint32_t *packed, int32_t n_masks, int32_t W, int32_t H,
                                        float min_dist, int32_t planes, uint32_t *hit_words, int32_t *hit_count, int32_t *status,
                                        void *workspace, int64_t workspace_bytes, cm3d_stream_t stream)
 {
-    if (!raw || !sweep_row_off || !sweep_xf || !frame_sweep_off || !points || !pt_off || !removed_cnt || !removed_idx) return CM3D_ERR_ARG;
+    if (!raw || !sweep_row_off || !sweep_xf || !frame_sweep_off || !pt_off || !removed_bits) return CM3D_ERR_ARG;
     if (raw_stride < 4 || n_sweeps <= 0 || pt_cap <= 0 || ((uintptr_t)points & 15)) return CM3D_ERR_ARG;
     if (max_sweeps_per_frame <= 0 || max_sweeps_per_frame > PH_MAX_SWEEPS) return CM3D_ERR_ARG;
     PhSweepIn sw;
     sw.raw = raw; sw.raw_stride = raw_stride; sw.sweep_row_off = sweep_row_off; sw.sweep_xf = sweep_xf;
     sw.frame_sweep_off = frame_sweep_off; sw.n_frames = n_frames; sw.n_sweeps = n_sweeps; sw.halfw = halfw;
-    sw.points_out = (float4 *)points; sw.pt_cap = pt_cap; sw.pt_off_out = pt_off; sw.removed_cnt = removed_cnt;
-    sw.removed_idx = removed_idx;
-    return ph_launch(&sw, points, pt_off, n_frames, max_pts_per_frame, n_points_total, cams, n_cams, mask_off, mask_cam, bbox, packed,
+    sw.points_out = (float4 *)points; sw.pt_cap = pt_cap; sw.pt_off_out = pt_off; sw.removed_bits = removed_bits;
+    return ph_launch(&sw, nullptr, nullptr, n_frames, max_pts_per_frame, n_points_total, cams, n_cams, mask_off, mask_cam, bbox, packed,
                      n_masks, W, H, min_dist, planes, hit_words, hit_count, status, workspace, workspace_bytes, stream);
 }
 
-extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, const int32_t *pt_off, int32_t n_frames,
-                                 int32_t max_pts_per_frame, int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
-                                 const int32_t *hit_count, const int32_t *removed_cnt, const int32_t *removed_idx,
-                                 int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx, int32_t *hit_row, int32_t idx_cap,
-                                 int32_t *tile_work, int32_t *status, void *workspace, int64_t workspace_bytes,
-                                 cm3d_stream_t stream)
+extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int32_t n_frames, int32_t max_pts_per_frame,
+                                 int32_t n_points_total, const int32_t *mask_off, int32_t n_masks, const int32_t *hit_count,
+                                 const uint32_t *removed_bits, const float *raw, int32_t raw_stride, const float *sweep_xf,
+                                 const float *points, int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx, int32_t *hit_row,
+                                 float *hit_xyz, int32_t idx_cap, int32_t *tile_work, int32_t *status, void *workspace,
+                                 int64_t workspace_bytes, cm3d_stream_t stream)
 {
-    if (!hit_words || !pt_off || !mask_off || !hit_count || !hit_off || !tile_off || !hit_idx || !hit_row || !status || !workspace)
-        return CM3D_ERR_ARG;
-    if ((removed_cnt == nullptr) != (removed_idx == nullptr)) return CM3D_ERR_ARG;
+    if (!hit_words || !mask_off || !hit_count || !hit_off || !tile_off || !hit_idx || !status || !workspace) return CM3D_ERR_ARG;
     if (planes <= 0 || n_frames <= 0 || max_pts_per_frame <= 0 || n_points_total <= 0 || n_masks <= 0 || idx_cap <= 0)
         return CM3D_ERR_ARG;
-    if (workspace_bytes < cm3d_project_workspace_bytes(n_frames, max_pts_per_frame, planes)) return CM3D_ERR_WORKSPACE;
+    if (hit_xyz && !points && !(raw && sweep_xf && raw_stride >= 4)) return CM3D_ERR_ARG;        // nothing to take the coordinates from
+    if (((uintptr_t)hit_xyz & 15) || ((uintptr_t)points & 15)) return CM3D_ERR_ARG;
+    if (workspace_bytes < cm3d_project_workspace_bytes(n_frames, max_pts_per_frame, planes) || ((uintptr_t)workspace & 15)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int nblk_max = (max_pts_per_frame + PH_BLOCK_PTS - 1) / PH_BLOCK_PTS;
+    PhWs ws;
+    ph_ws_layout(n_frames, max_pts_per_frame, planes, workspace, &ws);
+    const int nwc_max = (max_pts_per_frame + PH_WC - 1) / PH_WC;
     const int nm_cap = ph_nm_cap(planes);
-    hipLaunchKernelGGL(k_hit_offsets, dim3(n_frames), dim3(1024), 0, st, hit_count, n_masks, pt_off, mask_off, n_frames, nm_cap,
-                       nblk_max, hit_off, tile_off, (int32_t *)workspace, idx_cap, status);
+    hipLaunchKernelGGL(k_hit_offsets, dim3(n_frames), dim3(1024), 0, st, hit_count, n_masks, ws.ft, mask_off, n_frames, nm_cap, nwc_max,
+                       hit_off, tile_off, ws.wc_cnt, ws.wc_drop, removed_bits, idx_cap, status);
     CM3D_CHECK_LAUNCH();
     const int64_t tile_cap64 = md_tile_cap(n_masks, idx_cap);
     const int tile_cap = (int)(tile_cap64 > 0x7FFFFFFF ? 0x7FFFFFFF : tile_cap64);
-    hipLaunchKernelGGL(k_compact_hits, dim3(nblk_max, n_frames + (tile_work ? 1 : 0)), dim3(PH_THREADS), 0, st, hit_words,
-                       n_points_total, pt_off, mask_off, nm_cap, nblk_max, (const int32_t *)workspace, removed_cnt, removed_idx, hit_idx,
-                       hit_row, idx_cap, n_frames, n_masks, hit_off, tile_off, tile_cap, (TileDesc *)tile_work);
+    PhXyzSrc xs;
+    xs.raw = raw; xs.raw_stride = raw_stride; xs.sweep_xf = sweep_xf; xs.points = (const float4 *)points;
+    hipLaunchKernelGGL(k_compact_hits, dim3((nwc_max + PH_WAVES - 1) / PH_WAVES, n_frames + (tile_work ? 1 : 0)), dim3(PH_THREADS), 0, st,
+                       hit_words, n_points_total, ws.ft, nm_cap, nwc_max, ws.wc_cnt, ws.wc_drop, removed_bits, xs, hit_idx, hit_row,
+                       (float4 *)hit_xyz, idx_cap, n_frames, n_masks, hit_off, tile_off, tile_cap, (TileDesc *)tile_work);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

@@ -3,9 +3,10 @@
 // ONE streaming pass (HBM-bound): every raw row is transformed sensor -> ego -> global and written at
 // its own row index.  Rows inside the ego box (|x| < halfw && |y| < halfw, :442-445) are not compacted
 // away here -- that would need a counting pass over the whole batch first.  They are written as NaN
-// points (inert in every later test) and their frame-local row indices are appended to the frame's
-// removed list (unordered); k_compact_hits subtracts "removed rows before me" when it emits a point index, so the
-// index lists are exactly the indices into the reference's compacted cloud.
+// points (inert in every later test) and marked in the frame's removed-row bits (one bit per row, zeroed by
+// cm3d_batch_begin; sweeps of a frame may share a word, hence atomicOr -- 0.2 % of the rows); k_compact_hits subtracts
+// "removed rows before me" when it emits a point index, so the index lists are exactly the indices into the
+// reference's compacted cloud.
 // Algorithmic bytes: 4*raw_stride per raw row read + 16 per row written.
 #include "common.h"
 
@@ -20,15 +21,13 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_xform(const float *__restr
                                                              const float *__restrict__ sweep_xf,
                                                              const int32_t *__restrict__ frame_sweep_off, int n_frames,
                                                              int n_sweeps, float halfw, float4 *__restrict__ points, int pt_cap,
-                                                             int32_t *__restrict__ pt_off, int32_t *__restrict__ removed_cnt,
-                                                             int32_t *__restrict__ removed_idx, int32_t *__restrict__ status)
+                                                             int32_t *__restrict__ pt_off, uint32_t *__restrict__ removed_bits,
+                                                             int32_t *__restrict__ status)
 {
     __shared__ float s_xf[CM3D_SWEEP_XF_STRIDE];
     __shared__ int s_f, s_frow0;
-    __shared__ int s_ndrop, s_dropbase;
-    __shared__ int s_drop[SW_ROWS];                // dropped rows of this workgroup (frame-local row indices)
     const int s = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
-    if (t == 0) { s_f = -1; s_ndrop = 0; }
+    if (t == 0) s_f = -1;
     __syncthreads();
     const int r0 = sweep_row_off[s], n = sweep_row_off[s + 1] - r0;
     const int total_rows = sweep_row_off[n_sweeps];
@@ -59,6 +58,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_xform(const float *__restr
     }
     const float *src = raw + (size_t)row_base * raw_stride;
     const float qnan = __int_as_float(0x7FC00000);
+    uint32_t *bits = removed_bits + ((size_t)(frame_row0 >> 5) + 8 * (size_t)f);      // the frame's bits (see cm3d_hip.h)
 #pragma unroll
     for (int k = 0; k < SW_ROWS / SW_THREADS; ++k) {
         const int i = k * SW_THREADS + t;
@@ -71,15 +71,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_xform(const float *__restr
         }
         const int g = row_base + i;
         const bool drop = live && fabsf(x) < halfw && fabsf(y) < halfw;      // reference drops this row (2d_to_3d.py:442-445)
-        const uint64_t dm = __ballot(drop);
-        if (dm) {                                                            // collected in LDS, one LDS atomic per wave
-            int pos0 = 0;
-            if (cm3d_lane() == 0) pos0 = atomicAdd(&s_ndrop, (int)__popcll(dm));
-            pos0 = __builtin_amdgcn_readfirstlane(pos0);
-            if (drop) {
-                s_drop[pos0 + cm3d_mbcnt(dm)] = g - frame_row0;
-                points[g] = make_float4(qnan, qnan, qnan, w);
-            }
+        if (drop) {
+            const int r = g - frame_row0;
+            atomicOr(&bits[r >> 5], 1u << (r & 31));
+            points[g] = make_float4(qnan, qnan, qnan, w);
         }
         if (live && !drop) {
             // sensor -> ego (rotate then translate), ego -> global (2d_to_3d.py:450-457)
@@ -92,31 +87,21 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_xform(const float *__restr
             points[g] = make_float4(bx, by, bz, w);
         }
     }
-    // The workgroup's dropped rows join the frame's list with ONE global atomic.  (A returning atomic per wave on the
-    // frame's counter serialises at memory -- per-XCD L2s are not coherent -- and made a 4-sweeps-per-frame batch
-    // take 134 us instead of 57.)  Nothing waits for it but this workgroup's own tail.
-    __syncthreads();
-    const int nd = s_ndrop;
-    if (nd == 0) return;
-    if (t == 0) s_dropbase = atomicAdd(&removed_cnt[f], nd);
-    __syncthreads();
-    const int dbase = frame_row0 + s_dropbase;     // at most (rows of the frame) entries in the frame's list
-    for (int i = t; i < nd; i += SW_THREADS) removed_idx[dbase + i] = s_drop[i];
 }
 
 extern "C" int cm3d_sweep_prep(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
                                int32_t max_rows_per_sweep, const float *sweep_xf, const int32_t *frame_sweep_off,
                                int32_t n_frames, float halfw, float *points, int32_t pt_cap, int32_t *pt_off,
-                               int32_t *removed_cnt, int32_t *removed_idx, int32_t *status, cm3d_stream_t stream)
+                               uint32_t *removed_bits, int32_t *status, cm3d_stream_t stream)
 {
-    if (!raw || !sweep_row_off || !sweep_xf || !frame_sweep_off || !points || !pt_off || !removed_cnt || !removed_idx || !status)
+    if (!raw || !sweep_row_off || !sweep_xf || !frame_sweep_off || !points || !pt_off || !removed_bits || !status)
         return CM3D_ERR_ARG;
     if (raw_stride < 4 || n_sweeps <= 0 || n_frames <= 0 || max_rows_per_sweep <= 0 || pt_cap <= 0) return CM3D_ERR_ARG;
     if ((uintptr_t)points & 15) return CM3D_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sweep_xform, dim3((max_rows_per_sweep + SW_ROWS - 1) / SW_ROWS, n_sweeps), dim3(SW_THREADS), 0, st, raw,
                        raw_stride, sweep_row_off, sweep_xf, frame_sweep_off, n_frames, n_sweeps, halfw, (float4 *)points, pt_cap,
-                       pt_off, removed_cnt, removed_idx, status);
+                       pt_off, removed_bits, status);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

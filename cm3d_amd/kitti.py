@@ -131,12 +131,11 @@ def labels_of_frame(hb, res, f, classes, shape_priors):
     """Label lines (pred with score, pseudo without) of frame f from the device results (:1479-1536)."""
     from .lifting import get_detection_name
     pred, pseudo = [], []
-    p0 = res["pt_off"][f]
     for m in range(hb.mask_off[f], hb.mask_off[f + 1]):
         o, e = res["hit_off"][m], res["hit_off"][m + 1]
         if e - o <= 3:                                   # :1479-1480
             continue
-        pts = res["points"][p0 + res["hit_idx"][o:e], :3]
+        pts = res["hit_xyz"][o:e, :3]                    # the in-mask points (:1479), laid out like hit_idx
         try:
             yaw = obb_yaw(pts)
         except Exception:                                # :1481-1484: bare except -> identity box

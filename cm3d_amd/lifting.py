@@ -214,7 +214,10 @@ class LiftEngine:
     All launches go to torch's current HIP stream and never synchronise."""
 
     def __init__(self, device="cuda:0", classes: Optional[ClassTable] = None, min_dist=MIN_DIST,
-                 hits_per_point=4.0, keep_colsum=False):
+                 hits_per_point=4.0, keep_colsum=False, keep_cloud=None):
+        """keep_cloud: also materialise the transformed cloud (`points`, the reference's aggregated `pc`).  The path
+        itself does not need it -- the in-mask points are re-derived from the raw rows (hit_xyz) -- so the default is
+        off (CM3D_KEEP_CLOUD=1 turns it on); tests and callers that want the cloud back ask for it."""
         self.lib = _lib.lib()                      # raises when the extension is not built
         if not torch.cuda.is_available():
             raise Cm3dError("no HIP device: the lifting path only runs on the GPU (no CPU fallback)")
@@ -224,13 +227,11 @@ class LiftEngine:
         self.halfw = float(np.float32(np.sqrt(min_dist)))       # :443-444
         self.hits_per_point = hits_per_point
         self.keep_colsum = keep_colsum
+        self.keep_cloud = (os.environ.get("CM3D_KEEP_CLOUD", "0") == "1") if keep_cloud is None else bool(keep_cloud)
         self.b = None
         d = self.dev
         self.side = torch.cuda.Stream(device=d)              # lane-grid build overlaps the point/mask stages
         self.grid_done = torch.cuda.Event()
-        self.mask_stream = torch.cuda.Stream(device=d)       # mask expansion/erosion overlaps the sweep preparation
-        self.masks_done = torch.cuda.Event()
-        self.overlap_masks = os.environ.get("CM3D_OVERLAP_MASKS", "0") == "1"
         self.fused_sweeps = os.environ.get("CM3D_FUSED_SWEEPS", "1") == "1"    # 0: separate sweep and projection launches
         self.prior_wlh = torch.from_numpy(self.classes.prior_wlh).to(d)
         self.is_vehicle = torch.from_numpy(self.classes.is_vehicle).to(d)
@@ -264,19 +265,22 @@ class LiftEngine:
         b.lane = t(hb.lane); b.lane_off = t(hb.lane_off); b.frame_lane = t(hb.frame_lane); b.ego_xyz = t(hb.ego_xyz)
         b.pt_cap = hb.n_raw_rows
         b.max_pts = int(max(hb.sweep_row_off[hb.frame_sweep_off[1:]] - hb.sweep_row_off[hb.frame_sweep_off[:-1]]))
-        b.max_sweeps = int(np.max(np.diff(hb.frame_sweep_off))) if hb.frame_sweep_off.size > 1 else 0
         b.planes = (nm_max + 31) // 32
         b.idx_cap = int(max(1024, self.hits_per_point * b.pt_cap))
         e = lambda *shape, dtype=torch.int32: torch.empty(*shape, dtype=dtype, device=d)
-        b.points = e(b.pt_cap, 4, dtype=torch.float32)
+        # the transformed cloud exists only on request, or when the sweeps cannot be fused into the projection launch
+        b.max_sweeps = int(np.max(np.diff(hb.frame_sweep_off))) if hb.frame_sweep_off.size > 1 else 0
+        b.fused = self.fused_sweeps and 0 < b.max_sweeps <= _lib.MAX_FUSED_SWEEPS
+        b.points = e(b.pt_cap, 4, dtype=torch.float32) if (self.keep_cloud or not b.fused) else None
         b.pt_off = e(F + 1)
         b.status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=d)
         b.packed = e(M, H, Wp)
         b.bbox = e(M, 4)
         b.hit_words = e(b.planes, b.pt_cap)
         b.hit_count = e(M); b.hit_off = e(M + 1); b.tile_off = e(M + 1)
-        b.hit_idx = e(b.idx_cap); b.hit_row = e(b.idx_cap)
-        b.removed_cnt = e(F); b.removed_idx = e(b.pt_cap)
+        b.hit_idx = e(b.idx_cap); b.hit_xyz = e(b.idx_cap, 4, dtype=torch.float32)
+        b.removed_words = int(self.lib.cm3d_removed_words(b.pt_cap, F))
+        b.removed_bits = e(b.removed_words)
         b.medoid_pos = e(M); b.centroid = e(M, 3, dtype=torch.float32)
         b.centroid_g = e(M, 3, dtype=torch.float32) if hb.pose_rt is not None else b.centroid
         b.colsum = e(b.idx_cap, dtype=torch.float32) if self.keep_colsum else None
@@ -316,7 +320,8 @@ class LiftEngine:
     def stage_begin(self, st):
         """Resets the per-pass state and starts the lane-grid build on the side stream."""
         b = self.b
-        check(self.lib.cm3d_batch_begin(_ptr(b.status), _ptr(b.hit_count), b.M, _ptr(b.removed_cnt), b.F, st), "cm3d_batch_begin")
+        check(self.lib.cm3d_batch_begin(_ptr(b.status), _ptr(b.hit_count), b.M, _ptr(b.removed_bits), b.removed_words, st),
+              "cm3d_batch_begin")
         main = torch.cuda.current_stream(self.dev)
         self.side.wait_stream(main)          # the previous pass's lane queries have been issued before this point
         with torch.cuda.stream(self.side):
@@ -326,25 +331,11 @@ class LiftEngine:
     def wait_lane_grid(self):
         torch.cuda.current_stream(self.dev).wait_event(self.grid_done)
 
-    def stage_masks_async(self, masks="dense"):
-        """Mask expansion + erosion on the mask stream (optional, CM3D_OVERLAP_MASKS=1 makes `run` use it).
-        Measured on MI355X, also with a high-priority mask stream: the pass takes the same time (0.3207 vs
-        0.3211 ms) -- the HBM-bound sweep kernel fills every CU, so the two launches do not overlap usefully --
-        and `run` keeps the stages serial."""
-        main = torch.cuda.current_stream(self.dev)
-        self.mask_stream.wait_stream(main)       # after batch_begin and after the previous pass's readers of `packed`
-        with torch.cuda.stream(self.mask_stream):
-            self.stage_masks(self.mask_stream.cuda_stream, masks)
-            self.masks_done.record(self.mask_stream)
-
-    def wait_masks(self):
-        torch.cuda.current_stream(self.dev).wait_event(self.masks_done)
-
     def stage_sweeps(self, st):
         b = self.b
         check(self.lib.cm3d_sweep_prep(_ptr(b.raw), b.hb.raw_stride, _ptr(b.sweep_row_off), b.S, b.hb.max_rows_per_sweep,
                                        _ptr(b.sweep_xf), _ptr(b.frame_sweep_off), b.F, b.halfw, _ptr(b.points), b.pt_cap,
-                                       _ptr(b.pt_off), _ptr(b.removed_cnt), _ptr(b.removed_idx), _ptr(b.status), st), "cm3d_sweep_prep")
+                                       _ptr(b.pt_off), _ptr(b.removed_bits), _ptr(b.status), st), "cm3d_sweep_prep")
 
     def stage_masks(self, st, masks="dense"):
         b = self.b
@@ -367,7 +358,7 @@ class LiftEngine:
                                          _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_project_hits")
 
     def can_fuse_sweeps(self):
-        return self.fused_sweeps and 0 < self.b.max_sweeps <= _lib.MAX_FUSED_SWEEPS
+        return self.b.fused
 
     def stage_sweep_project(self, st):
         """Sweep preparation folded into the projection kernel (cm3d_sweep_project_hits): same outputs as
@@ -375,24 +366,25 @@ class LiftEngine:
         b = self.b
         check(self.lib.cm3d_sweep_project_hits(_ptr(b.raw), b.hb.raw_stride, _ptr(b.sweep_row_off), b.S, b.max_sweeps, _ptr(b.sweep_xf),
                                                _ptr(b.frame_sweep_off), b.halfw, _ptr(b.points), b.pt_cap, _ptr(b.pt_off),
-                                               _ptr(b.removed_cnt), _ptr(b.removed_idx), b.F, b.max_pts, b.pt_cap, _ptr(b.cams),
+                                               _ptr(b.removed_bits), b.F, b.max_pts, b.pt_cap, _ptr(b.cams),
                                                b.hb.n_cams, _ptr(b.mask_off), _ptr(b.mask_cam), _ptr(b.bbox), _ptr(b.packed), b.M, b.W,
                                                b.H, self.min_dist, b.planes, _ptr(b.hit_words), _ptr(b.hit_count), _ptr(b.status),
                                                _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_sweep_project_hits")
 
     def stage_compact(self, st):
         b = self.b
-        check(self.lib.cm3d_compact_hits(_ptr(b.hit_words), b.planes, _ptr(b.pt_off), b.F, b.max_pts, b.pt_cap, _ptr(b.mask_off),
-                                         b.M, _ptr(b.hit_count), _ptr(b.removed_cnt), _ptr(b.removed_idx), _ptr(b.hit_off),
-                                         _ptr(b.tile_off), _ptr(b.hit_idx), _ptr(b.hit_row), b.idx_cap, _ptr(b.tile_work), _ptr(b.status),
-                                         _ptr(b.pg_ws),
-                                         b.pg_ws_bytes, st), "cm3d_compact_hits")
+        # coordinates of the in-mask points: from the cloud when it exists, else re-derived from the raw rows
+        from_raw = b.points is None
+        check(self.lib.cm3d_compact_hits(_ptr(b.hit_words), b.planes, b.F, b.max_pts, b.pt_cap, _ptr(b.mask_off), b.M, _ptr(b.hit_count),
+                                         _ptr(b.removed_bits), _ptr(b.raw) if from_raw else 0, b.hb.raw_stride,
+                                         _ptr(b.sweep_xf) if from_raw else 0, _ptr(b.points), _ptr(b.hit_off), _ptr(b.tile_off),
+                                         _ptr(b.hit_idx), 0, _ptr(b.hit_xyz), b.idx_cap, _ptr(b.tile_work), _ptr(b.status),
+                                         _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_compact_hits")
 
     def stage_medoid(self, st):
         b = self.b
-        check(self.lib.cm3d_medoid(_ptr(b.points), _ptr(b.pt_off), _ptr(b.mask_frame), b.M, _ptr(b.hit_off), _ptr(b.tile_off),
-                                   _ptr(b.hit_row), b.idx_cap, _ptr(b.tile_work), _ptr(b.medoid_pos), _ptr(b.centroid), _ptr(b.colsum),
-                                   _ptr(b.ws), b.ws_bytes, st), "cm3d_medoid")
+        check(self.lib.cm3d_medoid(_ptr(b.hit_xyz), 0, 0, b.M, _ptr(b.hit_off), _ptr(b.tile_off), 0, b.idx_cap, _ptr(b.tile_work),
+                                   _ptr(b.medoid_pos), _ptr(b.centroid), _ptr(b.colsum), _ptr(b.ws), b.ws_bytes, st), "cm3d_medoid")
 
     def stage_lane_grid(self, st):
         """Spatial index of the lane tables.  It depends on the lane tables only, so `run` issues it on
@@ -425,18 +417,12 @@ class LiftEngine:
         torch.cuda.Event recorded around the projection launch on the launch stream (bench.py's roofline timing)."""
         st = torch.cuda.current_stream(self.dev).cuda_stream
         self.stage_begin(st)
-        if self.overlap_masks:
-            self.stage_masks_async(masks)
+        if not self.can_fuse_sweeps():
             self.stage_sweeps(st)
-            self.wait_masks()
-        elif not self.can_fuse_sweeps():
-            self.stage_sweeps(st)
-            self.stage_masks(st, masks)
-        else:
-            self.stage_masks(st, masks)
+        self.stage_masks(st, masks)
         if project_events is not None:
             project_events[0].record()
-        if self.overlap_masks or not self.can_fuse_sweeps():
+        if not self.can_fuse_sweeps():
             self.stage_project(st)
         else:
             self.stage_sweep_project(st)
@@ -472,11 +458,28 @@ class LiftEngine:
             raise Cm3dError("a frame has too many masks or a cam_num is out of range")
         return s
 
+    def removed_rows(self):
+        """Boolean array over the batch's raw rows: True where the reference drops the row (ego box, :442-445).
+        Decoded from the device's removed-row bits (frame f's bits start at word (pt_off[f] >> 5) + 8 f)."""
+        b = self.b
+        words = b.removed_bits.cpu().numpy().view(np.uint32)
+        p_off = b.pt_off.cpu().numpy()
+        out = np.zeros(int(p_off[-1]), bool)
+        for f in range(b.F):
+            p0, n = int(p_off[f]), int(p_off[f + 1] - p_off[f])
+            if n <= 0:
+                continue
+            w0 = (p0 >> 5) + 8 * f
+            bits = np.unpackbits(words[w0:w0 + (n + 31) // 32].view(np.uint8), bitorder="little")[:n]
+            out[p0:p0 + n] = bits.astype(bool)
+        return out
+
     def download(self, full=True):
-        """Synchronises, checks the status word and returns numpy results.  `points` / `pt_off` are returned in
-        the reference's form (the aggregated cloud without the ego-box rows, :445-465); on the device the cloud
-        keeps those rows as NaN placeholders (see cm3d_sweep_prep).  full=False: only the per-mask results (boxes, flags,
-        medoids, lane matches, list offsets) -- a few hundred KB instead of the cloud and the index lists."""
+        """Synchronises, checks the status word and returns numpy results.  full=False: only the per-mask results
+        (boxes, flags, medoids, lane matches, list offsets) -- a few hundred KB.  full=True adds the index lists
+        (`hit_idx`, the reference's track_points), the coordinates of the listed points (`hit_xyz`), `pt_off` in the
+        reference's form (the aggregated cloud without the ego-box rows, :445-465) and -- when the engine keeps the cloud
+        (keep_cloud) -- `points` in that form too; on the device the cloud keeps the dropped rows as NaN placeholders."""
         b = self.b
         s = self.check_status()
         if not full:
@@ -485,21 +488,17 @@ class LiftEngine:
                         centroid_global=b.centroid_g.cpu().numpy(), box=b.box.cpu().numpy(), flags=b.flags.cpu().numpy())
         n_rows, n_idx = int(s[1]), int(s[2])
         pt_off_rows = b.pt_off.cpu().numpy()
-        pts_rows = b.points[:n_rows].cpu().numpy()
-        rm_cnt = b.removed_cnt.cpu().numpy()
-        rm_idx = b.removed_idx[:n_rows].cpu().numpy()
-        keep = np.ones(n_rows, bool)
-        for f in range(b.F):
-            if rm_cnt[f]:
-                keep[pt_off_rows[f] + rm_idx[pt_off_rows[f]:pt_off_rows[f] + rm_cnt[f]]] = False
+        keep = ~self.removed_rows()[:n_rows]
         kept_per_frame = np.add.reduceat(keep.astype(np.int64), pt_off_rows[:-1]) if n_rows else np.zeros(b.F, np.int64)
         kept_per_frame = np.where(np.diff(pt_off_rows) > 0, kept_per_frame, 0)
         out = dict(
-            pt_off=np.concatenate([[0], np.cumsum(kept_per_frame)]).astype(np.int32), points=pts_rows[keep],
-            hit_off=b.hit_off.cpu().numpy(), hit_idx=b.hit_idx[:n_idx].cpu().numpy(),
+            pt_off=np.concatenate([[0], np.cumsum(kept_per_frame)]).astype(np.int32),
+            hit_off=b.hit_off.cpu().numpy(), hit_idx=b.hit_idx[:n_idx].cpu().numpy(), hit_xyz=b.hit_xyz[:n_idx].cpu().numpy(),
             bbox=b.bbox.cpu().numpy(), medoid_pos=b.medoid_pos.cpu().numpy(), centroid=b.centroid.cpu().numpy(),
             lane_idx=b.lane_idx.cpu().numpy(), lane_dist=b.lane_dist.cpu().numpy(), centroid_global=b.centroid_g.cpu().numpy(),
             box=b.box.cpu().numpy(), flags=b.flags.cpu().numpy())
+        if b.points is not None:
+            out["points"] = b.points[:n_rows].cpu().numpy()[keep]
         if b.colsum is not None:
             out["colsum"] = b.colsum[:n_idx].cpu().numpy()
         return out

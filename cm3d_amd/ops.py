@@ -107,7 +107,7 @@ def points_in_masks(points, cams, packed, bbox, cam_nums, W, H, min_dist=2.3):
     status = _e(_lib.STATUS_WORDS)
     hit_off, tile_off = _e(n + 1), _e(n + 1)
     cap = max(1024, N * 8)
-    hit_idx, hit_row = _e(cap), _e(cap)
+    hit_idx = _e(cap)
     st = _st()
     ws = _ws(L.cm3d_project_workspace_bytes(1, N, planes))
     check(L.cm3d_batch_begin(status.data_ptr(), hit_count.data_ptr(), n, 0, 0, st), "cm3d_batch_begin")
@@ -115,8 +115,8 @@ def points_in_masks(points, cams, packed, bbox, cam_nums, W, H, min_dist=2.3):
                               mask_cam.data_ptr(), bbox.data_ptr(), packed.data_ptr(), n, W, H, float(np.float32(min_dist)), planes,
                               hit_words.data_ptr(), hit_count.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), st),
           "cm3d_project_hits")
-    check(L.cm3d_compact_hits(hit_words.data_ptr(), planes, pt_off.data_ptr(), 1, N, N, mask_off.data_ptr(), n, hit_count.data_ptr(),
-                              0, 0, hit_off.data_ptr(), tile_off.data_ptr(), hit_idx.data_ptr(), hit_row.data_ptr(), cap, 0,
+    check(L.cm3d_compact_hits(hit_words.data_ptr(), planes, 1, N, N, mask_off.data_ptr(), n, hit_count.data_ptr(), 0, 0, 0, 0,
+                              pts.data_ptr(), hit_off.data_ptr(), tile_off.data_ptr(), hit_idx.data_ptr(), 0, 0, cap, 0,
                               status.data_ptr(), ws.data_ptr(), ws.numel(), st), "cm3d_compact_hits")
     s = status.cpu().numpy()
     if s[0]:
@@ -127,8 +127,9 @@ def points_in_masks(points, cams, packed, bbox, cam_nums, W, H, min_dist=2.3):
 
 
 # ----------------------------------------------------------------------------- a9
-def get_medoid(points, want_colsum=False):
-    """points: (3,M) float32 like the reference's argument; returns the medoid column index."""
+def get_medoid(points, want_colsum=False, via_rows=False):
+    """points: (3,M) float32 like the reference's argument; returns the medoid column index.  via_rows: hand the
+    kernel a cloud + row-index list (its gather form) instead of the contiguous per-hit coordinates."""
     L = _lib.lib()
     p = np.asarray(points.cpu() if torch.is_tensor(points) else points, np.float32)
     M = p.shape[1]
@@ -142,9 +143,9 @@ def get_medoid(points, want_colsum=False):
     med, cen = _e(1), _e(1, 3, dtype=torch.float32)
     colsum = _e(max(M, 1), dtype=torch.float32) if want_colsum else None      # None: lists of > 512 points take the two-pass route
     ws = _ws(L.cm3d_medoid_workspace_bytes(1, max(M, 1)))
-    check(L.cm3d_medoid(pts.data_ptr(), pt_off.data_ptr(), mask_frame.data_ptr(), 1, hit_off.data_ptr(), tile_off.data_ptr(),
-                        hit_idx.data_ptr(), max(M, 1), 0, med.data_ptr(), cen.data_ptr(), colsum.data_ptr() if want_colsum else 0,
-                        ws.data_ptr(), ws.numel(), _st()), "cm3d_medoid")
+    check(L.cm3d_medoid(pts.data_ptr(), pt_off.data_ptr() if via_rows else 0, mask_frame.data_ptr() if via_rows else 0, 1,
+                        hit_off.data_ptr(), tile_off.data_ptr(), hit_idx.data_ptr() if via_rows else 0, max(M, 1), 0, med.data_ptr(),
+                        cen.data_ptr(), colsum.data_ptr() if want_colsum else 0, ws.data_ptr(), ws.numel(), _st()), "cm3d_medoid")
     j = int(med.cpu()[0])
     return (j, colsum.cpu().numpy()[:M]) if want_colsum else j
 

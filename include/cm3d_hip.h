@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CM3D_ABI_VERSION 1
+#define CM3D_ABI_VERSION 2
 
 #define CM3D_OK 0
 #define CM3D_ERR_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
@@ -59,16 +59,17 @@ typedef void *cm3d_stream_t;
 int cm3d_abi_version(void);
 const char *cm3d_error_string(int code);
 
-/* Resets the per-pass device state: the status word, hit_count[n_masks] and (when not NULL)
- * removed_cnt[n_frames].  First call of every pass over a batch. */
-int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, int32_t *removed_cnt, int32_t n_frames,
+/* Resets the per-pass device state: the status word, hit_count[n_masks] and (when not NULL) the removed-row bits
+ * (removed_words = cm3d_removed_words(rows of the batch, n_frames) 32-bit words).  First call of every pass over a batch. */
+int64_t cm3d_removed_words(int32_t n_rows, int32_t n_frames);
+int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, uint32_t *removed_bits, int64_t removed_words,
                      cm3d_stream_t stream);
 
 /* ---- a2: sweep preparation -------------------------------------------------
  * Replaces 2d_to_3d.py:437-465 + utils/pcd.py:159-172,246-257: strip a raw sweep to 4 columns,
  * sensor->ego->global (rotate then translate, twice), sweeps of a frame back to back; one streaming pass.
  * The ego-box rows (|x|<halfw && |y|<halfw, halfw = f32(sqrt(2.3)), :442-445) are NOT compacted away:
- * they are written as NaN points (inert downstream) and listed per frame, and cm3d_compact_hits turns row
+ * they are written as NaN points (inert downstream) and marked in a bit set, and cm3d_compact_hits turns row
  * indices into indices of the reference's compacted cloud.  So point p of frame f sits at row pt_off[f]+p
  * of its raw rows.
  *  raw          float[rows][raw_stride]   all sweeps of the batch, back to back
@@ -78,13 +79,13 @@ int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, int32
  *  frame_sweep_off int32[F+1]
  *  points       float[pt_cap][4]  OUT     x,y,z,intensity in the global frame at the raw row index (pt_cap >= rows)
  *  pt_off       int32[F+1]        OUT     first row of each frame (= sweep_row_off[frame_sweep_off[f]])
- *  removed_cnt  int32[F]          IN/OUT  number of dropped rows per frame; must be zero on entry (cm3d_batch_begin)
- *  removed_idx  int32[pt_cap]     OUT     frame-local row indices of the dropped rows of frame f at
- *                                         [pt_off[f], pt_off[f] + removed_cnt[f]), in no particular order */
+ *  removed_bits uint32[cm3d_removed_words(rows, F)] IN/OUT  one bit per dropped row; must be zero on entry
+ *                                         (cm3d_batch_begin).  Frame f's bits start at word (pt_off[f] >> 5) + 8 f,
+ *                                         bit (r & 31) of word r >> 5 for its frame-local row r */
 int cm3d_sweep_prep(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
                     int32_t max_rows_per_sweep, const float *sweep_xf, const int32_t *frame_sweep_off,
                     int32_t n_frames, float halfw, float *points, int32_t pt_cap, int32_t *pt_off,
-                    int32_t *removed_cnt, int32_t *removed_idx, int32_t *status, cm3d_stream_t stream);
+                    uint32_t *removed_bits, int32_t *status, cm3d_stream_t stream);
 
 /* ---- a1: COCO-RLE expansion ------------------------------------------------
  * Replaces pycocotools.mask.decode at 2d_to_3d.py:425 (+ the transpose at :428): run
@@ -127,8 +128,8 @@ int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int3
  *  hit_words uint32[planes][n_points_total] OUT, planes = (max masks per frame + 31)/32;
  *        bit (k&31) of hit_words[k>>5][p] = point p lies in mask mask_off[f]+k
  *  hit_count int32[n_masks] IN/OUT accumulated with atomics; zeroed by cm3d_batch_begin
- *  workspace: cm3d_project_workspace_bytes(F, max_pts_per_frame, planes); it receives the per-(1024-point block,
- *        mask) hit counts and must be handed unchanged to cm3d_compact_hits */
+ *  workspace: cm3d_project_workspace_bytes(F, max_pts_per_frame, planes), 16-byte aligned; it receives the per-frame
+ *        tables and the per-(256-row chunk, mask) hit counts and must be handed unchanged to cm3d_compact_hits */
 int64_t cm3d_project_workspace_bytes(int32_t n_frames, int32_t max_pts_per_frame, int32_t planes);
 int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
                       int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off,
@@ -138,16 +139,18 @@ int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_fram
                       cm3d_stream_t stream);
 
 /* a2 + a4-a7 in one launch: cm3d_sweep_prep folded into cm3d_project_hits.  The kernel reads the raw sweep rows,
- * applies the ego-box drop and the sensor -> ego -> global chains (2d_to_3d.py:437-465) on the fly, writes the
- * transformed cloud (`points`, for cm3d_medoid and the caller), pt_off, the dropped-row lists and status[1] exactly as
- * cm3d_sweep_prep does, and produces hit_words / hit_count exactly as cm3d_project_hits does: same results, one pass
- * over the cloud less.  max_sweeps_per_frame (host-side knowledge of frame_sweep_off) must be <= 16; use the two
- * separate calls otherwise.  Arguments as in cm3d_sweep_prep and cm3d_project_hits. */
+ * applies the ego-box drop and the sensor -> ego -> global chains (2d_to_3d.py:437-465) on the fly, writes pt_off, the
+ * removed-row bits and status[1] exactly as cm3d_sweep_prep does, and produces hit_words / hit_count exactly as
+ * cm3d_project_hits does.  `points` is OPTIONAL: NULL = the transformed cloud is not materialised at all (the later stages
+ * only need the in-mask points, which cm3d_compact_hits re-derives from the raw rows into hit_xyz); non-NULL = the cloud
+ * is also written, bit for bit what cm3d_sweep_prep writes.  max_sweeps_per_frame (host-side knowledge of
+ * frame_sweep_off) must be <= 16; use the two separate calls otherwise.  Arguments as in cm3d_sweep_prep and
+ * cm3d_project_hits.  Rows of 4 or 5 floats (the reference's .bin layouts) take the fast path: 16-byte loads. */
 #define CM3D_MAX_FUSED_SWEEPS 16
 int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
                             int32_t max_sweeps_per_frame, const float *sweep_xf, const int32_t *frame_sweep_off,
-                            float halfw, float *points, int32_t pt_cap, int32_t *pt_off, int32_t *removed_cnt,
-                            int32_t *removed_idx, int32_t n_frames, int32_t max_pts_per_frame, int32_t n_points_total,
+                            float halfw, float *points, int32_t pt_cap, int32_t *pt_off, uint32_t *removed_bits,
+                            int32_t n_frames, int32_t max_pts_per_frame, int32_t n_points_total,
                             const float *cams, int32_t n_cams, const int32_t *mask_off, const int32_t *mask_cam,
                             const int32_t *bbox, const uint32_t *packed, int32_t n_masks, int32_t W, int32_t H,
                             float min_dist, int32_t planes, uint32_t *hit_words, int32_t *hit_count, int32_t *status,
@@ -155,27 +158,36 @@ int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t 
 
 /* ---- a7-a8: ordered compaction of the hits ----------------------------------
  * Replaces torch.where + the two .cpu() index-tracking steps at 2d_to_3d.py:606,613-617.
- *  removed_cnt / removed_idx  from cm3d_sweep_prep (both NULL when the points were not produced by it)
+ *  removed_bits  from cm3d_sweep_prep / cm3d_sweep_project_hits (NULL when the points were not produced by them)
+ *  raw, raw_stride, sweep_xf  the raw rows the fused launch read (NULL when `points` is given)
+ *  points   float[pt_cap][4] the transformed cloud, or NULL when it was not materialised
  *  hit_off  int32[n_masks+1] OUT exclusive scan of hit_count
  *  tile_off int32[n_masks+1] OUT exclusive scan of ceil(hit_count/CM3D_MEDOID_TILE)
  *  hit_idx  int32[idx_cap]   OUT ascending point indices of mask m at [hit_off[m], hit_off[m+1]): indices into the
  *                                frame's cloud WITHOUT the dropped rows, i.e. the reference's track_points
- *  hit_row  int32[idx_cap]   OUT the same points as frame-local row indices into `points` (for gathers)
+ *  hit_row  int32[idx_cap]   OUT, optional: the same points as frame-local row indices
+ *  hit_xyz  float[idx_cap][4] OUT, optional: global-frame x,y,z,intensity of every listed point (the gather of :620),
+ *                                laid out like hit_idx; from `points` when given, else from the raw rows through the
+ *                                very fma chains of the sweep preparation (bit-identical)
  *  tile_work OUT, optional (may be NULL): cm3d_tile_work_bytes(n_masks, idx_cap) bytes; the work list of
  *            cm3d_medoid (one record per medoid tile, longest lists first), built beside the compaction
- *  workspace: the buffer cm3d_project_hits filled */
-int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, const int32_t *pt_off, int32_t n_frames,
-                      int32_t max_pts_per_frame, int32_t n_points_total, const int32_t *mask_off, int32_t n_masks,
-                      const int32_t *hit_count, const int32_t *removed_cnt, const int32_t *removed_idx,
-                      int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx, int32_t *hit_row, int32_t idx_cap,
-                      int32_t *tile_work, int32_t *status, void *workspace, int64_t workspace_bytes, cm3d_stream_t stream);
+ *  workspace: the buffer cm3d_project_hits / cm3d_sweep_project_hits filled */
+int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int32_t n_frames, int32_t max_pts_per_frame,
+                      int32_t n_points_total, const int32_t *mask_off, int32_t n_masks, const int32_t *hit_count,
+                      const uint32_t *removed_bits, const float *raw, int32_t raw_stride, const float *sweep_xf,
+                      const float *points, int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx, int32_t *hit_row,
+                      float *hit_xyz, int32_t idx_cap, int32_t *tile_work, int32_t *status, void *workspace,
+                      int64_t workspace_bytes, cm3d_stream_t stream);
 int64_t cm3d_tile_work_bytes(int32_t n_masks, int32_t idx_cap);
 
 /* ---- a9: medoid --------------------------------------------------------------
  * Replaces get_medoid (2d_to_3d.py:116-119) + the gather at :620,645-647:
  * argmin_j sum_i cdist(P,P)[i][j] with torch.cdist's float32 arithmetic (direct form
  * for <=25 points, matmul expansion otherwise), rows summed in ascending i, first minimum.
- *  hit_row    the row-index list of cm3d_compact_hits (gathers go through it)
+ *  points / pt_off / mask_frame / hit_row: either the cloud, the frames' first rows, the frame of every mask and the
+ *             row-index list of cm3d_compact_hits (gathers go through it) -- or hit_row = NULL and `points` = the hit_xyz
+ *             array of cm3d_compact_hits (float[idx_cap][4], laid out like hit_idx; pt_off and mask_frame are then unused
+ *             and may be NULL): the in-mask points are then read as contiguous runs
  *  tile_work  the work list cm3d_compact_hits wrote for the same hit_off / tile_off, or NULL (then it is built here,
  *             one more launch)
  *  medoid_pos int32[n_masks]    OUT position in the mask's index list (-1 if the list is empty)

@@ -31,12 +31,39 @@ def test_lifting_bench_line():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "traffic" in rf
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
+    # bytes = what must move: rows x (raw row + hit word), nothing the kernel skips; no fraction anywhere above 1
+    assert rf["bytes_per_launch"] == rf["rows_per_launch"] * rf["bytes_per_row"] and rf["bytes_per_row"] == 4 * 5 + 4
+    assert d["config"]["cloud_materialised"] is False and d["ranks_in_group"] == 1
+
+    def fracs(o):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k.startswith("frac") and isinstance(v, (int, float)):
+                    yield v
+                yield from fracs(v)
+    assert all(0 <= v <= 1.0 for v in fracs(d)), list(fracs(d))
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["sample"]
     assert d["value"] > 20 * cb["value"]
     one = _run("--config", "tiny", "--frames", "8", "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--no-secondary", "--in-flight", "1",
                "--lane-points", "2000")
     assert one["config"]["batches_in_flight"] == 1 and one["cpu_baseline"] is None
+
+
+def test_two_ranks_from_a_bare_command_line():
+    """`python bench.py --gpus 2` with no torchrun wrapper: two ranks (sharing this box's one GPU, gloo for the exchange)."""
+    env = dict(os.environ, CM3D_SINGLE_DEVICE="1", CM3D_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "tiny", "--frames", "8", "--steps", "4", "--warmup", "1",
+                        "--cpu-sample", "0", "--no-secondary", "--lane-points", "2000"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_in_group"] == 2 and d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
 
 
 def test_fusion_bench_line():

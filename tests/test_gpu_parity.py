@@ -12,31 +12,45 @@ pytestmark = pytest.mark.gpu
 BOX_TOL = 1e-4    # BASELINE.json north_star tolerance on (x,y,z,l,w,h,theta)
 
 
-def _run(cfg_name, n_frames, masks, oracle, **over):
+def _run(cfg_name, n_frames, masks, oracle, keep_cloud=None, **over):
+    """keep_cloud None: the dense-mask runs also materialise the cloud (and compare it), the RLE runs take the product
+    default -- no cloud, in-mask coordinates re-derived from the raw rows."""
     import torch
     from cm3d_amd import lifting
+    if keep_cloud is None:
+        keep_cloud = masks == "dense"
     cfg = syn.config(cfg_name, **over)
     frames = [syn.make_frame(cfg, i) for i in range(n_frames)]
     lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 4000, seed=1), syn.make_lane_table(frames[-1].ego_xyz[:2], 3000, seed=2)]
     frame_lane = [i % 2 for i in range(n_frames)]
     hb = lifting.pack_frames(frames, lanes, frame_lane)
-    eng = lifting.LiftEngine(keep_colsum=True)
+    eng = lifting.LiftEngine(keep_colsum=True, keep_cloud=keep_cloud)
     eng.upload(hb)
     if masks == "dense":
         eng.decode_masks_dense()
     eng.run(masks=masks)
     torch.cuda.synchronize()
     got = eng.download()
+    assert ("points" in got) == bool(keep_cloud)
     exp = oracle_batch(oracle, frames, lanes, frame_lane, hb)
     return hb, got, exp
 
 
+def _expected_hit_xyz(hb, exp):
+    """Coordinates of every listed point, from the oracle's cloud: points[pt_off[frame of mask] + hit_idx]."""
+    per_mask_frame = np.repeat(np.arange(hb.n_frames), np.diff(hb.mask_off))
+    base = np.repeat(exp["pt_off"][per_mask_frame], np.diff(exp["hit_off"]))
+    return exp["points"][base + exp["hit_idx"]]
+
+
 def _compare(hb, got, exp):
     assert np.array_equal(got["pt_off"], exp["pt_off"])
-    assert np.array_equal(got["points"].view(np.uint32), exp["points"].view(np.uint32)), "sweep prep not bit-exact"
+    if "points" in got:
+        assert np.array_equal(got["points"].view(np.uint32), exp["points"].view(np.uint32)), "sweep prep not bit-exact"
     assert np.array_equal(got["bbox"], exp["bbox"])
     assert np.array_equal(got["hit_off"], exp["hit_off"])
     assert np.array_equal(got["hit_idx"], exp["hit_idx"]), "point-to-mask index lists differ"
+    assert np.array_equal(got["hit_xyz"].view(np.uint32), _expected_hit_xyz(hb, exp).view(np.uint32)), "in-mask coordinates not bit-exact"
     assert np.array_equal(got["medoid_pos"], exp["medoid_pos"])
     assert np.array_equal(got["centroid"].view(np.uint32), exp["centroid"].view(np.uint32))
     assert np.array_equal(got["lane_idx"], exp["lane_idx"])
@@ -298,7 +312,7 @@ def test_full_size_batch_properties():
     assert np.array_equal(mp >= 0, cnt > 0) and np.all(mp[cnt > 0] < cnt[cnt > 0])
     # the centroid is the medoid point of the frame's (reference-order) cloud
     sel = np.nonzero(cnt > 0)[0]
-    pts = a["points"][a["pt_off"][per_mask_frame[sel]] + idx[off[sel] + mp[sel]]]
+    pts = a["hit_xyz"][off[sel] + mp[sel]]
     assert np.array_equal(pts[:, :3].view(np.uint32), a["centroid"][sel].view(np.uint32))
     # a box exists (bit 0) exactly for the masks with points; NMS (bit 1) keeps a subset of them
     assert np.array_equal((a["flags"] & 1) != 0, cnt > 0) and np.all(((a["flags"] & 2) == 0) | (cnt > 0))
@@ -353,8 +367,9 @@ def test_kitti_pipeline(oracle):
     assert exp["hit_idx"].size > 50
     for k in ("pt_off", "hit_off", "hit_idx", "medoid_pos", "bbox"):
         assert np.array_equal(got[k], exp[k]), k
-    assert np.array_equal(got["points"].view(np.uint32), exp["points"].view(np.uint32))
+    assert np.array_equal(got["hit_xyz"].view(np.uint32), _expected_hit_xyz(hb, exp).view(np.uint32))
     assert np.array_equal(got["centroid"].view(np.uint32), exp["centroid"].view(np.uint32))
+    exp["hit_xyz"] = _expected_hit_xyz(hb, exp)
     pri = lifting.SHAPE_PRIORS_CHATGPT
     pred, pseudo = kt.labels_of_frame(hb, got, 0, lifting.ClassTable.nuscenes(), pri)
     pred_e, _ = kt.labels_of_frame(hb, exp, 0, lifting.ClassTable.nuscenes(), pri)
