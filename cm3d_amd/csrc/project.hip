@@ -271,7 +271,8 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
                                                      const float *__restrict__ cams, int n_cams,
                                                      const int32_t *__restrict__ mask_off, const int32_t *__restrict__ mask_cam,
                                                      const int4 *__restrict__ bbox, int W, int H, float min_dist, int nm_cap,
-                                                     int max_pts_per_frame, int32_t *__restrict__ ft_all, int4 *__restrict__ ment_all,
+                                                     int max_pts_per_frame, uint32_t mask_words, int32_t *__restrict__ ft_all,
+                                                     int4 *__restrict__ ment_all,
                                                      int32_t *__restrict__ status)
 {
     const int f = blockIdx.x, lane = threadIdx.x;
@@ -335,7 +336,10 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
                 if (c == 0 && (cam < 0 || cam >= n_cams)) atomicOr(&status[0], 4);           // such a mask gets no points
             }
             const uint64_t mk = __ballot(v);
-            if (v) ment[run + cm3d_mbcnt(mk)] = make_int4(bb.x | (k << 16), bb.y, bb.z - bb.x, bb.w - bb.y);
+            // entry: corner and extent of the bounding box as 16-bit pairs (y in the high half, like the pixel codes),
+            // mask number inside the frame, first word of the mask in `packed` (a batch holds < 2^31 mask words)
+            if (v) ment[run + cm3d_mbcnt(mk)] = make_int4(bb.x | (bb.y << 16), (bb.z - bb.x) | ((bb.w - bb.y) << 16), k,
+                                                          (int)((uint32_t)(m0 + k) * mask_words));
             run += (int)__popcll(mk);
         }
     }
@@ -352,6 +356,8 @@ static __device__ __forceinline__ void ph_xform(const float *xf, float x, float 
     cm3d_rot3(xf + 12, ax, ay, az, ox, oy, oz);
     ox = ox + xf[21]; oy = oy + xf[22]; oz = oz + xf[23];
 }
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));       // pixel codes / box corners: v_pk_{sub,min}_u16
 
 // The 4 rows of this lane: x, y, z, w of row j at v[j*S .. j*S+3], S = row stride in registers (5 for 5-column rows,
 // else 4).  STRIDE > 0: full chunks come as STRIDE 16-byte loads per lane (rows 4l..4l+3 are 4*STRIDE consecutive dwords);
@@ -453,7 +459,6 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     PH_STAMP(0);                                                    // setup
 
     const int4 *ment = ment_all + (size_t)f * nm_cap;
-    const size_t mask_words = (size_t)H * Wp;
     const float qnan = __int_as_float(0x7FC00000);
     constexpr int S = PhRows<STRIDE>::S;
     int acc_cnt = 0;                                                // ONE_PLANE: lane k = hits of mask k over this wave's chunks
@@ -463,28 +468,33 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
         // the next chunk's rows are requested now, into their own registers, and arrive under the camera loop
         PhRows<STRIDE> nxt;
         if (chunk + 1 < c_hi) ph_load_rows<STRIDE>(nxt, src, src_stride, (size_t)p0 + (size_t)cb + PH_WC, min(PH_WC, n - cb - PH_WC), lane, PH_DIAG(8));
-        float px_[PH_PT], py_[PH_PT], pz_[PH_PT];
+        f2 X[PH_NP], Y[PH_NP], Z[PH_NP];                           // rows (2h, 2h+1) of this lane side by side
         if (FUSED) {
             // sweep of the chunk's first and last row: equal for all but the chunks that hold a sweep boundary
             const int32_t *srow = ft + FT_SROW;
             int sw_lo = 0, sw_hi = 0;
             if (ns > 1) { sw_lo = ph_sweep_of(srow, ns, cb); sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1); }
-            const bool uni = sw_lo >= sw_hi;
             const float *xf_u = sweep_xf + (size_t)(sa + sw_lo) * CM3D_SWEEP_XF_STRIDE;                    // scalar loads
             uint32_t nib = 0;
+            // (scalar float32 per row: the 24 coefficients stay in scalar registers as operands; the packed form needs every
+            // one of them splatted into a VGPR pair, which costs a wave per SIMD)
+            const bool uni = sw_lo >= sw_hi;
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
-                const int i = cb + 4 * lane + j;
-                const bool live = 4 * lane + j < nvalid;
-                const float x = cur.v[j * S], y = cur.v[j * S + 1], z = cur.v[j * S + 2];
-                const bool drop = live && fabsf(x) < halfw && fabsf(y) < halfw;      // reference drops this row (2d_to_3d.py:442-445)
                 float bx, by, bz;
-                if (uni) ph_xform(xf_u, x, y, z, bx, by, bz);
-                else ph_xform(sweep_xf + (size_t)(sa + ph_sweep_of(srow, ns, i)) * CM3D_SWEEP_XF_STRIDE, x, y, z, bx, by, bz);
-                if (!live || drop) { bx = qnan; by = qnan; bz = qnan; }
-                px_[j] = bx; py_[j] = by; pz_[j] = bz;
+                if (uni) ph_xform(xf_u, cur.v[j * S], cur.v[j * S + 1], cur.v[j * S + 2], bx, by, bz);
+                else ph_xform(sweep_xf + (size_t)(sa + ph_sweep_of(srow, ns, cb + 4 * lane + j)) * CM3D_SWEEP_XF_STRIDE, cur.v[j * S],
+                              cur.v[j * S + 1], cur.v[j * S + 2], bx, by, bz);
+                X[j >> 1][j & 1] = bx; Y[j >> 1][j & 1] = by; Z[j >> 1][j & 1] = bz;
+            }
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) {
+                const bool live = 4 * lane + j < nvalid;
+                const bool drop = live && fabsf(cur.v[j * S]) < halfw && fabsf(cur.v[j * S + 1]) < halfw;      // reference drops this row (2d_to_3d.py:442-445)
+                if (!live || drop) { X[j >> 1][j & 1] = qnan; Y[j >> 1][j & 1] = qnan; Z[j >> 1][j & 1] = qnan; }
                 nib |= (drop ? 1u : 0u) << j;
-                if (points_out && live) points_out[(size_t)p0 + i] = make_float4(bx, by, bz, cur.v[j * S + 3]);
+                if (points_out && live)
+                    points_out[(size_t)p0 + cb + 4 * lane + j] = make_float4(X[j >> 1][j & 1], Y[j >> 1][j & 1], Z[j >> 1][j & 1], cur.v[j * S + 3]);
             }
             if (__ballot(nib != 0u)) {
                 // this chunk's 8 words of the frame's removed-row bits (zeroed by cm3d_batch_begin): lane l holds bits 4(l&7)..+3 of word l>>3
@@ -496,17 +506,11 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
                 const bool live = 4 * lane + j < nvalid;
-                px_[j] = live ? cur.v[j * S] : qnan; py_[j] = live ? cur.v[j * S + 1] : qnan; pz_[j] = live ? cur.v[j * S + 2] : qnan;
+                X[j >> 1][j & 1] = live ? cur.v[j * S] : qnan; Y[j >> 1][j & 1] = live ? cur.v[j * S + 1] : qnan;
+                Z[j >> 1][j & 1] = live ? cur.v[j * S + 2] : qnan;
             }
         }
         PH_STAMP(1);                                                // rows arrive, transform, [cloud store]
-        f2 X[PH_NP], Y[PH_NP], Z[PH_NP];
-#pragma unroll
-        for (int h = 0; h < PH_NP; ++h) {
-            X[h] = (f2){px_[2 * h], px_[2 * h + 1]};
-            Y[h] = (f2){py_[2 * h], py_[2 * h + 1]};
-            Z[h] = (f2){pz_[2 * h], pz_[2 * h + 1]};
-        }
         uint32_t bits[PH_PT];
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) bits[j] = 0;
@@ -539,6 +543,8 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             }
             PH_STAMP(2);                                            // cone tests
             if (!__ballot(inside >= 0.0f)) continue;
+            const int e0 = __builtin_amdgcn_readfirstlane(s_first[c]), e1 = __builtin_amdgcn_readfirstlane(s_first[c + 1]);
+            if (e0 >= e1) continue;                                 // a camera without (non-empty) masks: nothing to hit
             const int cns = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 54]);
             const int cfl = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 55]);
             const float *cm = s_cam + c * CM3D_CAM_STRIDE;
@@ -552,13 +558,18 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             for (int j = 1; j < PH_PT; ++j) pxall &= px[j];
             PH_STAMP(3);                                            // projection
             if (!__ballot(pxall >= 0) || PH_DIAG(2)) continue;      // no point of the wave in this image
-            // px = iv << 16 | iu; px = -1 gives iv = -1
-#define PX_IU(j) (px[j] & 0xFFFF)
-#define PX_IV(j) (px[j] >> 16)
-            // the masks of this camera (sorted entries: bounding box + mask number), PH_MB at a time: all entries, then all
-            // mask words of the batch are requested before the first one is used (one memory round trip per batch)
-            const int e1 = __builtin_amdgcn_readfirstlane(s_first[c + 1]);
-            for (int e = __builtin_amdgcn_readfirstlane(s_first[c]); e < e1; e += PH_MB) {
+            // px = iv << 16 | iu (two 16-bit halves; -1 = outside): byte offset of the point's word inside a mask and its bit,
+            // once per camera
+            uint32_t wo4[PH_PT], sh[PH_PT];
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) {
+                const uint32_t iu = (uint32_t)px[j] & 0xFFFFu, iv = (uint32_t)px[j] >> 16;
+                wo4[j] = (iv * (uint32_t)Wp + (iu >> 5)) << 2;
+                sh[j] = iu & 31u;
+            }
+            // the masks of this camera (sorted entries: bounding box, mask number, first word), PH_MB at a time: all entries,
+            // then all mask words of the batch are requested before the first one is used (one memory round trip per batch)
+            for (int e = e0; e < e1; e += PH_MB) {
                 int4 en[PH_MB];
 #pragma unroll
                 for (int b = 0; b < PH_MB; ++b) en[b] = ment[min(e + b, e1 - 1)];                  // uniform: scalar loads
@@ -568,17 +579,19 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                 for (int b = 0; b < PH_MB; ++b) {
 #pragma unroll
                     for (int j = 0; j < PH_PT; ++j) word[b][j] = 0u;
-                    const int ex = __builtin_amdgcn_readfirstlane(en[b].x), y0 = __builtin_amdgcn_readfirstlane(en[b].y);
-                    const int rx = __builtin_amdgcn_readfirstlane(en[b].z), ry = __builtin_amdgcn_readfirstlane(en[b].w);
-                    const int x0 = ex & 0xFFFF;
-                    kb[b] = e + b < e1 ? (ex >> 16) : -1;
+                    kb[b] = e + b < e1 ? __builtin_amdgcn_readfirstlane(en[b].z) : -1;
                     if (kb[b] < 0) continue;                        // past the camera's last mask (wave-uniform)
-                    const uint32_t *mw = packed + (size_t)(m0 + kb[b]) * mask_words;
+                    const us2 org = __builtin_bit_cast(us2, __builtin_amdgcn_readfirstlane(en[b].x));
+                    const us2 ext = __builtin_bit_cast(us2, __builtin_amdgcn_readfirstlane(en[b].y));
+                    const char *mw = reinterpret_cast<const char *>(packed) + ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane(en[b].w) << 2);
 #pragma unroll
                     for (int j = 0; j < PH_PT; ++j) {
-                        // iv = -1 < y0 fails the unsigned range test by itself
-                        const bool cand = ((unsigned)(PX_IU(j) - x0) <= (unsigned)rx) & ((unsigned)(PX_IV(j) - y0) <= (unsigned)ry);
-                        if (cand) word[b][j] = mw[(size_t)PX_IV(j) * Wp + (PX_IU(j) >> 5)];
+                        // inside the box <=> (x - x0 <= rx) and (y - y0 <= ry) as unsigned 16-bit halves; -1 (0xFFFF, 0xFFFF) is
+                        // outside every box (corners are < 32767)
+                        const us2 d = __builtin_bit_cast(us2, px[j]) - org;
+                        const us2 m = __builtin_elementwise_min(d, ext);
+                        if (__builtin_bit_cast(uint32_t, m) == __builtin_bit_cast(uint32_t, d))
+                            word[b][j] = *reinterpret_cast<const uint32_t *>(mw + wo4[j]);
                     }
                 }
 #pragma unroll
@@ -587,10 +600,10 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                     int cnt = 0;
 #pragma unroll
                     for (int j = 0; j < PH_PT; ++j) {
-                        const bool hit = (word[b][j] >> (px[j] & 31)) & 1u;          // word = 0 for a non-candidate
-                        if (ONE_PLANE) bits[j] |= (hit ? 1u : 0u) << kb[b];
+                        const uint32_t hit = (word[b][j] >> sh[j]) & 1u;             // word = 0 for a non-candidate
+                        if (ONE_PLANE) bits[j] |= hit << kb[b];
                         else if (hit) s_bits[(kb[b] >> 5) * PH_WC + 4 * lane + j] |= 1u << (kb[b] & 31);
-                        cnt += (int)__popcll(__ballot(hit));
+                        cnt += (int)__popcll(__ballot(hit != 0u));
                     }
                     if (cnt) {
                         if (ONE_PLANE) mycnt += lane == kb[b] ? cnt : 0;
@@ -986,21 +999,22 @@ extern "C" int64_t cm3d_project_workspace_bytes(int32_t n_frames, int32_t max_pt
     return ph_ws_layout(n_frames, max_pts_per_frame, planes, nullptr, nullptr);
 }
 
-// workgroups the projection launch aims at: every CU filled once with resident workgroups (no second round with a
-// partly filled chip), each wave walking a contiguous run of wave-chunks
-static int ph_target_blocks()
+// workgroups the projection launch aims at: every CU filled exactly once with resident workgroups (a second round would
+// run on a partly filled chip), each wave walking a contiguous run of wave-chunks.  CM3D_PH_BLOCKS overrides (experiments).
+static int ph_target_blocks(const void *kernel, size_t lds)
 {
-    static int target = 0;
-    if (!target) {
-        if (const char *e = getenv("CM3D_PH_BLOCKS")) target = atoi(e);
-        if (target <= 0) {
-            int dev = 0, cus = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-                cus = 256;
-            target = cus * 5;
-        }
+    static int forced = -1, cus = 0;
+    if (forced < 0) {
+        const char *e = getenv("CM3D_PH_BLOCKS");
+        forced = e ? atoi(e) : 0;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
     }
-    return target;
+    if (forced > 0) return forced;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PH_THREADS, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+    return cus * per_cu;
 }
 
 static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
@@ -1024,15 +1038,36 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
     PhSweepIn none = {};
     const PhSweepIn sw = fused ? *fused : none;
     hipLaunchKernelGGL(k_frame_tables, dim3(n_frames), dim3(64), 0, st, sw, fused ? 1 : 0, pt_off, n_frames, cams, n_cams, mask_off, mask_cam,
-                       (const int4 *)bbox, W, H, min_dist, nm_cap, max_pts_per_frame, ws.ft, ws.ment, status);
+                       (const int4 *)bbox, W, H, min_dist, nm_cap, max_pts_per_frame, (uint32_t)H * (uint32_t)Wp, ws.ft, ws.ment, status);
     CM3D_CHECK_LAUNCH();
-    int gx = (ph_target_blocks() + n_frames - 1) / n_frames;
+    const float *src = fused ? sw.raw : points;
+    const int stride = fused ? sw.raw_stride : 4;
+    const int which = !fused ? 0 : (stride == 5 ? 1 : (stride == 4 ? 2 : 3));
+    const bool one = planes_cap == 1;
+    const void *fn = one ? (which == 0 ? (const void *)k_project_hits<true, false, 4>
+                            : which == 1 ? (const void *)k_project_hits<true, true, 5>
+                            : which == 2 ? (const void *)k_project_hits<true, true, 4> : (const void *)k_project_hits<true, true, 0>)
+                         : (which == 0 ? (const void *)k_project_hits<false, false, 4>
+                            : which == 1 ? (const void *)k_project_hits<false, true, 5>
+                            : which == 2 ? (const void *)k_project_hits<false, true, 4> : (const void *)k_project_hits<false, true, 0>);
+    size_t lds = one ? 0 : (size_t)PH_WAVES * ((size_t)planes_cap * PH_WC * sizeof(uint32_t) + (size_t)nm_cap * sizeof(int));
+    if (!one) {
+        static size_t lds_allowed[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+        if (lds > lds_allowed[which]) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CM3D_ERR_LAUNCH;
+            lds_allowed[which] = lds;
+        }
+    }
+    static int blocks_one[4] = {0, 0, 0, 0};                        // cached for the register-only variants (no dynamic LDS)
+    int target = one ? blocks_one[which] : 0;
+    if (!target) {
+        target = ph_target_blocks(fn, lds);
+        if (one) blocks_one[which] = target;
+    }
+    int gx = (target + n_frames - 1) / n_frames;
     const int gx_max = (nwc_max + PH_WAVES - 1) / PH_WAVES;          // at least one wave-chunk per wave
     if (gx > gx_max) gx = gx_max;
     if (gx < 1) gx = 1;
-    size_t lds = 0;
-    const float *src = fused ? sw.raw : points;
-    const int stride = fused ? sw.raw_stride : 4;
 #define PH_LAUNCH(ONE, FUSED, STRIDE)                                                                                            \
     hipLaunchKernelGGL((k_project_hits<ONE, FUSED, STRIDE>), dim3(gx, n_frames), dim3(PH_THREADS), lds, st, src, stride, sw.sweep_xf, \
                        sw.halfw, sw.points_out, sw.removed_bits, ws.ft, ws.ment, cams, n_cams, packed, W, H, Wp, min_dist, nm_cap, \
@@ -1044,21 +1079,8 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
         else if (stride == 4) PH_LAUNCH(ONE, true, 4);                                                                           \
         else PH_LAUNCH(ONE, true, 0);                                                                                            \
     } while (0)
-    if (planes_cap == 1) {
-        PH_LAUNCH_S(true);
-    } else {
-        lds = (size_t)PH_WAVES * ((size_t)planes_cap * PH_WC * sizeof(uint32_t) + (size_t)nm_cap * sizeof(int));
-        static size_t lds_allowed[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
-        const int which = !fused ? 0 : (stride == 5 ? 1 : (stride == 4 ? 2 : 3));
-        if (lds > lds_allowed[which]) {
-            const void *fn = which == 0 ? (const void *)k_project_hits<false, false, 4>
-                             : which == 1 ? (const void *)k_project_hits<false, true, 5>
-                             : which == 2 ? (const void *)k_project_hits<false, true, 4> : (const void *)k_project_hits<false, true, 0>;
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CM3D_ERR_LAUNCH;
-            lds_allowed[which] = lds;
-        }
-        PH_LAUNCH_S(false);
-    }
+    if (one) PH_LAUNCH_S(true);
+    else PH_LAUNCH_S(false);
 #undef PH_LAUNCH_S
 #undef PH_LAUNCH
     CM3D_CHECK_LAUNCH();
