@@ -255,6 +255,81 @@ def rehearse_launch(args):
     return 0
 
 
+def end_to_end_bench(args):
+    """`--end-to-end N`: what a user of the drop-in script pays -- files on disk -> pseudolabels_minival.json, through
+    cm3d_amd.pipeline_nuscenes (src/nuscenes/2d_to_3d.py) on a synthetic nuScenes-layout dataset of N frames shaped like
+    --config (C2 by default): table walk, <f>_data.json, mask pickles + RLE strings, sweep files, H2D, the GPU pass,
+    the record gather, the JSON writer.  Timed three ways: the native loader (libcm3d_reader.so) on threads of this process,
+    reader processes that each run the native loader, and -- on a slice -- the per-frame Python reader that mirrors the
+    reference.  Inputs come from the page cache (the dataset was just written).  One JSON line."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from cm3d_amd import nusc_io, pipeline_nuscenes as pn
+    cfg = syn.config(args.config)
+    per_scene = 32
+    n_scenes = max(2, (args.end_to_end + per_scene - 1) // per_scene)
+    n_frames = n_scenes * per_scene
+    root = tempfile.mkdtemp(prefix="cm3d_e2e_", dir=os.environ.get("CM3D_E2E_DIR") or None)
+    try:
+        t0 = time.perf_counter()
+        dataroot, mask_dir, names = nusc_io.write_synthetic_dataset(root, cfg, n_scenes=n_scenes, frames_per_scene=per_scene,
+                                                                    lane_points=args.lane_points, pool=64)
+        t_write = time.perf_counter() - t0
+        sweep_bytes = sum(os.path.getsize(os.path.join(dataroot, "sweeps", "LIDAR_TOP", f)) for f in os.listdir(os.path.join(dataroot, "sweeps", "LIDAR_TOP")))
+        cores = visible_cores()
+
+        def run(tag, scenes, reader_threads, workers):
+            out_dir = os.path.join(root, "out_" + tag)
+            argv = ["--version", "v1.0-synth", "--dataroot", dataroot, "--mask-dir", mask_dir, "--output-dir", out_dir, "--scenes", ",".join(scenes),
+                    "--ratio", str(cfg.ratio), "--n-sweeps", str(cfg.n_sweeps), "--scenes-per-batch", str(max(1, args.frames // per_scene)),
+                    "--reader-threads", str(reader_threads), "--workers", str(workers), "--priors", os.path.join(ROOT, "src", "nuscenes", "cfg", "shape_priors_chatgpt.json")]
+            buf = io.StringIO()
+            t = time.perf_counter()
+            with contextlib.redirect_stdout(buf):
+                rc = pn.main(argv)
+            dt = time.perf_counter() - t
+            if rc != 0:
+                raise RuntimeError(f"entry point returned {rc}")
+            timer = {}
+            for line in buf.getvalue().splitlines():
+                if ":" in line and not line.startswith("wrote"):
+                    k, v = line.split(":", 1)
+                    try:
+                        timer[k.strip()] = round(float(v), 3)
+                    except ValueError:
+                        pass
+            return dt, json.load(open(os.path.join(out_dir, pn.OUTPUT_NAME))), timer
+
+        run("warm", names[:2], 0, 0)                                      # first-use costs (library loads, allocator) stay out
+        nproc = max(2, min(cores // 2, 16))
+        dt_t, res_t, timer_t = run("threads", names, 0, 0)
+        dt_p, res_p, timer_p = run("procs", names, max(1, cores // nproc), nproc)
+        sub = names[:max(2, 128 // per_scene)]
+        dt_py, res_py, _ = run("python", sub, -1, 0)
+        same_procs = res_t == res_p
+        same_python = all(res_t["results"][k] == v for k, v in res_py["results"].items())
+        best = min(dt_t, dt_p)
+        print(json.dumps({
+            "metric": "pseudo-label frames/sec, files on disk -> pseudolabels_minival.json (entry point, end to end)",
+            "value": round(n_frames / best, 1), "unit": "frames/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}-shaped nuScenes-layout dataset: {n_scenes} scenes x {per_scene} frames = {n_frames} frames "
+                                   f"({cfg.n_points}x{cfg.n_sweeps} pts, {cfg.n_cams} cams, {cfg.n_masks} masks {cfg.width}x{cfg.height}), "
+                                   f"{sweep_bytes / 1e6:.0f} MB of sweep files in the page cache, {args.frames} frames per GPU batch"},
+            "native_reader_threads": {"frames_per_s": round(n_frames / dt_t, 1), "seconds": round(dt_t, 3), "threads": cores, "timer": timer_t},
+            "native_reader_processes": {"frames_per_s": round(n_frames / dt_p, 1), "seconds": round(dt_p, 3), "processes": nproc,
+                                        "threads_each": max(1, cores // nproc), "timer": timer_p},
+            "python_reader": {"frames_per_s": round(len(sub) * per_scene / dt_py, 1), "frames": len(sub) * per_scene, "seconds": round(dt_py, 3),
+                              "note": "pickle.load + np.fromfile per frame in one process, as the reference reads (2d_to_3d.py:422-441)"},
+            "identical_output": {"threads_vs_processes": bool(same_procs), "native_vs_python_reader": bool(same_python)},
+            "sweep_read_GBs": round(sweep_bytes / best / 1e9, 2), "usable_cores": cores, "dataset_write_seconds": round(t_write, 1),
+            "samples": len(res_t["results"]), "boxes": sum(len(v) for v in res_t["results"].values())}))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return 0
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
@@ -278,6 +353,8 @@ def main(argv=None):
     ap.add_argument("--fusion", type=int, default=0, metavar="SAMPLES",
                     help="time the SAM3D fusion matching (SURVEY 8 f4) on this many samples instead of the lifting path")
     ap.add_argument("--rehearse-launch", action="store_true", help="launch, rendezvous and the record exchange only (no GPU needed)")
+    ap.add_argument("--end-to-end", type=int, default=0, metavar="FRAMES",
+                    help="time the entry point instead: files of a synthetic dataset of this many frames -> pseudolabels json")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error("--gpus >= 1")
@@ -293,6 +370,8 @@ def main(argv=None):
     if args.fusion > 0:
         fusion_bench(args.fusion, min(args.steps, 50), min(args.warmup, 5))
         return 0
+    if args.end_to_end > 0:
+        return end_to_end_bench(args)
 
     rank, world, local_rank = cdist.init_from_env()
     if os.environ.get("CM3D_SINGLE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box (with CM3D_DIST_BACKEND=gloo)

@@ -3,8 +3,10 @@
 The reference is a single process (no torch.distributed anywhere); frames are
 independent (stage 1 per (frame, mask), stage 2 per box, NMS per frame --
 src/nuscenes/2d_to_3d.py:415-694, :733-822, :844-924), so the only exchange is
-one gather of fixed-size box records to rank 0: `all_reduce(MAX)` of the record
-count, then one padded `all_gather` over RCCL (backend "nccl" on ROCm) or gloo on CPU; rank 0 keeps the result.
+one gather of fixed-size box records to rank 0 (`gather_records`): an `all_gather` of the
+per-rank record counts, then one padded `all_gather` of the records over RCCL (backend "nccl" on
+ROCm) or gloo on CPU; rank 0 keeps the result.  The entry points (pipeline_nuscenes, pipeline_waymo)
+and bench.py all use this one exchange -- also in a one-rank run, where it is a pass-through.
 """
 import os
 from typing import List, Optional

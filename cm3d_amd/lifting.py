@@ -204,6 +204,54 @@ def pack_frames(frames: Sequence, lane_tables: Sequence[np.ndarray], frame_lane:
         ego_box=not ((len(pose_rt) == len(frames) and len(frames) > 0) or all(getattr(f, "no_ego_box", False) for f in frames)))
 
 
+def pack_manifest(man, lane_tables, frame_lane, classes: Optional[ClassTable], rd, stride=5, alloc=None):
+    """Frame manifests (nusc_io.scene_manifest) -> HostBatch, with the bulk data read by the native loader `rd`
+    (cm3d_amd.reader.Reader): all sweeps of the batch land in one (page-locked) `raw` buffer, all RLE strings are parsed
+    to run lengths by its thread pool.  Frames without masks are left out, like pack_frames' callers do.
+    Returns (HostBatch or None when no frame has a mask, indices of the frames it holds)."""
+    classes = classes or ClassTable.nuscenes()
+    counts, rle_off, fmo, wh = rd.load_masks([m.mask_path for m in man])
+    n_per = np.diff(fmo)
+    live = [i for i in range(len(man)) if n_per[i] > 0]
+    if not live:
+        return None, []
+    if len(live) != len(man):                       # rare: repack the frames that have masks
+        hb, sub = pack_manifest([man[i] for i in live], lane_tables, [frame_lane[i] for i in live], classes, rd, stride, alloc)
+        return hb, [live[k] for k in sub]
+    W, H = int(wh[0, 0]), int(wh[0, 1])
+    if np.any(wh[:, 0] != W) or np.any(wh[:, 1] != H):
+        raise ValueError("all frames of a batch must share mask size and camera count")
+    raw, row_off = rd.load_sweeps([p for m in man for p in m.sweep_paths], stride, alloc)
+    fso = np.concatenate([[0], np.cumsum([len(m.sweep_paths) for m in man])]).astype(np.int32)
+    n_cams = man[0].cams.shape[0]
+    mask_cam, mask_frame, class_id, score = [], [], [], []
+    for fi, m in enumerate(man):
+        n = int(n_per[fi])
+        if not (len(m.labels) == len(m.scores) == len(m.cam_nums) == n):
+            raise ValueError("labels / detection_scores / cam_nums / masks differ in length")
+        if m.cams.shape[0] != n_cams:
+            raise ValueError("all frames of a batch must share mask size and camera count")
+        mask_cam.extend(int(c) for c in m.cam_nums)
+        mask_frame.extend([fi] * n)
+        for l in m.labels:
+            ci = classes.index(get_detection_name(l))
+            if classes.out_names is not None and classes.out_names[ci] == "":
+                raise ValueError(f"label {l!r} has no output type")
+            class_id.append(ci)
+        score.extend(float(s) for s in m.scores)
+    lane32 = [np.asarray(t, np.float64).astype(np.float32).reshape(-1, 3) for t in lane_tables]
+    lane_off = np.concatenate([[0], np.cumsum([t.shape[0] for t in lane32])]).astype(np.int32)
+    i32 = lambda a: np.asarray(a, np.int32)
+    hb = HostBatch(
+        raw=raw, raw_stride=stride, sweep_row_off=row_off, sweep_xf=np.concatenate([np.asarray(m.sweep_xf, np.float32).reshape(-1, _lib.SWEEP_XF_STRIDE) for m in man], 0),
+        frame_sweep_off=fso, max_rows_per_sweep=max(1, int(np.diff(row_off).max())), cams=np.stack([np.asarray(m.cams, np.float32) for m in man]),
+        n_cams=n_cams, mask_off=fmo.astype(np.int32), mask_cam=i32(mask_cam), mask_frame=i32(mask_frame), rle_counts=counts, rle_off=rle_off,
+        class_id=i32(class_id), score=np.asarray(score, np.float64), lane=np.concatenate(lane32, 0), lane_off=lane_off,
+        frame_lane=i32(frame_lane), ego_xyz=np.stack([m.ego_xyz for m in man]), width=W, height=H, tokens=[m.token for m in man],
+        labels=[list(m.labels) for m in man], ego_box=True)
+    return hb, list(range(len(man)))
+
+
 # ---- device side ----------------------------------------------------------------
 def _ptr(t: Optional[torch.Tensor]):
     return 0 if t is None else t.data_ptr()
@@ -241,7 +289,9 @@ class LiftEngine:
     # -- upload + allocation
     def upload(self, hb: HostBatch, dense_masks: Optional[torch.Tensor] = None):
         d = self.dev
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+        def t(a):
+            h = torch.from_numpy(np.ascontiguousarray(a))
+            return h.to(d, non_blocking=h.is_pinned())        # page-locked staging buffers (cm3d_amd.reader) copy asynchronously
         F, M, S = hb.n_frames, hb.n_masks, len(hb.sweep_row_off) - 1
         if M <= 0 or F <= 0 or S <= 0 or hb.n_raw_rows <= 0:
             raise ValueError("empty batch")
@@ -518,6 +568,7 @@ class LiftPipeline:
         self.engines = [LiftEngine(device, **engine_kw) for _ in range(depth)]
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(depth)]
         self.masks = [None] * depth
+        self.uploaded = [torch.cuda.Event() for _ in range(depth)]      # recorded behind a slot's H2D copies (submit)
         self._next = 0
 
     @property
@@ -532,6 +583,7 @@ class LiftPipeline:
         eng = self.engines[slot]
         with torch.cuda.stream(self.streams[slot]):
             eng.upload(hb)
+            self.uploaded[slot].record(self.streams[slot])
             if masks == "dense":
                 eng.decode_masks_dense()
             eng.run(masks=masks)
@@ -543,6 +595,17 @@ class LiftPipeline:
         with torch.cuda.stream(self.streams[slot]):
             self.engines[slot].run(masks=masks or self.masks[slot], project_events=project_events)
 
+    def collect_records(self, slot, frame_ids):
+        """Waits for the slot's stream, checks the status word and returns the slot's kept-box records as a DEVICE tensor
+        (kept_box_records): what an entry point hands to the end-of-job gather -- nothing else is downloaded."""
+        self.streams[slot].synchronize()
+        eng = self.engines[slot]
+        eng.check_status()
+        with torch.cuda.stream(self.streams[slot]):
+            rec = kept_box_records(eng.b, frame_ids, self.dev)
+        self.streams[slot].synchronize()
+        return rec
+
     def collect(self, slot, full=True):
         """Waits for the slot's stream only and returns (host batch, numpy results); full=False: per-mask results only
         (LiftEngine.download)."""
@@ -551,6 +614,46 @@ class LiftPipeline:
         with torch.cuda.stream(self.streams[slot]):
             res = eng.download(full=full)
         return eng.b.hb, res
+
+
+REC_FRAME_A, REC_FRAME_B = 5, 6       # columns of a shipped record that carry the frame's identity (see kept_box_records)
+
+
+def kept_box_records(b, frame_ids, device=None):
+    """The fixed-size records the multi-GPU gather ships: one row of CM3D_BOX_STRIDE doubles per box that
+    survives NMS, in (frame, mask) order.  Columns 0-4, 7-9 are cm3d_box_nms's (centre, rotation, score, class, flags);
+    columns 5 and 6 -- lane yaw and distance, which no output file contains -- are overwritten with the frame's identity
+    frame_ids[f] = (a, b) (nuScenes: global sample index, 0; Waymo: scene index, frame number), so that rank 0 can rebuild
+    every output record from the gathered rows and the job's deterministic frame order alone."""
+    device = device or b.box.device
+    keep = (b.flags & 3) == 3
+    rec = b.box[keep].clone()
+    ids = torch.as_tensor(np.ascontiguousarray(frame_ids, np.float64).reshape(-1, 2), device=device)
+    fr = b.mask_frame[keep].long()
+    rec[:, REC_FRAME_A] = ids[fr, 0]
+    rec[:, REC_FRAME_B] = ids[fr, 1]
+    return rec
+
+
+def nuscenes_boxes_from_records(rec, tokens, classes: Optional[ClassTable] = None):
+    """Gathered records (numpy (k, 10), see kept_box_records) -> the reference's per-sample box dict lists (:808-817 after NMS
+    :913-924): {sample_token: [box, ...]} with every token of `tokens` present ([] when a sample has no box, :845)."""
+    classes = classes or ClassTable.nuscenes()
+    results = {t: [] for t in tokens}
+    for r in np.asarray(rec, np.float64).reshape(-1, _lib.BOX_STRIDE):
+        token, ci = tokens[int(r[REC_FRAME_A])], int(r[8])
+        name = classes.names[ci]
+        results[token].append({
+            "sample_token": token,
+            "translation": [float(r[0]), float(r[1]), float(r[2])],
+            "size": [float(v) for v in classes.prior_wlh[ci]],
+            "rotation": [float(r[3]), 0.0, 0.0, float(r[4])],
+            "velocity": [0, 0],
+            "detection_name": name,
+            "detection_score": float(r[7]),
+            "attribute_name": ATTRIBUTE_NAMES[name],
+        })
+    return results
 
 
 def box_records(hb: HostBatch, res: dict, classes: Optional[ClassTable] = None):

@@ -29,6 +29,7 @@ ANNOTATION_TABLES = ["category", "attribute", "instance", "sample_annotation"]  
 class NuscTables:
     def __init__(self, version, dataroot):
         self.version, self.dataroot = version, dataroot
+        self.cam_templates = {}          # (calibrated_sensor token, ratio) -> camera record with the sensor's half filled in
         base = os.path.join(dataroot, version)
         self.t = {}
         for name in TABLES:
@@ -98,31 +99,29 @@ def load_lane_points(dataroot, location):
     return np.asarray(pts, np.float64).reshape(-1, 3)
 
 
-def frames_of_scene(tables: NuscTables, scene, mask_dir, n_sweeps=3, ratio=0.64, missing_ok=False):
-    """Kernel inputs of every frame of a scene (reference :415-503)."""
-    frames = []
+def scene_manifest(tables: NuscTables, scene, mask_dir, n_sweeps=3, ratio=0.64, missing_ok=False):
+    """What the frames of a scene consist of, without reading any bulk data (reference :415-503): per frame the sweep files
+    with their transforms, the camera records, the mask file and the contents of the small <f>_data.json."""
+    out = []
     for frame_num, sample in enumerate(tables.samples_of_scene(scene)):
         mp = os.path.join(mask_dir, scene["name"], f"{frame_num}_masks.pkl")
         dp = os.path.join(mask_dir, scene["name"], f"{frame_num}_data.json")
         if not (os.path.exists(mp) and os.path.exists(dp)):
             if missing_ok:       # the producer writes no files for frames without detections (gen_2d_masks_detic.py:490-491)
-                rles, data = [], {"labels": [], "detection_scores": [], "cam_nums": []}
+                mp, data = None, {"labels": [], "detection_scores": [], "cam_nums": []}
             else:
                 raise FileNotFoundError(mp)
         else:
-            with open(mp, "rb") as f:
-                rles = pickle.load(f)
             with open(dp) as f:
                 data = json.load(f)
         # sweeps: the key frame's LIDAR_TOP sample_data and its `next` chain (:433-463)
         sd = tables.get("sample_data", tables.sample_data_of[sample["token"]]["LIDAR_TOP"])
         key_pose = tables.get("ego_pose", sd["ego_pose_token"])
-        raws, xfs = [], []
+        paths, xfs = [], []
         for _ in range(n_sweeps):
-            scan = np.fromfile(os.path.join(tables.dataroot, sd["filename"]), dtype=np.float32).reshape(-1, 5)
             cs = tables.get("calibrated_sensor", sd["calibrated_sensor_token"])
             pose = tables.get("ego_pose", sd["ego_pose_token"])
-            raws.append(scan)
+            paths.append(os.path.join(tables.dataroot, sd["filename"]))
             xfs.append(geo.sweep_xf_record(cs["translation"], cs["rotation"], pose["translation"], pose["rotation"]))
             if sd.get("next", "") == "":
                 break
@@ -131,26 +130,57 @@ def frames_of_scene(tables: NuscTables, scene, mask_dir, n_sweeps=3, ratio=0.64,
         for ch in CAM_LIST:
             csd = tables.get("sample_data", tables.sample_data_of[sample["token"]][ch])
             pose = tables.get("ego_pose", csd["ego_pose_token"])
-            cs = tables.get("calibrated_sensor", csd["calibrated_sensor_token"])
-            cams.append(geo.nusc_cam_record(pose["translation"], pose["rotation"], cs["translation"], cs["rotation"],
-                                            cs["camera_intrinsic"], ratio))
+            # a calibrated_sensor row serves every frame of its log: its half of the record (stage 1 and K') is built once
+            key = (csd["calibrated_sensor_token"], ratio)
+            tmpl = tables.cam_templates.get(key)
+            if tmpl is None:
+                cs = tables.get("calibrated_sensor", csd["calibrated_sensor_token"])
+                tmpl = geo.nusc_cam_record([0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], cs["translation"], cs["rotation"], cs["camera_intrinsic"], ratio)
+                tables.cam_templates[key] = tmpl
+            rec = tmpl.copy()
+            rec[0:3] = (-np.asarray(pose["translation"], np.float64)).astype(np.float32)
+            rec[3:12] = geo.quat_to_rotmat(pose["rotation"]).T.astype(np.float32).reshape(9)
+            cams.append(rec)
+        out.append(SimpleNamespace(token=sample["token"], sweep_paths=paths, sweep_xf=np.stack(xfs), cams=np.stack(cams), mask_path=mp,
+                                   labels=list(data["labels"]), scores=list(data["detection_scores"]), cam_nums=list(data["cam_nums"]),
+                                   ego_xyz=np.asarray(key_pose["translation"], np.float64), ratio=ratio))
+    return out
+
+
+def frames_of_scene(tables: NuscTables, scene, mask_dir, n_sweeps=3, ratio=0.64, missing_ok=False):
+    """Kernel inputs of every frame of a scene (reference :415-503), read frame by frame like the reference does:
+    pickle.load of the mask file (:422-424), np.fromfile of every sweep (utils/pcd.py:250)."""
+    frames = []
+    for m in scene_manifest(tables, scene, mask_dir, n_sweeps, ratio, missing_ok):
+        rles = []
+        if m.mask_path is not None:
+            with open(m.mask_path, "rb") as f:
+                rles = pickle.load(f)
+        raws = [np.fromfile(p, dtype=np.float32).reshape(-1, 5) for p in m.sweep_paths]
         if rles:
             W, H = rles[0]["size"]
         else:
             W, H = int(1600 * ratio), int(900 * ratio)
         frames.append(SimpleNamespace(
-            token=sample["token"], sweeps_raw=raws, sweep_xf=np.stack(xfs), cams=np.stack(cams), rles=list(rles),
-            labels=list(data["labels"]), scores=list(data["detection_scores"]), cam_nums=list(data["cam_nums"]),
-            ego_xyz=np.asarray(key_pose["translation"], np.float64), width=int(W), height=int(H)))
+            token=m.token, sweeps_raw=raws, sweep_xf=m.sweep_xf, cams=m.cams, rles=list(rles), labels=m.labels, scores=m.scores,
+            cam_nums=m.cam_nums, ego_xyz=m.ego_xyz, width=int(W), height=int(H)))
     return frames
 
 
 # --------------------------------------------------------------------------- synthetic dataset on disk
 def write_synthetic_dataset(root, cfg: syn.SyntheticConfig, n_scenes=2, frames_per_scene=4, version="v1.0-synth",
-                            mask_subdir="mask_outputs/nuscenes-detic", lane_points=4000):
+                            mask_subdir="mask_outputs/nuscenes-detic", lane_points=4000, pool=0):
     """Writes `<root>/data/nuScenes/{<version>/*.json, sweeps/..., lanes/<loc>.npy}` and
     `<root>/<mask_subdir>/<scene>/<f>_{masks.pkl,data.json}` from synthetic frames.
+    pool > 0: only that many distinct frames are generated and reused in turn (large datasets for throughput runs).
     Returns (dataroot, mask_dir, scene_names)."""
+    made = {}
+
+    def frame_of(idx):
+        key = idx % pool if pool > 0 else idx
+        if key not in made:
+            made[key] = syn.make_frame(cfg, key)
+        return made[key]
     dataroot = os.path.join(root, "data", "nuScenes")
     mask_dir = os.path.join(root, mask_subdir)
     os.makedirs(os.path.join(dataroot, version), exist_ok=True)
@@ -178,7 +208,7 @@ def write_synthetic_dataset(root, cfg: syn.SyntheticConfig, n_scenes=2, frames_p
         first_center = None
         sample_tokens = [tok("sample", s, f) for f in range(frames_per_scene)]
         for f in range(frames_per_scene):
-            fr = syn.make_frame(cfg, s * 1000 + f)
+            fr = frame_of(s * 1000 + f)
             if first_center is None:
                 first_center = fr.ego_xyz[:2].copy()
             st = sample_tokens[f]

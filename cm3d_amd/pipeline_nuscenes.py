@@ -36,6 +36,7 @@ def _load_priors(path):
 
 
 _WORKER_TABLES = {}
+_WORKER_READER = None
 
 
 def prepare_scene_batch(task):
@@ -50,6 +51,47 @@ def prepare_scene_batch(task):
         _WORKER_TABLES[key] = nusc_io.NuscTables(version, dataroot)
     tables = _WORKER_TABLES[key]
     classes = lifting.ClassTable.nuscenes(priors)
+    native = task[9] if len(task) > 9 else None
+    through_shm = len(task) > 8 and task[8]
+    if isinstance(native, int):            # a reader process: its own loader with that many threads, created once
+        global _WORKER_READER
+        if _WORKER_READER is None or _WORKER_READER[0] != native:
+            from . import reader as rdmod
+            _WORKER_READER = (native, rdmod.Reader(native, pinned=False))
+        native = _WORKER_READER[1]
+    if native is not None:
+        # the native loader (libcm3d_reader.so): this thread only walks the tables and the small json files; sweeps and mask
+        # pickles of the whole batch are read and parsed by the loader's thread pool, into page-locked staging buffers
+        man, lanes, frame_lane = [], [], []
+        for k, name in enumerate(names):
+            scene = tables.scene_by_name(name)
+            ms = nusc_io.scene_manifest(tables, scene, mask_dir, n_sweeps=n_sweeps, ratio=ratio, missing_ok=missing_ok)
+            lanes.append(nusc_io.load_lane_points(tables.dataroot, tables.location(scene)))
+            man.extend(ms)
+            frame_lane.extend([k] * len(ms))
+        from .reader import ERR_FORMAT, ReaderError
+        segs = []
+
+        def shm_alloc(n_floats):                # the sweeps go straight from the page cache into the segment the parent maps
+            from multiprocessing import shared_memory
+            shm = shared_memory.SharedMemory(create=True, size=max(4 * int(n_floats), 16))
+            segs.append(shm)
+            return np.ndarray((int(n_floats),), np.float32, buffer=shm.buf)
+        try:
+            hb, _ = lifting.pack_manifest(man, lanes, frame_lane, classes, native, alloc=shm_alloc if through_shm else None)
+            if through_shm and hb is not None:
+                shape = hb.raw.shape
+                hb.raw = (segs[-1].name, shape)
+                for shm in segs[:-1]:              # a repack after dropping mask-less frames allocated twice
+                    shm.close(); shm.unlink()
+                segs[-1].close()
+            return [m.token for m in man], ([hb] if hb is not None else []), time.time() - t0
+        except ReaderError as exc:
+            if exc.code != ERR_FORMAT:
+                raise                 # a pickle the native parser does not know: the Python reader below takes the batch
+        except ValueError as exc:
+            if "share mask size" not in str(exc):
+                raise                 # frames with different mask sizes: the Python reader below groups them
     frames, lanes, frame_lane = [], [], []
     for k, name in enumerate(names):
         scene = tables.scene_by_name(name)
@@ -64,7 +106,7 @@ def prepare_scene_batch(task):
     for (W, H) in sorted({(frames[i].width, frames[i].height) for i in live}):
         sel = [i for i in live if (frames[i].width, frames[i].height) == (W, H)]
         batches.append(lifting.pack_frames([frames[i] for i in sel], lanes, [frame_lane[i] for i in sel], classes))
-    if len(task) > 8 and task[8]:           # reader process: the sweeps (nearly all of the bytes) go through shared memory
+    if through_shm:                         # reader process: the sweeps (nearly all of the bytes) go through shared memory
         from multiprocessing import shared_memory
         for hb in batches:
             shm = shared_memory.SharedMemory(create=True, size=max(hb.raw.nbytes, 16))
@@ -95,48 +137,63 @@ def _release(keep):
     keep.clear()
 
 
+def sample_tokens(tables, scene_names):
+    """The job's sample tokens in output order (scenes in the given order, samples in scene order): every rank derives the
+    same list from the tables alone, so a shipped record only needs its index into it."""
+    return [s["token"] for name in scene_names for s in tables.samples_of_scene(tables.scene_by_name(name))]
+
+
 def lift_scenes(tables, scene_names, mask_dir, classes, device, n_sweeps=3, ratio=0.64, masks="rle", timer=None,
-                scenes_per_batch=4, missing_ok=False, workers=0, priors=None):
-    """Runs the hot path over the given scenes; returns {sample_token: [box dict, ...]} in sample order.
+                scenes_per_batch=4, missing_ok=False, workers=0, priors=None, token_index=None, reader_threads=-1):
+    """Runs the hot path over the given scenes; returns the kept-box records of all their frames as ONE device tensor
+    (lifting.kept_box_records; column 5 = token_index[sample token], default: the index into sample_tokens(scene_names)).
     workers > 0: that many reader processes prepare the batches (prepare_scene_batch: file reads, RLE strings,
     packing -- single-threaded Python does ~360 frames/s of it, the GPU loop 63 k) while this process only uploads,
     launches and collects; each reader loads the tables itself."""
     timer = timer if timer is not None else {}
-    results = {}
+    if token_index is None:
+        token_index = {t: i for i, t in enumerate(sample_tokens(tables, scene_names))}
+    records = []
     pipe = lifting.LiftPipeline(device, depth=2, classes=classes)      # batch i+1 is uploaded while batch i runs
-    pending = []                                                       # slots in flight, oldest first
+    pending = []                                                       # (slot, frame ids) in flight, oldest first
 
     def drain(keep):
         while len(pending) > keep:
             t1 = time.time()
-            hb, res = pipe.collect(pending.pop(0), full=False)      # box records need the per-mask results only
+            slot, ids = pending.pop(0)
+            records.append(pipe.collect_records(slot, ids))           # stays on the device until the one gather at the end
             timer["gpu lifting"] = timer.get("gpu lifting", 0.0) + time.time() - t1
-            results.update(lifting.box_records(hb, res, classes))
 
     _WORKER_TABLES.setdefault((tables.version, tables.dataroot), tables)
     tasks = [(tables.version, tables.dataroot, mask_dir, list(scene_names[b0:b0 + scenes_per_batch]), n_sweeps, ratio, missing_ok, priors)
              for b0 in range(0, len(scene_names), scenes_per_batch)]
     pool, segments = None, []
+    if reader_threads >= 0 and workers <= 0:
+        from . import reader as rdmod
+        rd = rdmod.Reader(reader_threads)              # 0 = one thread per core
+        tasks = [t + (False, rd) for t in tasks]
     if workers > 0 and len(tasks) > 1:
         import multiprocessing as mp
-        pool = mp.get_context("spawn").Pool(min(workers, len(tasks)))       # spawn: the readers never inherit GPU state
-        prepared = pool.imap(prepare_scene_batch, [t + (True,) for t in tasks])
+        nproc = min(workers, len(tasks))
+        pool = mp.get_context("spawn").Pool(nproc)     # spawn: the readers never inherit GPU state
+        if reader_threads >= 0:                        # every reader process runs the native loader on its share of the cores
+            per = reader_threads if reader_threads > 0 else max(1, (os.cpu_count() or nproc) // nproc)
+            prepared = pool.imap(prepare_scene_batch, [t + (True, int(per)) for t in tasks])
+        else:
+            prepared = pool.imap(prepare_scene_batch, [t + (True,) for t in tasks])
     else:
         prepared = map(prepare_scene_batch, tasks)
     try:
         for tokens, batches, io_s in prepared:
             timer["io"] = timer.get("io", 0.0) + io_s
-            # frames without any mask produce no box but still own a key in the output (:735)
-            for tok in tokens:
-                results[tok] = []
             for hb in batches:
                 t1 = time.time()
                 _attach_raw(hb, segments)
                 drain(pipe.depth - 1)                                  # the slot about to be reused is free
-                pending.append(pipe.submit(hb, masks))
+                ids = np.array([[token_index[t], 0] for t in hb.tokens], np.float64)
+                pending.append((pipe.submit(hb, masks), ids))
                 if segments:                                           # the upload has copied the sweeps: free the segment
-                    torch.cuda.current_stream(pipe.dev).synchronize()
-                    pipe.streams[pending[-1]].synchronize()
+                    pipe.uploaded[pending[-1][0]].synchronize()        # (an event behind the H2D copies, not the whole pass)
                     hb.raw = None
                     _release(segments)
                 timer["gpu lifting"] = timer.get("gpu lifting", 0.0) + time.time() - t1
@@ -146,7 +203,9 @@ def lift_scenes(tables, scene_names, mask_dir, classes, device, n_sweeps=3, rati
         if pool is not None:
             pool.terminate()
             pool.join()
-    return results
+    if records:
+        return torch.cat(records, 0)
+    return torch.zeros(0, 10, dtype=torch.float64, device=device)
 
 
 def main(argv=None):
@@ -164,7 +223,10 @@ def main(argv=None):
     ap.add_argument("--missing-ok", action="store_true", help="frames without mask files yield no boxes instead of an error")
     ap.add_argument("--scenes-per-batch", type=int, default=4, help="scenes whose frames form one GPU batch")
     ap.add_argument("--workers", type=int, default=int(os.environ.get("CM3D_WORKERS", "0")),
-                    help="reader processes that read and pack the batches (0: in this process)")
+                    help="reader processes that read and pack the batches with the Python reader (0: in this process)")
+    ap.add_argument("--reader-threads", type=int, default=int(os.environ.get("CM3D_READER_THREADS", "0")),
+                    help="threads of the native loader (libcm3d_reader.so) that reads sweeps and mask files; 0 = one per core, "
+                         "-1 = the Python reader (pickle.load / np.fromfile per frame, like the reference)")
     args = ap.parse_args(argv)
 
     total_start = time.time()
@@ -184,20 +246,22 @@ def main(argv=None):
     # scene-aligned sharding: each rank loads only its scenes' lane tables
     sizes = [tables.scene_by_name(n)["nbr_samples"] for n in names]
     lo, hi = cdist.shard_scenes(sizes, world)[rank]
+    tokens = sample_tokens(tables, names)                  # the whole job's samples, identical on every rank
     mine = lift_scenes(tables, names[lo:hi], args.mask_dir, classes, device, args.n_sweeps, args.ratio, args.masks, timer,
-                       missing_ok=args.missing_ok, workers=args.workers, priors=priors, scenes_per_batch=max(1, args.scenes_per_batch))
+                       missing_ok=args.missing_ok, workers=args.workers, priors=priors, scenes_per_batch=max(1, args.scenes_per_batch),
+                       token_index={t: i for i, t in enumerate(tokens)}, reader_threads=args.reader_threads)
 
+    # the single exchange of the job: fixed-size box records -> rank 0 (one RCCL all_gather of payload; also the path of a
+    # one-rank run).  Ranks hold contiguous scene blocks, so rank order is sample order.
     t0 = time.time()
+    gathered = cdist.gather_records(mine, dst=0)
     if world > 1:
-        gathered = [None] * world if rank == 0 else None
-        torch.distributed.gather_object(mine, gathered, dst=0)
-        if rank != 0:
-            return 0
-        results = {}
-        for part in gathered:
-            results.update(part)
-    else:
-        results = mine
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank != 0:
+        return 0
+    rec = torch.cat([g.cpu() for g in gathered], 0).numpy()
+    results = lifting.nuscenes_boxes_from_records(rec, tokens, classes)
     timer["gather"] = time.time() - t0
 
     final_predictions = {"meta": dict(META), "results": results}

@@ -58,8 +58,10 @@ def load_scene(frames_dir, mask_dir, scene):
     return frames, lane_table
 
 
-def lift_scene(eng, frames, lane_table, classes, masks="rle"):
-    objs = []
+def lift_scene(eng, frames, lane_table, classes, masks="rle", scene_index=0):
+    """One scene through the hot path; returns its kept-box records as device tensors (lifting.kept_box_records with
+    column 5 = scene_index, column 6 = the frame's number inside the scene), one tensor per image size."""
+    recs = []
     by_size = {}
     for f in frames:
         by_size.setdefault((f.width, f.height), []).append(f)     # Waymo has two image sizes (:520-523)
@@ -70,12 +72,30 @@ def lift_scene(eng, frames, lane_table, classes, masks="rle"):
             eng.decode_masks_dense()
         eng.run(masks=masks)
         torch.cuda.synchronize()
-        res = eng.download(full=False)      # objects need boxes and flags only
-        objs.append((hb, res, [(f.context_name, f.timestamp_micros) for f in fs]))
-    encoded = []
-    for hb, res, meta in objs:
-        encoded.extend(wm.objects_from_results(hb, res, classes, meta))
-    return encoded
+        eng.check_status()
+        ids = np.array([[scene_index, int(f.token.rsplit(":", 1)[1])] for f in fs], np.float64)
+        recs.append(lifting.kept_box_records(eng.b, ids))
+    return recs
+
+
+def objects_from_records(rec, scenes, frames_dir, classes):
+    """Gathered records -> encoded metrics_pb2.Object payloads in the reference's order (scenes in order, frames in
+    order, kept boxes in mask order; src/waymo/2d_to_3d.py:1034-1065,1262-1297).  The frame's context name and timestamp
+    (:1050-1051) come from its extracted-frame file; the records only carry (scene index, frame number)."""
+    rec = np.asarray(rec, np.float64).reshape(-1, 10)
+    order = np.lexsort((np.arange(len(rec)), rec[:, lifting.REC_FRAME_B], rec[:, lifting.REC_FRAME_A]))     # stable inside a frame
+    meta, out = {}, []
+    for r in rec[order]:
+        key = (int(r[lifting.REC_FRAME_A]), int(r[lifting.REC_FRAME_B]))
+        if key not in meta:
+            z = np.load(os.path.join(frames_dir, scenes[key[0]], f"{key[1]}_frame.npz"), allow_pickle=False)
+            meta[key] = (str(z["context_name"]), int(z["timestamp_micros"]))
+        ctx, ts = meta[key]
+        ci = int(r[8])
+        pr = classes.prior_wlh[ci]
+        out.append(wm.encode_object(r[0:3], length=pr[1], width=pr[0], height=pr[2], heading=r[3],
+                                    type_id=wm.WAYMO_TYPE[classes.out_names[ci]], score=r[7], context_name=ctx, timestamp_micros=ts))
+    return out
 
 
 def main(argv=None):
@@ -89,24 +109,29 @@ def main(argv=None):
     args = ap.parse_args(argv)
     t0 = time.time()
     rank, world, local_rank = cdist.init_from_env()
+    if os.environ.get("CM3D_SINGLE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box (with CM3D_DIST_BACKEND=gloo)
+        local_rank = 0
     scenes = [s for s in args.scenes.split(",") if s] or sorted(os.listdir(args.frames_dir))
     pri = json.load(open(args.priors)) if os.path.exists(args.priors) else None
     classes = lifting.ClassTable.waymo(pri)
     eng = lifting.LiftEngine(f"cuda:{local_rank}", classes=classes)
     lo, hi = cdist.shard_range(len(scenes), rank, world)
     mine = []
-    for scene in scenes[lo:hi]:
-        frames, lanes = load_scene(args.frames_dir, args.mask_dir, scene)
+    for si in range(lo, hi):
+        frames, lanes = load_scene(args.frames_dir, args.mask_dir, scenes[si])
         if frames:
             if lanes is None:
-                raise FileNotFoundError(f"{scene}: no lane polylines (frame 0)")
-            mine.extend(lift_scene(eng, frames, lanes, classes, args.masks))
+                raise FileNotFoundError(f"{scenes[si]}: no lane polylines (frame 0)")
+            mine.extend(lift_scene(eng, frames, lanes, classes, args.masks, scene_index=si))
+    rec = torch.cat(mine, 0) if mine else torch.zeros(0, 10, dtype=torch.float64, device=eng.dev)
+    # the single exchange of the job: fixed-size box records -> rank 0 (also the path of a one-rank run)
+    gathered = cdist.gather_records(rec, dst=0)
     if world > 1:
-        gathered = [None] * world if rank == 0 else None
-        torch.distributed.gather_object(mine, gathered, dst=0)
-        if rank != 0:
-            return 0
-        mine = [o for part in gathered for o in part]
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank != 0:
+        return 0
+    mine = objects_from_records(torch.cat([g.cpu() for g in gathered], 0).numpy(), scenes, args.frames_dir, classes)
     os.makedirs(os.path.dirname(os.path.abspath(args.output)), exist_ok=True)
     with open(args.output, "wb") as f:
         f.write(wm.encode_objects(mine))

@@ -61,27 +61,23 @@ def test_nuscenes_entry_point_end_to_end(tmp_path, oracle):
     assert 0.0 < summary["mean_ap"] <= 1.0
 
 
-def test_waymo_entry_point(tmp_path, oracle):
-    """src/waymo/2d_to_3d.py on extracted-frame files, against the oracle on the same files."""
+def _write_waymo_scene(tmp_path, scene, first, count):
+    """Extracted-frame files + mask files of one synthetic Waymo scene (frames first .. first+count-1 of the generator)."""
     import pickle
-    from cm3d_amd import lifting, pipeline_waymo as pw, synthetic as syn, waymo as wm
-    from tests.helpers import oracle_batch
+    from cm3d_amd import geometry as geo, synthetic as syn
     cfg = syn.config("tiny", n_cams=5)
-    scene = "segment-synthetic-0"
     fdir, mdir = tmp_path / "frames" / scene, tmp_path / "masks" / scene
     os.makedirs(fdir); os.makedirs(mdir)
-    rng = np.random.default_rng(3)
     centre = None
-    for i in range(3):
-        fr = syn.make_waymo_frame(cfg, i)
+    for i in range(count):
+        fr = syn.make_waymo_frame(cfg, first + i)
         P = np.asarray(fr.pose).reshape(4, 4)
         centre = P[:2, 3] if centre is None else centre
         # recover the raw calibration the frame was built from (the generator keeps it in the record only)
         S = np.array([[0, -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float64)
-        base = syn.make_frame(cfg, i)
+        base = syn.make_frame(cfg, first + i)
         ext, intr = [], []
         for c in range(base.cams.shape[0]):
-            from cm3d_amd import geometry as geo
             t_cs_neg, R_csT, _ = geo.cam_stage(base.cams[c], 1)
             T = np.eye(4); T[:3, :3] = R_csT.T; T[:3, 3] = -t_cs_neg
             K = geo.cam_K(base.cams[c]) / cfg.ratio
@@ -94,6 +90,14 @@ def test_waymo_entry_point(tmp_path, oracle):
         np.savez_compressed(fdir / f"{i}_frame.npz", **rec)
         pickle.dump(fr.rles, open(mdir / f"{i}_masks.pkl", "wb"))
         json.dump({"labels": fr.labels, "detection_scores": fr.scores, "cam_nums": fr.cam_nums}, open(mdir / f"{i}_data.json", "w"))
+
+
+def test_waymo_entry_point(tmp_path, oracle):
+    """src/waymo/2d_to_3d.py on extracted-frame files, against the oracle on the same files."""
+    from cm3d_amd import lifting, pipeline_waymo as pw, waymo as wm
+    from tests.helpers import oracle_batch
+    scene = "segment-synthetic-0"
+    _write_waymo_scene(tmp_path, scene, 0, 3)
     out = tmp_path / "out" / "pred.bin"
     r = subprocess.run([sys.executable, "2d_to_3d.py", "--frames-dir", str(tmp_path / "frames"), "--mask-dir", str(tmp_path / "masks"),
                         "--output", str(out)], cwd=os.path.join(ROOT, "src", "waymo"), capture_output=True, text=True, timeout=600)
@@ -188,3 +192,23 @@ def test_nuscenes_entry_point_two_ranks(tmp_path):
     two = json.load(open(tmp_path / "two" / "pseudolabels_minival.json"))
     assert list(one["results"]) == list(two["results"]) and len(one["results"]) == 6
     assert one == two and sum(len(v) for v in one["results"].values()) > 10
+
+
+def test_waymo_entry_point_two_ranks(tmp_path):
+    """The N>1 path of the Waymo entry point: two ranks (gloo, both on the one GPU of the box) shard the scenes, one
+    exchange of box records, rank 0 writes; the file must equal the single-process one byte for byte."""
+    for k in range(3):
+        _write_waymo_scene(tmp_path, f"segment-synthetic-{k}", 10 * k, 2)
+    cwd = os.path.join(ROOT, "src", "waymo")
+    args = ["--frames-dir", str(tmp_path / "frames"), "--mask-dir", str(tmp_path / "masks")]
+    r = subprocess.run([sys.executable, "2d_to_3d.py", *args, "--output", str(tmp_path / "one.bin")], cwd=cwd, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, CM3D_DIST_BACKEND="gloo", CM3D_SINGLE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29722", "2d_to_3d.py", *args, "--output", str(tmp_path / "two.bin")], cwd=cwd, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one, two = open(tmp_path / "one.bin", "rb").read(), open(tmp_path / "two.bin", "rb").read()
+    from cm3d_amd import waymo as wm
+    assert one == two and len(wm.decode_objects(one)) > 5

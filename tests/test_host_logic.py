@@ -149,6 +149,64 @@ def test_shard_helpers():
     assert max(loads) <= 1.5 * sum(sizes) / 4
 
 
+def test_c3_partition_covers_trainval_exactly_once():
+    """BASELINE config C3: the 28 130 keyframes / 850 scenes of nuScenes-trainval over 8 ranks (also 1, 2, 4): every frame
+    and every scene is owned by exactly one rank, in order, and the frame loads are balanced."""
+    from cm3d_amd import dist
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(26, 41, 850)                         # nuScenes scenes hold ~33 keyframes on average
+    while sizes.sum() != 28130:                               # total as in BASELINE.md
+        k = rng.integers(0, 850)
+        sizes[k] += 1 if sizes.sum() < 28130 else -1
+    assert sizes.sum() == 28130 and sizes.min() > 0
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    for world in (1, 2, 4, 8):
+        owner = np.full(28130, -1)
+        for rank in range(world):
+            a, b = dist.shard_range(28130, rank, world)
+            assert np.all(owner[a:b] == -1)
+            owner[a:b] = rank
+        assert np.all(owner >= 0) and np.all(np.diff(owner) >= 0)
+        counts = np.bincount(owner, minlength=world)
+        assert counts.max() - counts.min() <= 1
+        bounds = dist.shard_scenes([int(x) for x in sizes], world)
+        assert len(bounds) == world and bounds[0][0] == 0 and bounds[-1][1] == 850
+        assert all(x[1] == y[0] for x, y in zip(bounds, bounds[1:])) and all(lo < hi for lo, hi in bounds)
+        loads = np.array([starts[hi] - starts[lo] for lo, hi in bounds])
+        assert loads.sum() == 28130 and loads.max() <= 28130 / world + 42          # within one scene of the ideal share
+        # more ranks than scenes: trailing ranks own nothing, nothing is lost
+        few = dist.shard_scenes([40, 40, 40], 8)
+        assert [hi - lo for lo, hi in few].count(1) == 3 and sum(hi - lo for lo, hi in few) == 3
+
+
+def test_gathered_records_rebuild_the_box_dicts():
+    """The single exchange ships kept-box records (lifting.kept_box_records); rank 0 rebuilds the output dicts from them and
+    the job's token order (lifting.nuscenes_boxes_from_records): same result as building them from the per-mask arrays."""
+    import torch
+    from types import SimpleNamespace
+    from cm3d_amd import lifting
+    cfg = syn.config("tiny")
+    frames = [syn.make_frame(cfg, i) for i in range(3)]
+    hb = lifting.pack_frames(frames, [syn.make_lane_table([600, 1600], 100, seed=0)], [0, 0, 0])
+    M = hb.n_masks
+    rng = np.random.default_rng(1)
+    flags = rng.choice([0, 1, 3], M).astype(np.int32)
+    box = rng.normal(0, 50, (M, 10))
+    box[:, 7], box[:, 8], box[:, 9] = hb.score, hb.class_id, flags
+    want = lifting.box_records(hb, {"flags": flags, "box": box})
+    # the job has two more samples in front of this batch's three (records carry the global sample index)
+    tokens = ["other-0", "other-1"] + hb.tokens
+    b = SimpleNamespace(flags=torch.from_numpy(flags), box=torch.from_numpy(box), mask_frame=torch.from_numpy(hb.mask_frame))
+    rec = lifting.kept_box_records(b, np.array([[2 + f, 0] for f in range(3)], np.float64))
+    assert rec.shape == (int((flags == 3).sum()), 10) and rec.dtype == torch.float64
+    # split over two "ranks" and concatenated in rank order, as gather_records returns them
+    parts = [rec[:4], rec[4:]]
+    got = lifting.nuscenes_boxes_from_records(torch.cat(parts, 0).numpy(), tokens)
+    assert list(got) == tokens and got["other-0"] == [] and got["other-1"] == []
+    assert {t: got[t] for t in hb.tokens} == want
+    json.dumps(got)
+
+
 def test_prepare_scene_batch_in_reader_processes(tmp_path):
     """pipeline_nuscenes.prepare_scene_batch (file reads + RLE strings + packing; no GPU) gives the same host batches in
     spawned reader processes as in this process."""
