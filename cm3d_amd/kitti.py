@@ -119,6 +119,11 @@ def obb_yaw(pts3d):
     return float(Rotation.from_matrix(Rm).as_euler("zyx")[0])
 
 
+# src/kitti/2d_to_3d.py:105-116: what get_detection_name (:183-197) finally returns -- the KITTI class written to the label file
+KITTI_CLASS_MAPS = {"car": "Car", "pedestrian": "Pedestrian", "truck": "Truck", "bus": "Tram", "traffic_cone": "Misc",
+                    "construction_vehicle": "Misc", "bicycle": "Cyclist", "motorcycle": "Cyclist", "trailer": "Misc", "barrier": "Misc"}
+
+
 def label_line(object_type, wlh, xyz, yaw, conf=None, truncation=-1, occlusion=-1, alpha=-10):
     """save_pred (:879-885); the 2D box is written as 0 0 0 0 (:1535-1536)."""
     ltrb = [0, 0, 0, 0]
@@ -141,8 +146,10 @@ def labels_of_frame(hb, res, f, classes, shape_priors):
         except Exception:                                # :1481-1484: bare except -> identity box
             yaw = 0.0
         label = hb.labels[f][m - hb.mask_off[f]]
-        name = get_detection_name(label)
-        wlh = shape_priors[name]
+        name = KITTI_CLASS_MAPS[get_detection_name(label)]       # :1523, :183-197: the label file carries the KITTI class
+        # :1530 looks the prior up by the RAW label; for the three spellings get_detection_name renames (trafficcone,
+        # constructionvehicle, human) the reference's table has no key and it raises -- here the renamed key is used
+        wlh = shape_priors[label] if label in shape_priors else shape_priors[get_detection_name(label)]
         wlh = [wlh[2], wlh[0], wlh[1]]                   # :1530-1531
         c = [float(v) for v in res["centroid"][m]]
         center = [c[0], c[1] + wlh[0] / 2, c[2]]         # :1533

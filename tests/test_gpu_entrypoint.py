@@ -137,13 +137,27 @@ def test_kitti_entry_point(tmp_path, oracle):
     r = subprocess.run([sys.executable, "2d_to_3d.py", "--kitti-dir", str(kdir), "--mask-dir", str(mdir), "--ratio", str(cfg.ratio)],
                        cwd=os.path.join(ROOT, "src", "kitti"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    # expectation: the oracle over the frames as the entry point loads them, through the same label writer
+    from cm3d_amd import kitti as kt, lifting
+    from tests.helpers import oracle_batch
+    frames = []
+    for i in range(3):
+        rles = pickle.load(open(mdir / f"{i}_masks.pkl", "rb"))
+        data = json.load(open(mdir / f"{i}_data.json"))
+        frames.append(kt.frame_from_files(i, str(kdir / "training" / "velodyne" / f"{i:06d}.bin"), str(kdir / "training" / "calib" / f"{i:06d}.txt"),
+                                          rles, data["labels"], data["detection_scores"], cfg.ratio))
+    hb = lifting.pack_frames(frames, [[[0.0, 0.0, 0.0]]], [0] * 3)
+    exp = oracle_batch(oracle, frames, [np.zeros((1, 3))], [0] * 3, hb)
+    per_mask_frame = np.repeat(np.arange(3), np.diff(hb.mask_off))
+    exp["hit_xyz"] = exp["points"][np.repeat(exp["pt_off"][per_mask_frame], np.diff(exp["hit_off"])) + exp["hit_idx"]]
     total = 0
     for i in range(3):
         pred = open(kdir / "training" / "pred" / f"{i:06d}.txt").read().splitlines()
         pseudo = open(kdir / "training" / "pseudo" / f"{i:06d}.txt").read().splitlines()
-        assert len(pred) == len(pseudo)
+        want_pred, want_pseudo = kt.labels_of_frame(hb, exp, i, lifting.ClassTable.nuscenes(), lifting.SHAPE_PRIORS_CHATGPT)
+        assert pred == [l.rstrip("\n") for l in want_pred] and pseudo == [l.rstrip("\n") for l in want_pseudo], i
         for a, b in zip(pred, pseudo):
-            assert a.rsplit(" ", 1)[0] == b and len(a.split()) == 16
+            assert a.rsplit(" ", 1)[0] == b and len(a.split()) == 16 and a.split()[0] in kt.KITTI_CLASS_MAPS.values()
         total += len(pred)
     assert total > 3 and f"wrote {total} labels" in r.stdout
 

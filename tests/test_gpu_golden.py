@@ -29,6 +29,55 @@ def test_g2_index_lists_from_reference_body():
                 assert np.array_equal(lists[m], g[f"idx{k}"][ioff[m]:ioff[m + 1]]), f"frame {k} mask {m} ({path})"
 
 
+def test_g2b_reference_resolution_frame_index_lists():
+    """G2 at the reference's own configuration (104 k points, 1024x576 masks at ratio 0.64, 24 masks): the whole-frame kernel
+    path -- fused sweep preparation, projection, compaction -- against the index lists the reference's loop body produced."""
+    import torch
+    from cm3d_amd import lifting, synthetic as syn
+    from tests.test_oracle_golden import _g2b_frame
+    cfg, f, P, g = _g2b_frame()
+    lanes = [syn.make_lane_table(f.ego_xyz[:2], 2000, seed=1)]
+    hb = lifting.pack_frames([f], lanes, [0])
+    for masks in ("rle", "dense"):
+        eng = lifting.LiftEngine(keep_cloud=masks == "dense")
+        eng.upload(hb)
+        if masks == "dense":
+            eng.decode_masks_dense()
+        eng.run(masks=masks)
+        torch.cuda.synchronize()
+        got = eng.download()
+        assert np.array_equal(got["hit_off"], g["idx_off"]) and np.array_equal(got["hit_idx"], g["idx"]), masks
+        assert np.array_equal(got["hit_xyz"].view(np.uint32), P[g["idx"]].view(np.uint32))
+
+
+def test_g3b_medoid_on_real_in_mask_lists():
+    """The reference's get_medoid on 351 real in-mask lists (global-frame magnitudes, a third with duplicated rows, up to
+    2284 points): the kernel -- all lists in ONE call, laid out like the compaction's hit_xyz, two-pass route for the long
+    ones -- returns the reference's index on every list; the row-gather form agrees on a sample."""
+    import torch
+    from cm3d_amd import _lib, ops
+    g = np.load(os.path.join(G, "g3b_medoid_lists.npz"))
+    off = g["off"].astype(np.int32)
+    n, tot = len(off) - 1, int(off[-1])
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    xyz = torch.zeros(tot, 4, dtype=torch.float32, device=dev)
+    xyz[:, :3] = torch.from_numpy(g["pts"]).to(dev)
+    hit_off = torch.from_numpy(off).to(dev)
+    tiles = (np.diff(off) + _lib.MEDOID_TILE - 1) // _lib.MEDOID_TILE
+    tile_off = torch.from_numpy(np.concatenate([[0], np.cumsum(tiles)]).astype(np.int32)).to(dev)
+    med, cen = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, 3, dtype=torch.float32, device=dev)
+    ws = torch.empty(int(L.cm3d_medoid_workspace_bytes(n, tot)), dtype=torch.uint8, device=dev)
+    _lib.check(L.cm3d_medoid(xyz.data_ptr(), 0, 0, n, hit_off.data_ptr(), tile_off.data_ptr(), 0, tot, 0, med.data_ptr(), cen.data_ptr(), 0,
+                             ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "cm3d_medoid")
+    got = med.cpu().numpy()
+    assert np.array_equal(got, g["ref_index"]), np.flatnonzero(got != g["ref_index"])
+    assert np.array_equal(cen.cpu().numpy().view(np.uint32), g["pts"][off[:-1] + g["ref_index"]].view(np.uint32))
+    for k in list(range(0, n, 17)) + [int(np.argmax(np.diff(off)))]:
+        p = g["pts"][off[k]:off[k + 1]]
+        assert ops.get_medoid(p.T, via_rows=True) == int(g["ref_index"][k]) == ops.get_medoid(p.T), k
+
+
 def test_g3_get_medoid():
     from cm3d_amd import ops
     cases = json.load(open(os.path.join(G, "g3_medoid.json")))

@@ -270,6 +270,34 @@ def test_wider_sample_against_oracle(oracle):
     _compare(hb, got, exp)
 
 
+def _check_batch_properties(hb, a):
+    """Size-independent properties of one downloaded pass (shapes too large for the oracle)."""
+    F = hb.n_frames
+    off, idx = a["hit_off"], a["hit_idx"]
+    assert off[0] == 0 and off[-1] == idx.size and np.all(np.diff(off) >= 0)
+    # ascending inside every list, inside the frame's point range
+    starts = np.zeros(idx.size, bool); starts[off[:-1][np.diff(off) > 0]] = True
+    assert np.all((np.diff(idx) > 0) | starts[1:])
+    n_pts = np.diff(a["pt_off"])
+    per_mask_frame = np.repeat(np.arange(F), np.diff(hb.mask_off))
+    cnt = np.diff(off)
+    assert np.all(idx >= 0) and np.all(idx < np.repeat(n_pts[per_mask_frame], cnt))
+    # the reference drops the ego-box rows: what is left is what the frame's sweeps hold minus those rows
+    raw_per_frame = np.diff(hb.sweep_row_off[hb.frame_sweep_off])
+    assert np.all(n_pts <= raw_per_frame) and (not hb.ego_box or n_pts.sum() < raw_per_frame.sum())
+    # medoid position inside its list, exactly the masks with points have a centroid
+    mp = a["medoid_pos"]
+    assert np.array_equal(mp >= 0, cnt > 0) and np.all(mp[cnt > 0] < cnt[cnt > 0])
+    # the centroid is the medoid point of the mask's in-mask points, and those are finite global-frame coordinates
+    sel = np.nonzero(cnt > 0)[0]
+    pts = a["hit_xyz"][off[sel] + mp[sel]]
+    assert np.array_equal(pts[:, :3].view(np.uint32), a["centroid"][sel].view(np.uint32))
+    assert np.all(np.isfinite(a["hit_xyz"][:, :3]))
+    # a box exists (bit 0) exactly for the masks with points; NMS (bit 1) keeps a subset of them
+    assert np.array_equal((a["flags"] & 1) != 0, cnt > 0) and np.all(((a["flags"] & 2) == 0) | (cnt > 0))
+    return cnt
+
+
 def test_full_size_batch_properties():
     """BASELINE's full C2 batch (256 frames x 35 k points x 20 masks of 1600x900), too large for the oracle: the two
     independent mask paths (run lengths -> packed, and run lengths -> dense bytes -> packed) must give identical
@@ -298,25 +326,70 @@ def test_full_size_batch_properties():
     for k in a:
         assert np.array_equal(a[k], a2[k], equal_nan=True), f"second pass differs in {k}"
         assert np.array_equal(a[k], b[k], equal_nan=True), f"mask paths differ in {k}"
-    off, idx = a["hit_off"], a["hit_idx"]
-    assert off[0] == 0 and off[-1] == idx.size and np.all(np.diff(off) >= 0) and idx.size > 200000
-    # ascending inside every list, inside the frame's point range
-    starts = np.zeros(idx.size, bool); starts[off[:-1][np.diff(off) > 0]] = True
-    assert np.all((np.diff(idx) > 0) | starts[1:])
-    n_pts = np.diff(a["pt_off"])
+    _check_batch_properties(hb, a)
+    assert a["hit_idx"].size > 200000 and int(((a["flags"] & 3) == 3).sum()) > 2000
+    # with the cloud materialised (keep_cloud) every result is the same, and the cloud's rows are the listed coordinates
+    eng2 = lifting.LiftEngine(keep_cloud=True)
+    eng2.upload(hb)
+    eng2.run(masks="rle")
+    torch.cuda.synchronize()
+    c = eng2.download()
+    for k in a:
+        assert np.array_equal(a[k], c[k], equal_nan=True), f"keep_cloud changes {k}"
     per_mask_frame = np.repeat(np.arange(F), np.diff(hb.mask_off))
-    cnt = np.diff(off)
-    assert np.all(idx >= 0) and np.all(idx < np.repeat(n_pts[per_mask_frame], cnt))
-    # medoid position inside its list, exactly the masks with points have a centroid
-    mp = a["medoid_pos"]
-    assert np.array_equal(mp >= 0, cnt > 0) and np.all(mp[cnt > 0] < cnt[cnt > 0])
-    # the centroid is the medoid point of the frame's (reference-order) cloud
-    sel = np.nonzero(cnt > 0)[0]
-    pts = a["hit_xyz"][off[sel] + mp[sel]]
-    assert np.array_equal(pts[:, :3].view(np.uint32), a["centroid"][sel].view(np.uint32))
-    # a box exists (bit 0) exactly for the masks with points; NMS (bit 1) keeps a subset of them
-    assert np.array_equal((a["flags"] & 1) != 0, cnt > 0) and np.all(((a["flags"] & 2) == 0) | (cnt > 0))
-    assert int(((a["flags"] & 3) == 3).sum()) > 2000
+    base = np.repeat(c["pt_off"][per_mask_frame], np.diff(c["hit_off"]))
+    assert np.array_equal(c["points"][base + c["hit_idx"]].view(np.uint32), c["hit_xyz"].view(np.uint32))
+
+
+def _full_size(cfg_name, n_batch, oracle):
+    """One BASELINE shape at full size: frame 0 against the oracle (everything _compare checks), a batch of n_batch frames
+    through the size-independent properties, and a second pass that must reproduce the first bit for bit."""
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config(cfg_name)
+    frames = [syn.make_frame(cfg, 7000 + i) for i in range(n_batch)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 50000, seed=5, extent=400.0)]
+    hb = lifting.pack_frames(frames, lanes, [0] * n_batch)
+    eng = lifting.LiftEngine()
+    eng.upload(hb)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    a = eng.download()
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    a2 = eng.download()
+    for k in a:
+        assert np.array_equal(a[k], a2[k], equal_nan=True), f"second pass differs in {k}"
+    cnt = _check_batch_properties(hb, a)
+    # frame 0 alone, against the oracle
+    hb1 = lifting.pack_frames(frames[:1], lanes, [0])
+    eng1 = lifting.LiftEngine(keep_colsum=True, keep_cloud=True)
+    eng1.upload(hb1)
+    eng1.run(masks="rle")
+    torch.cuda.synchronize()
+    got = eng1.download()
+    exp = oracle_batch(oracle, frames[:1], lanes, [0], hb1)
+    _compare(hb1, got, exp)
+    # ... and frame 0 inside the batch gives what it gives alone
+    m1 = hb1.n_masks
+    assert np.array_equal(a["hit_off"][:m1 + 1], got["hit_off"]) and np.array_equal(a["hit_idx"][:got["hit_idx"].size], got["hit_idx"])
+    assert np.array_equal(a["medoid_pos"][:m1], got["medoid_pos"]) and np.array_equal(a["flags"][:m1], got["flags"])
+    return hb, a, cnt
+
+
+def test_c4_waymo_shape_at_full_size(oracle):
+    """BASELINE C4: 180 k points, 5 cameras, 20 masks of 1920x1280 per frame."""
+    hb, a, cnt = _full_size("c4", 12, oracle)
+    assert hb.n_raw_rows == 12 * 180000 and (hb.width, hb.height, hb.n_cams) == (1920, 1280, 5)
+    assert a["hit_idx"].size > 20000
+
+
+def test_c5_ten_sweeps_eighty_masks_at_full_size(oracle):
+    """BASELINE C5: 10 sweeps x 35 k points and 80 masks of 1600x900 per frame (3 hit-word planes, lists of thousands of
+    points: the two-pass medoid on the batch, the exact one -- keep_colsum -- on the frame compared with the oracle)."""
+    hb, a, cnt = _full_size("c5", 6, oracle)
+    assert hb.n_raw_rows == 6 * 350000 and int(np.diff(hb.mask_off).max()) == 80 and int(np.diff(hb.frame_sweep_off).max()) == 10
+    assert cnt.max() > 512 and a["hit_idx"].size > 100000
 
 
 def test_waymo_pipeline(oracle):

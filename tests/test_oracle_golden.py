@@ -40,6 +40,51 @@ def test_g2_index_lists_bit_exact(oracle):
     assert total > 1000
 
 
+def _g2b_frame():
+    """The frame tests/golden/gen_golden_wide.py ran the reference's loop body on, rebuilt from the committed generator and
+    pinned by the fixture's checksum (inputs are not stored: 104 k float32 points do not compress)."""
+    g = np.load(os.path.join(G, "g2b_c1_frame.npz"))
+    fs = json.loads(str(g["spec"]))
+    from cm3d_amd import rle, synthetic as syn
+    from oracle import oracle as orc
+    cfg = syn.config(fs["config"], **fs["over"])
+    f = syn.make_frame(cfg, fs["index"])
+    P = np.concatenate([orc.sweep_prep(r, x[0:9], x[9:12], x[12:21], x[21:24]) for r, x in zip(f.sweeps_raw, f.sweep_xf)], 0)
+    import hashlib
+    h = hashlib.sha256()
+    for a in [P, f.cams, np.array(f.cam_nums, np.int32)] + [rle.string_to_counts(r["counts"]) for r in f.rles]:
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest() == str(g["sha256"]), "the synthetic generator changed: regenerate tests/golden/g2b_c1_frame.npz"
+    return cfg, f, P, g
+
+
+def test_g2b_reference_resolution_frame_index_lists(oracle):
+    """G2 at the reference's own configuration: 3 sweeps (104 k points), 6 cameras, 24 masks of 1024x576 at ratio 0.64."""
+    from cm3d_amd import rle
+    cfg, f, P, g = _g2b_frame()
+    assert (cfg.width, cfg.height) == (1024, 576) and P.shape[0] == int(g["n_points"]) > 100000 and len(f.rles) == 24
+    off = g["idx_off"]
+    for m, (r, c) in enumerate(zip(f.rles, f.cam_nums)):
+        mask = rle.counts_to_dense(rle.string_to_counts(r["counts"]), f.width, f.height)
+        got = oracle.points_in_mask(P, f.cams[c], oracle.erode3x3(mask))
+        assert np.array_equal(got, g["idx"][off[m]:off[m + 1]]), f"mask {m}"
+    assert off[-1] > 5000
+
+
+def test_g3b_medoid_on_real_in_mask_lists(oracle):
+    """The reference's get_medoid on 351 in-mask lists of c1-shaped frames at global-frame magnitudes (117 of them with
+    duplicated rows): the oracle -- sequential float32 column sums where torch uses a cascade sum -- picks the same index on
+    every one of them (tests/golden/gen_report.json records the rate the generator saw)."""
+    g = np.load(os.path.join(G, "g3b_medoid_lists.npz"))
+    off = g["off"]
+    assert len(off) - 1 >= 300 and int(g["has_duplicates"].sum()) >= 100 and int(np.diff(off).max()) > 2000
+    assert np.array_equal(g["ref_index"], g["oracle_index"])
+    for k in range(len(off) - 1):
+        p = g["pts"][off[k]:off[k + 1]]
+        P4 = np.concatenate([p, np.zeros((p.shape[0], 1), np.float32)], 1)
+        assert oracle.medoid(P4, np.arange(p.shape[0])) == int(g["ref_index"][k]), f"list {k} (M = {p.shape[0]})"
+
+
 def test_g3_medoid_matches_reference(oracle):
     cases = json.load(open(os.path.join(G, "g3_medoid.json")))
     g = np.load(os.path.join(G, "g3_medoid.npz"))
