@@ -8,8 +8,8 @@ there is no kernel here.
 What is mirrored
   * `DetectionConfig` (:36-100) and the CVPR-2019 defaults of nuscenes-devkit's `detection_cvpr_2019.json`;
   * `load_gt` (:296-404) incl. `category_to_detection_name[_rare]` (:204-262) and the devkit's `box_velocity`;
-  * `add_center_dist` (:103-127), `filter_eval_boxes` (:441-536: range, zero-point and bike-rack filters; the
-    drivable-area filter needs the map's polygons, which this package does not read -- it is skipped with a notice);
+  * `add_center_dist` (:103-127), `filter_eval_boxes` (:441-536: range, zero-point, bike-rack and drivable-area filters; the
+    drivable polygons are read from the map-expansion json directly, `load_drivable_polygons`);
   * `accumulate_object_class` (:542-706, class-agnostic "object" matching) and `accumulate_with_recall` (:709-864);
   * `calc_ap` / `calc_tp` and the `DetectionMetrics` summary (mAP, TP errors, NDS) of nuscenes-devkit 1.1.10;
   * `DetectionEval.evaluate/main` (:866-1155): `metrics_summary.json`, `metrics_details.json`, the printed table.
@@ -190,8 +190,47 @@ def _point_in_box(center, size_wlh, rotation, p):
     return abs(local[0]) <= l / 2 and abs(local[1]) <= w / 2 and abs(local[2]) <= h / 2
 
 
+def load_drivable_polygons(dataroot, location):
+    """The drivable-area polygons of a map, read straight from the nuScenes map-expansion file
+    `<dataroot>/maps/expansion/<location>.json` (what NuScenesMap.drivable_area + extract_polygon give at :496-505): every
+    polygon token of every drivable_area record -> (exterior ring (n,2), [hole rings]).  No devkit, no shapely."""
+    path = os.path.join(dataroot, "maps", "expansion", location + ".json")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"drivable-area filtering needs {path}")
+    with open(path) as f:
+        m = json.load(f)
+    node = {n["token"]: (float(n["x"]), float(n["y"])) for n in m["node"]}
+    poly = {p["token"]: p for p in m["polygon"]}
+    out = []
+    for rec in m["drivable_area"]:
+        for tok in rec["polygon_tokens"]:
+            p = poly[tok]
+            ext = np.array([node[t] for t in p["exterior_node_tokens"]], np.float64).reshape(-1, 2)
+            holes = [np.array([node[t] for t in h["node_tokens"]], np.float64).reshape(-1, 2) for h in p.get("holes", [])]
+            out.append((ext, holes))
+    return out
+
+
+def _inside_ring(ring, x, y):
+    """Even-odd rule (strictly inside for points off the boundary, like shapely's `within` up to a set of measure zero)."""
+    xs, ys = ring[:, 0], ring[:, 1]
+    xn, yn = np.roll(xs, -1), np.roll(ys, -1)
+    crosses = ((ys > y) != (yn > y)) & (x < (xn - xs) * (y - ys) / np.where(yn == ys, 1.0, yn - ys) + xs)
+    return bool(np.count_nonzero(crosses) & 1)
+
+
+def point_in_polygons(polygons, x, y):
+    """`any(Point(x, y).within(polygon))` of :514-519: inside an exterior ring and in none of its holes."""
+    for ext, holes in polygons:
+        if ext.shape[0] >= 3 and _inside_ring(ext, x, y) and not any(h.shape[0] >= 3 and _inside_ring(h, x, y) for h in holes):
+            return True
+    return False
+
+
 def filter_eval_boxes(tables, eval_boxes, max_dist, drivable_filtering=False, verbose=False):
-    """:441-536 (distance, zero points, bike racks).  The drivable-area filter is not available here."""
+    """:441-536: distance, zero points, bike racks, and -- when asked for -- the drivable-area filter (:489-526): a box stays
+    only if its centre lies within a drivable-area polygon of the map of the FIRST sample's scene (like the reference, which
+    looks the map up once, :491-493)."""
     total = dist_f = point_f = rack_f = 0
     for tok in eval_boxes.sample_tokens:
         total += len(eval_boxes[tok])
@@ -214,8 +253,16 @@ def filter_eval_boxes(tables, eval_boxes, max_dist, drivable_filtering=False, ve
         print("> After distance based filtering: %d" % dist_f)
         print("> After LIDAR and RADAR points based filtering: %d" % point_f)
         print("> After bike rack filtering: %d" % rack_f)
-    if drivable_filtering:
-        print("> Drivable-area filtering needs the map polygons (nuscenes-devkit NuScenesMap); skipped.")
+    if drivable_filtering and eval_boxes.sample_tokens:
+        first = tables.get('sample', eval_boxes.sample_tokens[0])
+        scene = tables.get('scene', first['scene_token'])
+        polygons = load_drivable_polygons(tables.dataroot, tables.location(scene))
+        driv_f = 0
+        for tok in eval_boxes.sample_tokens:
+            eval_boxes.boxes[tok] = [b for b in eval_boxes[tok] if point_in_polygons(polygons, b['translation'][0], b['translation'][1])]
+            driv_f += len(eval_boxes[tok])
+        if verbose:
+            print("> After drivable area filtering: %d" % driv_f)
     return eval_boxes
 
 

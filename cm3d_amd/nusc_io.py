@@ -260,6 +260,17 @@ def write_synthetic_dataset(root, cfg: syn.SyntheticConfig, n_scenes=2, frames_p
         tabs["scene"].append({"token": tok("scene", s), "name": name, "log_token": tok("log", s),
                               "first_sample_token": sample_tokens[0], "nbr_samples": frames_per_scene})
         np.save(os.path.join(dataroot, "lanes", loc + ".npy"), syn.make_lane_table(first_center, lane_points, seed=100 + s))
+        # drivable area in the map-expansion layout (node / polygon / drivable_area tables): a 160 m square around the first
+        # ego position with a 24 m square hole to its north-east -- what eval_custom's drivable filter reads (:496-505)
+        os.makedirs(os.path.join(dataroot, "maps", "expansion"), exist_ok=True)
+        cx, cy = float(first_center[0]), float(first_center[1])
+        rings = {"ext": [(cx - 80, cy - 80), (cx + 80, cy - 80), (cx + 80, cy + 80), (cx - 80, cy + 80)],
+                 "hole": [(cx + 20, cy + 20), (cx + 44, cy + 20), (cx + 44, cy + 44), (cx + 20, cy + 44)]}
+        nodes = [{"token": f"node-{s}-{k}-{i}", "x": x, "y": y} for k, pts in rings.items() for i, (x, y) in enumerate(pts)]
+        polygon = {"token": f"poly-{s}", "exterior_node_tokens": [f"node-{s}-ext-{i}" for i in range(4)],
+                   "holes": [{"node_tokens": [f"node-{s}-hole-{i}" for i in range(4)]}]}
+        with open(os.path.join(dataroot, "maps", "expansion", loc + ".json"), "w") as fh:
+            json.dump({"node": nodes, "polygon": [polygon], "drivable_area": [{"token": f"da-{s}", "polygon_tokens": [polygon["token"]]}]}, fh)
     for k, rows in tabs.items():
         with open(os.path.join(dataroot, version, k + ".json"), "w") as fh:
             json.dump(rows, fh)

@@ -126,3 +126,52 @@ def test_pseudo_labels_on_the_synthetic_scene(synthetic_eval):
     assert r.returncode == 0, r.stderr[-2000:]
     cli = json.load(open(tmp / "cli" / "metrics_summary.json"))
     assert abs(cli["mean_ap"] - summary["mean_ap"]) < 1e-12
+
+
+def test_drivable_area_filter_known_answers(synthetic_eval):
+    """eval_custom's drivable-area filter (:489-526): a box survives only if its centre lies within a drivable polygon of the
+    first sample's map.  The synthetic map is a 160 m square around the first ego position with a 24 m square hole."""
+    tables, dataroot, _, tmp = synthetic_eval
+    scene = tables.scenes()[0]
+    polys = ev.load_drivable_polygons(dataroot, tables.location(scene))
+    assert len(polys) == 1 and polys[0][0].shape == (4, 2) and len(polys[0][1]) == 1
+    (x0, y0), (x1, y1) = polys[0][0].min(0), polys[0][0].max(0)
+    cx, cy = (x0 + x1) / 2, (y0 + y1) / 2
+    assert ev.point_in_polygons(polys, cx, cy) and ev.point_in_polygons(polys, x0 + 1e-6, cy)
+    assert not ev.point_in_polygons(polys, cx + 30.0, cy + 30.0)                 # in the hole
+    assert ev.point_in_polygons(polys, cx + 19.9, cy + 30.0) and ev.point_in_polygons(polys, cx + 44.1, cy + 30.0)
+    assert not ev.point_in_polygons(polys, x1 + 0.1, cy) and not ev.point_in_polygons(polys, cx, y0 - 5.0)
+    tok = tables.samples_of_scene(scene)[0]["token"]
+    boxes = ev.EvalBoxes()
+    mk = lambda x, y: ev._box(tok, (x, y, 0.0), (2, 4, 1.5), (1, 0, 0, 0), detection_name="car", detection_score=0.5)
+    boxes.add_boxes(tok, [mk(cx + 5, cy - 3), mk(cx + 30, cy + 30), mk(cx + 10, cy + 10), mk(cx + 200, cy)])
+    ev.add_center_dist(tables, boxes)
+    far = {k: 1e9 for k in ev.CVPR_2019["class_range"]}
+    kept = ev.filter_eval_boxes(tables, boxes, far, drivable_filtering=True)
+    assert [tuple(b["translation"][:2]) for b in kept[tok]] == [(cx + 5, cy - 3), (cx + 10, cy + 10)]
+    # without the flag nothing is dropped; with it, ground truth is filtered the same way inside DetectionEval
+    boxes2 = ev.EvalBoxes()
+    boxes2.add_boxes(tok, [mk(cx + 30, cy + 30)])
+    ev.add_center_dist(tables, boxes2)
+    assert len(ev.filter_eval_boxes(tables, boxes2, far, drivable_filtering=False)[tok]) == 1
+
+
+def test_rare_class_configuration(synthetic_eval, tmp_path):
+    """cfg/rare_config.json (12 classes: + child, stroller; min_recall = min_precision = 0): with more than 10 classes the
+    ground truth is loaded through category_to_detection_name_rare (:204-232,:927-930)."""
+    tables, dataroot, result_path, tmp = synthetic_eval
+    cfg = ev.DetectionConfig.deserialize(json.load(open(os.path.join(ROOT, "src", "nuscenes", "cfg", "rare_config.json"))))
+    assert len(cfg.class_range) == 12 and cfg.class_range["child"] == 40 and cfg.min_recall == 0 and cfg.min_precision == 0
+    # turn one pedestrian annotation of the synthetic scene into a child: rare ground truth keeps it apart
+    child_cat = "cat-human.pedestrian.child"
+    tables.t["category"][child_cat] = {"token": child_cat, "name": "human.pedestrian.child"}
+    ann = next(a for a in tables.t["sample_annotation"].values() if tables.category_name(a) == "human.pedestrian.adult")
+    tables.t["instance"][ann["instance_token"]]["category_token"] = child_cat
+    plain = ev.load_gt(tables, rare=False)
+    rare = ev.load_gt(tables, rare=True)
+    assert sum(b["detection_name"] == "child" for b in plain.all) == 0 and sum(b["detection_name"] == "child" for b in rare.all) == 1
+    assert len(plain.all) == len(rare.all)
+    de = ev.DetectionEval(tables, cfg, result_path, None, str(tmp_path / "rare"), False, False, verbose=False)
+    assert any(b["detection_name"] == "child" for b in de.gt_boxes.all)
+    summary = de.main()
+    assert set(summary["mean_dist_aps"]) == set(cfg.class_range) and summary["mean_dist_aps"]["child"] == 0.0
