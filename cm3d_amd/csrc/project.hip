@@ -55,6 +55,9 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 #define PH_STAMP(k) do { } while (0)
 #endif
 
+#ifndef PH_LOADMODE
+#define PH_LOADMODE 1          // how a full chunk's rows are fetched: 0 lane-strided non-temporal, 1 lane-strided, 2 coalesced + LDS transpose
+#endif
 #define PH_THREADS 256
 #define PH_WAVES (PH_THREADS / 64)
 #define PH_PT 4                                   // consecutive rows per lane
@@ -67,11 +70,16 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 //   [4] sa first sweep [5] ns sweeps  [6] first word of the frame's removed-row bits  [7] nwc wave-chunks
 //   [8..16]  cam_first[0..8]: masks of camera c = entries [cam_first[c], cam_first[c+1]) of the frame's sorted list
 //   [24..40] frame-local first row of each sweep (fused path; ns <= PH_MAX_SWEEPS)
+//   [17] largest pixel margin of the approximate projections  [18] bit c = camera c has an approximate projection
 //   [64..127] visibility cones, 8 floats per camera
-#define FT_WORDS 128
+//   [128..255] approximate projections, 16 floats per camera (cone_setup)
+#define FT_WORDS 256
 #define FT_CAMFIRST 8
+#define FT_MARGIN 17
+#define FT_APXOK 18
 #define FT_SROW 24
 #define FT_CONE 64
+#define FT_APX 128
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));        // 16 bytes at dword alignment
 typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -185,45 +193,56 @@ static __device__ __forceinline__ void project_quad(const float *cm, int ns, int
     }
 }
 
-// Conservative visibility cone of one camera, from its float32 record: a point can only pass the exact
-// in-image test if it is in front of the camera by more than min_dist (minus a margin) and inside the
-// circular cone around the optical axis that contains the whole image (plus a 2 degree margin).
-// out: [0..2] camera centre (global), [3..5] optical axis (global), [6] min axial distance, [7] 1 + tan^2.
-// The float32 error of this test is ~1e-4 m at nuScenes' global magnitudes -- orders below the margins --
-// and a camera record the derivation does not cover (skew, non-trivial last row of K) disables the test.
-static __device__ void cone_setup(const float *cm, int W, int H, float min_dist, float *out)
+// Conservative tests of one camera, derived from its float32 record (composed in double, so that what is left is the
+// rounding of the kernels' own float32 evaluation):
+//  * visibility cone: a point can only pass the exact in-image test if it is in front of the camera by more than
+//    min_dist (minus a margin) and inside the circular cone around the optical axis that contains the whole image (plus a
+//    2 degree margin).  out: [0..2] camera centre (global), [3..5] optical axis (global), [6] min axial distance, [7] 1 + tan^2.
+//  * approximate projection (apx, 16 floats): camera centre o [0..2], composed rotation A [3..11] (p_cam = A (p - o)),
+//    fx, fy, cx, cy of K' [12..15].  Evaluated in float32 as A (p - o) it differs from the exact chain's camera
+//    coordinates by less than `delta` = 1e-6 max|o| + 1e-4 metres (both forms round p +- 1e3-magnitude translations once or
+//    twice: ~6e-5 m at nuScenes' global magnitudes, so the bound has a factor of several to spare), i.e. by less than
+//    *margin_px = 1 + ceil(2 max(fx, fy) delta / zmin) pixels for every point the depth test can accept.
+// A camera record the derivation does not cover (skew, non-trivial last row of K, stages that are not rigid) disables both
+// tests for that camera (the cone accepts everything, *apx_ok = false).
+static __device__ void cone_setup(const float *cm, int W, int H, float min_dist, float *out, float *apx, int *margin_px, bool *apx_ok)
 {
     const float *K = cm + 45;
     const int ns = (int)cm[54], fl = (int)cm[55];
     // compose the stages: p_cam = M p + c
-    float M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, c[3] = {0, 0, 0};
+    double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, c[3] = {0, 0, 0};
     for (int s = 0; s < ns && s < 3; ++s) {
         const float *st = cm + 15 * s, *Rm = st + 3;
-        if (fl & (1 << (2 * s))) { c[0] += st[0]; c[1] += st[1]; c[2] += st[2]; }
-        float Mn[9], cn[3];
+        if (fl & (1 << (2 * s))) { c[0] += (double)st[0]; c[1] += (double)st[1]; c[2] += (double)st[2]; }
+        double Mn[9], cn[3];
         for (int r = 0; r < 3; ++r) {
-            for (int q = 0; q < 3; ++q) Mn[3 * r + q] = Rm[3 * r] * M[q] + Rm[3 * r + 1] * M[3 + q] + Rm[3 * r + 2] * M[6 + q];
-            cn[r] = Rm[3 * r] * c[0] + Rm[3 * r + 1] * c[1] + Rm[3 * r + 2] * c[2];
+            for (int q = 0; q < 3; ++q) Mn[3 * r + q] = (double)Rm[3 * r] * M[q] + (double)Rm[3 * r + 1] * M[3 + q] + (double)Rm[3 * r + 2] * M[6 + q];
+            cn[r] = (double)Rm[3 * r] * c[0] + (double)Rm[3 * r + 1] * c[1] + (double)Rm[3 * r + 2] * c[2];
         }
         for (int q = 0; q < 9; ++q) M[q] = Mn[q];
         for (int q = 0; q < 3; ++q) c[q] = cn[q];
-        if (fl & (2 << (2 * s))) { c[0] += st[12]; c[1] += st[13]; c[2] += st[14]; }
+        if (fl & (2 << (2 * s))) { c[0] += (double)st[12]; c[1] += (double)st[13]; c[2] += (double)st[14]; }
     }
     // camera centre: M o + c = 0  <=>  o = -M^T c  (M orthonormal)
-    const float ox = -(M[0] * c[0] + M[3] * c[1] + M[6] * c[2]);
-    const float oy = -(M[1] * c[0] + M[4] * c[1] + M[7] * c[2]);
-    const float oz = -(M[2] * c[0] + M[5] * c[1] + M[8] * c[2]);
-    out[0] = ox; out[1] = oy; out[2] = oz;
-    out[3] = M[6]; out[4] = M[7]; out[5] = M[8];
+    const double ox = -(M[0] * c[0] + M[3] * c[1] + M[6] * c[2]);
+    const double oy = -(M[1] * c[0] + M[4] * c[1] + M[7] * c[2]);
+    const double oz = -(M[2] * c[0] + M[5] * c[1] + M[8] * c[2]);
+    out[0] = (float)ox; out[1] = (float)oy; out[2] = (float)oz;
+    out[3] = (float)M[6]; out[4] = (float)M[7]; out[5] = (float)M[8];
+    apx[0] = (float)ox; apx[1] = (float)oy; apx[2] = (float)oz;
+    for (int q = 0; q < 9; ++q) apx[3 + q] = (float)M[q];
+    apx[12] = K[0]; apx[13] = K[4]; apx[14] = K[2]; apx[15] = K[5];
+    *apx_ok = false;
+    *margin_px = 0;
     const bool plain = K[1] == 0.f && K[3] == 0.f && K[6] == 0.f && K[7] == 0.f && K[8] == 1.f && K[0] > 0.f && K[4] > 0.f;
     // orthonormality of M (a rotation up to float32 rounding)?
-    float dev = 0.f;
+    double dev = 0.0;
     for (int r = 0; r < 3; ++r)
-        for (int c = r; c < 3; ++c) {
-            const float d = M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1] + M[3 * r + 2] * M[3 * c + 2] - (r == c ? 1.f : 0.f);
-            dev = fmaxf(dev, fabsf(d));
+        for (int q = r; q < 3; ++q) {
+            const double d = M[3 * r] * M[3 * q] + M[3 * r + 1] * M[3 * q + 1] + M[3 * r + 2] * M[3 * q + 2] - (r == q ? 1.0 : 0.0);
+            dev = fmax(dev, fabs(d));
         }
-    if (!plain || !(dev < 1e-3f)) { out[6] = -INFINITY; out[7] = INFINITY; return; }   // accept everything
+    if (!plain || !(dev < 1e-3)) { out[6] = -INFINITY; out[7] = INFINITY; return; }   // accept everything
     float t2 = 0.f;
     for (int cx = 0; cx < 2; ++cx)
         for (int cy = 0; cy < 2; ++cy) {
@@ -232,8 +251,15 @@ static __device__ void cone_setup(const float *cm, int W, int H, float min_dist,
         }
     const float t = sqrtf(t2), tm = 0.035f;            // tan(2 deg)
     const float tt = t * tm < 0.9f ? (t + tm) / (1.f - t * tm) : INFINITY;
-    out[6] = min_dist - 0.05f - 1e-4f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+    const float omax = (float)fmax(fmax(fabs(ox), fabs(oy)), fabs(oz));
+    const float zmin = min_dist - 0.05f - 1e-4f * omax;
+    out[6] = zmin;
     out[7] = 1.f + tt * tt * 1.01f;
+    if (zmin > 0.1f && dev < 1e-5) {
+        const float delta = 1e-6f * omax + 1e-4f;
+        const float mg = 1.f + ceilf(2.f * fmaxf(K[0], K[4]) * delta / zmin);
+        if (mg < 64.f) { *margin_px = (int)mg; *apx_ok = true; }
+    }
 }
 
 struct PhSweepIn {
@@ -316,31 +342,60 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
         ft[6] = (p0 >> 5) + 8 * f;          // frames never overlap: sum ceil(n_g / 32) <= (p0 >> 5) + f, and a chunk owns 8 whole words
         ft[7] = (n + PH_WC - 1) / PH_WC;
     }
-    if (lane < CM3D_MAX_CAMS) {
-        float *cone = reinterpret_cast<float *>(ft + FT_CONE) + 8 * lane;
-        if (lane < n_cams) cone_setup(cams + ((size_t)f * n_cams + lane) * CM3D_CAM_STRIDE, W, H, min_dist, cone);
-        else { cone[6] = INFINITY; cone[7] = 0.f; }
+    {
+        int mg = 0;
+        bool ok = false;
+        if (lane < CM3D_MAX_CAMS) {
+            float *cone = reinterpret_cast<float *>(ft + FT_CONE) + 8 * lane, *apx = reinterpret_cast<float *>(ft + FT_APX) + 16 * lane;
+            if (lane < n_cams) cone_setup(cams + ((size_t)f * n_cams + lane) * CM3D_CAM_STRIDE, W, H, min_dist, cone, apx, &mg, &ok);
+            else { cone[6] = INFINITY; cone[7] = 0.f; }
+        }
+        const uint64_t okm = __ballot(ok);
+        mg = cm3d_wave_max(mg);
+        if (lane == 0) { ft[FT_MARGIN] = mg; ft[FT_APXOK] = (int)(uint32_t)okm; }
     }
+    // the frame's masks sorted by camera: count per camera (lane c = masks of camera c), exclusive prefix, placement by
+    // ballot rank.  Every mask is loaded once per pass (twice when the frame has more than 64 masks).
     int4 *ment = ment_all + (size_t)f * nm_cap;
-    int run = 0;
-    for (int c = 0; c < n_cams; ++c) {
-        if (lane == 0) ft[FT_CAMFIRST + c] = run;
-        for (int k0 = 0; k0 < nm; k0 += 64) {
-            const int k = k0 + lane;
-            bool v = false;
-            int4 bb = make_int4(0, 0, -1, -1);
-            if (k < nm) {
-                const int cam = mask_cam[m0 + k];
-                bb = bbox[m0 + k];
-                v = cam == c && bb.z >= bb.x && bb.w >= bb.y;
-                if (c == 0 && (cam < 0 || cam >= n_cams)) atomicOr(&status[0], 4);           // such a mask gets no points
-            }
-            const uint64_t mk = __ballot(v);
+    auto load_mask = [&](int k, int &cam, int4 &bb) {
+        cam = -1;
+        bb = make_int4(0, 0, -1, -1);
+        if (k < nm) {
+            cam = mask_cam[m0 + k];
+            bb = bbox[m0 + k];
+            if (cam < 0 || cam >= n_cams) { atomicOr(&status[0], 4); cam = -1; }         // such a mask gets no points
+            else if (!(bb.z >= bb.x && bb.w >= bb.y)) cam = -1;                          // empty after the erosion
+        }
+    };
+    int cam0;
+    int4 bb0;
+    load_mask(lane, cam0, bb0);                      // the first 64 masks stay in registers for both passes
+    int cnt = 0;                                     // lane c: masks of camera c
+    for (int k0 = 0; k0 < nm; k0 += 64) {
+        int cam = cam0;
+        int4 bb = bb0;
+        if (k0) load_mask(k0 + lane, cam, bb);
+        for (int c = 0; c < n_cams; ++c) {
+            const int x = (int)__popcll(__ballot(cam == c));
+            cnt += lane == c ? x : 0;
+        }
+    }
+    int first = cm3d_wave_incl_scan(lane < n_cams ? cnt : 0) - (lane < n_cams ? cnt : 0);       // lane c: first entry of camera c
+    const int run = __builtin_amdgcn_readlane(first, CM3D_MAX_CAMS - 1) + __builtin_amdgcn_readlane(lane < n_cams ? cnt : 0, CM3D_MAX_CAMS - 1);
+    if (lane < n_cams) ft[FT_CAMFIRST + lane] = first;
+    for (int k0 = 0; k0 < nm; k0 += 64) {
+        int cam = cam0;
+        int4 bb = bb0;
+        if (k0) load_mask(k0 + lane, cam, bb);
+        const int k = k0 + lane;
+        for (int c = 0; c < n_cams; ++c) {
+            const uint64_t mk = __ballot(cam == c);
+            const int base = __builtin_amdgcn_readlane(first, c);
             // entry: corner and extent of the bounding box as 16-bit pairs (y in the high half, like the pixel codes),
             // mask number inside the frame, first word of the mask in `packed` (a batch holds < 2^31 mask words)
-            if (v) ment[run + cm3d_mbcnt(mk)] = make_int4(bb.x | (bb.y << 16), (bb.z - bb.x) | ((bb.w - bb.y) << 16), k,
-                                                          (int)((uint32_t)(m0 + k) * mask_words));
-            run += (int)__popcll(mk);
+            if (cam == c) ment[base + cm3d_mbcnt(mk)] = make_int4(bb.x | (bb.y << 16), (bb.z - bb.x) | ((bb.w - bb.y) << 16), k,
+                                                                  (int)((uint32_t)(m0 + k) * mask_words));
+            first += lane == c ? (int)__popcll(mk) : 0;
         }
     }
     if (lane == 0)
@@ -381,12 +436,27 @@ static __device__ __forceinline__ void ph_load_rows(PhRows<STRIDE> &r, const flo
         return;
     }
     if (STRIDE > 0 && nvalid >= PH_WC) {
+#if PH_LOADMODE == 2
+        // the chunk's 256 x STRIDE floats as STRIDE fully coalesced 1-KiB requests (lane l: bytes [1024 q + 16 l, + 16)): every
+        // cache line is asked for once.  ph_rows_from_pieces turns the pieces into this lane's rows.
+        const f4u *p = reinterpret_cast<const f4u *>(src + row0 * STRIDE) + lane;
+#pragma unroll
+        for (int q = 0; q < STRIDE; ++q) {
+            const f4u t = __builtin_nontemporal_load(p + 64 * q);
+            r.v[4 * q] = t.x; r.v[4 * q + 1] = t.y; r.v[4 * q + 2] = t.z; r.v[4 * q + 3] = t.w;
+        }
+#else
         const f4u *p = reinterpret_cast<const f4u *>(src + (row0 + (size_t)(4 * lane)) * STRIDE);
 #pragma unroll
         for (int q = 0; q < STRIDE; ++q) {
+#if PH_LOADMODE == 1
+            const f4u t = p[q];
+#else
             const f4u t = __builtin_nontemporal_load(p + q);
+#endif
             r.v[4 * q] = t.x; r.v[4 * q + 1] = t.y; r.v[4 * q + 2] = t.z; r.v[4 * q + 3] = t.w;
         }
+#endif
     } else {
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) {
@@ -400,6 +470,25 @@ static __device__ __forceinline__ void ph_load_rows(PhRows<STRIDE> &r, const flo
             if (S == 5) r.v[j * S + 4] = 0.f;
         }
     }
+}
+
+// PH_LOADMODE 2: the pieces of a full chunk (ph_load_rows) -> the lane's four rows, through the wave's own LDS slice
+// (STRIDE 16-byte stores at lane stride 16 B, STRIDE 16-byte loads at lane stride 16 STRIDE B: both conflict-free).
+template <int STRIDE>
+static __device__ __forceinline__ void ph_rows_from_pieces(PhRows<STRIDE> &r, float *s_tr, int lane)
+{
+#if PH_LOADMODE == 2
+    if (STRIDE > 0) {
+#pragma unroll
+        for (int q = 0; q < STRIDE; ++q)
+            *reinterpret_cast<float4 *>(s_tr + 256 * q + 4 * lane) = make_float4(r.v[4 * q], r.v[4 * q + 1], r.v[4 * q + 2], r.v[4 * q + 3]);
+#pragma unroll
+        for (int q = 0; q < STRIDE; ++q) {
+            const float4 t = *reinterpret_cast<const float4 *>(s_tr + 4 * STRIDE * lane + 4 * q);
+            r.v[4 * q] = t.x; r.v[4 * q + 1] = t.y; r.v[4 * q + 2] = t.z; r.v[4 * q + 3] = t.w;
+        }
+    }
+#endif
 }
 
 // sweep of frame-local row i (ns > 1): srow = the frame table's sweep starts
@@ -421,7 +510,7 @@ static __device__ __forceinline__ int ph_sweep_of(const int32_t *srow, int ns, i
 // FUSED: `src` = raw sweep rows (a2, reference :437-465); otherwise `src` = a prepared float4 cloud (STRIDE 4) whose
 // dropped rows are NaN points.
 template <bool ONE_PLANE, bool FUSED, int STRIDE>
-__global__ __launch_bounds__(PH_THREADS) void k_project_hits(
+__global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
     const float *__restrict__ src, int src_stride, const float *__restrict__ sweep_xf, float halfw, float4 *__restrict__ points_out,
     uint32_t *__restrict__ removed_bits, const int32_t *__restrict__ ft_all, const int4 *__restrict__ ment_all,
     const float *__restrict__ cams, int n_cams, const uint32_t *__restrict__ packed, int W, int H, int Wp, float min_dist, int nm_cap,
@@ -443,7 +532,11 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
 
     __shared__ float s_cam[CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
     __shared__ float s_cone[CM3D_MAX_CAMS][8];
+    __shared__ float s_apx[CM3D_MAX_CAMS][16];
     __shared__ int s_first[CM3D_MAX_CAMS + 1];
+#if PH_LOADMODE == 2
+    __shared__ __align__(16) float s_tr[PH_WAVES][PH_WC * (STRIDE > 0 ? STRIDE : 1)];      // row transposition, one slice per wave
+#endif
     // dynamic LDS (several planes only), one slice per wave: hit words [planes_cap][PH_WC], counts [nm_cap]
     extern __shared__ __align__(16) unsigned char s_dyn[];
     uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_dyn) + (size_t)wave * planes_cap * PH_WC;
@@ -455,6 +548,8 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS) s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
     if (threadIdx.x < CM3D_MAX_CAMS * 8) (&s_cone[0][0])[threadIdx.x] = reinterpret_cast<const float *>(ft + FT_CONE)[threadIdx.x];
     if (threadIdx.x <= CM3D_MAX_CAMS) s_first[threadIdx.x] = ft[FT_CAMFIRST + threadIdx.x];
+    if (threadIdx.x < CM3D_MAX_CAMS * 16) (&s_apx[0][0])[threadIdx.x] = reinterpret_cast<const float *>(ft + FT_APX)[threadIdx.x];
+    const int apx_margin = ft[FT_MARGIN], apx_okmask = ft[FT_APXOK];
     __syncthreads();                                                // the only one: from here on the waves are on their own
     PH_STAMP(0);                                                    // setup
 
@@ -462,12 +557,53 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
     const float qnan = __int_as_float(0x7FC00000);
     constexpr int S = PhRows<STRIDE>::S;
     int acc_cnt = 0;                                                // ONE_PLANE: lane k = hits of mask k over this wave's chunks
+    uint32_t pend_bits[PH_PT] = {0u, 0u, 0u, 0u};                   // results of the previous chunk, not stored yet
+    int pend_cnt = 0, pend_chunk = -1;
+    // results of a chunk: hit words (16 bytes per lane and plane), per-mask counts
+    auto flush_results = [&]() {
+        if (pend_chunk < 0) return;                                 // uniform
+        const int pcb = pend_chunk * PH_WC, pvalid = min(PH_WC, n - pcb);
+        int32_t *cnt_row = wc_cnt + ((size_t)f * nwc_max + pend_chunk) * nm_cap;
+        if (ONE_PLANE) {
+            uint32_t *hw = hit_words + (size_t)p0 + pcb + 4 * lane;
+            if (pvalid >= PH_WC) {
+                *reinterpret_cast<u4u *>(hw) = (u4u){pend_bits[0], pend_bits[1], pend_bits[2], pend_bits[3]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j)
+                    if (4 * lane + j < pvalid) hw[j] = pend_bits[j];
+            }
+            if (lane < 32) cnt_row[lane] = pend_cnt;
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int pl = 0; pl < planes; ++pl) {
+                const uint4 w4 = *reinterpret_cast<const uint4 *>(&s_bits[pl * PH_WC + 4 * lane]);
+                uint32_t *hw = hit_words + (size_t)pl * n_points_total + p0 + pcb + 4 * lane;
+                if (pvalid >= PH_WC) {
+                    *reinterpret_cast<u4u *>(hw) = (u4u){w4.x, w4.y, w4.z, w4.w};
+                } else {
+                    const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int j = 0; j < PH_PT; ++j)
+                        if (4 * lane + j < pvalid) hw[j] = wv[j];
+                }
+            }
+            for (int k = lane; k < nm; k += 64) {
+                const int cv = s_cnt[k];
+                cnt_row[k] = cv;
+                if (cv) atomicAdd(&hit_count[m0 + k], cv);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
     for (int chunk = c_lo; chunk < c_hi; ++chunk) {
         const int cb = chunk * PH_WC;
         const int nvalid = min(PH_WC, n - cb);                      // uniform
-        // the next chunk's rows are requested now, into their own registers, and arrive under the camera loop
-        PhRows<STRIDE> nxt;
-        if (chunk + 1 < c_hi) ph_load_rows<STRIDE>(nxt, src, src_stride, (size_t)p0 + (size_t)cb + PH_WC, min(PH_WC, n - cb - PH_WC), lane, PH_DIAG(8));
+#if PH_LOADMODE == 2
+        if (STRIDE > 0 && nvalid >= PH_WC) ph_rows_from_pieces<STRIDE>(cur, s_tr[wave], lane);
+#endif
         f2 X[PH_NP], Y[PH_NP], Z[PH_NP];                           // rows (2h, 2h+1) of this lane side by side
         if (FUSED) {
             // sweep of the chunk's first and last row: equal for all but the chunks that hold a sweep boundary
@@ -511,6 +647,13 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             }
         }
         PH_STAMP(1);                                                // rows arrive, transform, [cloud store]
+        // vmcnt counts loads and stores together and in order, and the waits the compiler places are "everything so far":
+        // the one memory wait of an iteration that can be long is the one above, for rows requested a whole camera loop
+        // ago.  Right behind it go the previous chunk's result stores and the request for the next chunk's rows; both
+        // have the camera loop to complete before anything waits again.
+        flush_results();
+        PhRows<STRIDE> nxt;
+        if (chunk + 1 < c_hi) ph_load_rows<STRIDE>(nxt, src, src_stride, (size_t)p0 + (size_t)cb + PH_WC, min(PH_WC, n - cb - PH_WC), lane, PH_DIAG(8));
         uint32_t bits[PH_PT];
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) bits[j] = 0;
@@ -545,6 +688,60 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             if (!__ballot(inside >= 0.0f)) continue;
             const int e0 = __builtin_amdgcn_readfirstlane(s_first[c]), e1 = __builtin_amdgcn_readfirstlane(s_first[c + 1]);
             if (e0 >= e1) continue;                                 // a camera without (non-empty) masks: nothing to hit
+            // Pre-test on the approximate projection (cone_setup): which masks of this camera can any of the wave's points
+            // hit?  A point in a mask lies in the mask's bounding box; its approximate pixel is within apx_margin pixels of the
+            // exact one, so it lies in the box grown by that margin.  Two thirds of the (wave, camera) pairs that reach this
+            // point end here, and the exact projection below then only meets the masks that have a candidate.
+            const int ne = e1 - e0;
+            const bool pretest = ne <= 32 && ((apx_okmask >> c) & 1) && !PH_DIAG(32);
+            uint32_t cmask = ne >= 32 ? 0xFFFFFFFFu : ((1u << ne) - 1u);          // bit i = entry e0 + i is a candidate
+            if (pretest) {
+                const float *ap = s_apx[c];
+                const float zmin = s_cone[c][6];
+                int pa[PH_PT];
+#pragma unroll
+                for (int h = 0; h < PH_NP; ++h) {
+                    const f2 vx = X[h] - ap[0], vy = Y[h] - ap[1], vz = Z[h] - ap[2];
+                    f2 xc = ap[3] * vx; xc = PK_FMA((f2)(ap[4]), vy, xc); xc = PK_FMA((f2)(ap[5]), vz, xc);
+                    f2 yc = ap[6] * vx; yc = PK_FMA((f2)(ap[7]), vy, yc); yc = PK_FMA((f2)(ap[8]), vz, yc);
+                    f2 zc = ap[9] * vx; zc = PK_FMA((f2)(ap[10]), vy, zc); zc = PK_FMA((f2)(ap[11]), vz, zc);
+                    const f2 r = {__builtin_amdgcn_rcpf(zc.x), __builtin_amdgcn_rcpf(zc.y)};
+                    const f2 ua = PK_FMA(ap[12] * xc, r, (f2)(ap[14])), va = PK_FMA(ap[13] * yc, r, (f2)(ap[15]));
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        // pixel grid shifted by +1 and clamped, so that both halves are unsigned 16-bit values; NaN and
+                        // points behind zmin become 0xFFFF, 0xFFFF: outside every box
+                        const int iu = (int)(fminf(fmaxf(ua[q], -1.f), 32000.f) + 1.f), iv = (int)(fminf(fmaxf(va[q], -1.f), 32000.f) + 1.f);
+                        pa[2 * h + q] = zc[q] > zmin ? ((iv << 16) | iu) : -1;
+                    }
+                }
+                cmask = 0u;
+                for (int e = e0; e < e1; e += PH_MB) {
+                    int4 en[PH_MB];
+#pragma unroll
+                    for (int b = 0; b < PH_MB; ++b) en[b] = ment[min(e + b, e1 - 1)];              // uniform: scalar loads
+#pragma unroll
+                    for (int b = 0; b < PH_MB; ++b) {
+                        if (e + b >= e1) continue;
+                        const int ox = __builtin_amdgcn_readfirstlane(en[b].x), ex = __builtin_amdgcn_readfirstlane(en[b].y);
+                        // the box grown by the margin, in the shifted grid: [x0 + 1 - mg, x1 + 1 + mg], low end clamped at 0
+                        const int lx = max((ox & 0xFFFF) + 1 - apx_margin, 0), ly = max((ox >> 16) + 1 - apx_margin, 0);
+                        const int hx = (ox & 0xFFFF) + (ex & 0xFFFF) + 1 + apx_margin, hy = (ox >> 16) + (ex >> 16) + 1 + apx_margin;
+                        const us2 org = __builtin_bit_cast(us2, lx | (ly << 16));
+                        const us2 ext = __builtin_bit_cast(us2, (hx - lx) | ((hy - ly) << 16));
+                        bool any = false;
+#pragma unroll
+                        for (int j = 0; j < PH_PT; ++j) {
+                            const us2 d = __builtin_bit_cast(us2, pa[j]) - org;
+                            const us2 m = __builtin_elementwise_min(d, ext);
+                            any |= __builtin_bit_cast(uint32_t, m) == __builtin_bit_cast(uint32_t, d);
+                        }
+                        if (__ballot(any)) cmask |= 1u << (e + b - e0);
+                    }
+                }
+                PH_STAMP(3);
+                if (!cmask) continue;                               // no point of the wave near any mask of this camera
+            }
             const int cns = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 54]);
             const int cfl = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 55]);
             const float *cm = s_cam + c * CM3D_CAM_STRIDE;
@@ -560,27 +757,36 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
             if (!__ballot(pxall >= 0) || PH_DIAG(2)) continue;      // no point of the wave in this image
             // px = iv << 16 | iu (two 16-bit halves; -1 = outside): byte offset of the point's word inside a mask and its bit,
             // once per camera
-            uint32_t wo4[PH_PT], sh[PH_PT];
+            uint32_t wo4[PH_PT];
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
                 const uint32_t iu = (uint32_t)px[j] & 0xFFFFu, iv = (uint32_t)px[j] >> 16;
                 wo4[j] = (iv * (uint32_t)Wp + (iu >> 5)) << 2;
-                sh[j] = iu & 31u;
             }
-            // the masks of this camera (sorted entries: bounding box, mask number, first word), PH_MB at a time: all entries,
-            // then all mask words of the batch are requested before the first one is used (one memory round trip per batch)
-            for (int e = e0; e < e1; e += PH_MB) {
+            // the candidate masks of this camera (sorted entries: bounding box, mask number, first word), PH_MB at a time:
+            // all entries, then all mask words of the batch are requested before the first one is used (one memory round
+            // trip per batch).  Entries are walked through the candidate bits; a camera with more than 32 masks walks its
+            // whole range (eb = first entry of a block of 32).
+            for (int eb = e0; eb < e1; eb += 32) {
+              uint32_t rem = ne <= 32 ? cmask : (e1 - eb >= 32 ? 0xFFFFFFFFu : ((1u << (e1 - eb)) - 1u));
+              while (rem) {
+                int ei[PH_MB];
+#pragma unroll
+                for (int b = 0; b < PH_MB; ++b) {
+                    ei[b] = rem ? eb + __builtin_ctz(rem) : -1;
+                    rem = rem ? (rem & (rem - 1)) : 0u;
+                }
                 int4 en[PH_MB];
 #pragma unroll
-                for (int b = 0; b < PH_MB; ++b) en[b] = ment[min(e + b, e1 - 1)];                  // uniform: scalar loads
+                for (int b = 0; b < PH_MB; ++b) en[b] = ment[max(ei[b], e0)];                      // uniform: scalar loads
                 uint32_t word[PH_MB][PH_PT];
                 int kb[PH_MB];
 #pragma unroll
                 for (int b = 0; b < PH_MB; ++b) {
 #pragma unroll
                     for (int j = 0; j < PH_PT; ++j) word[b][j] = 0u;
-                    kb[b] = e + b < e1 ? __builtin_amdgcn_readfirstlane(en[b].z) : -1;
-                    if (kb[b] < 0) continue;                        // past the camera's last mask (wave-uniform)
+                    kb[b] = ei[b] >= 0 ? __builtin_amdgcn_readfirstlane(en[b].z) : -1;
+                    if (kb[b] < 0) continue;                        // past the last candidate (wave-uniform)
                     const us2 org = __builtin_bit_cast(us2, __builtin_amdgcn_readfirstlane(en[b].x));
                     const us2 ext = __builtin_bit_cast(us2, __builtin_amdgcn_readfirstlane(en[b].y));
                     const char *mw = reinterpret_cast<const char *>(packed) + ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane(en[b].w) << 2);
@@ -600,7 +806,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                     int cnt = 0;
 #pragma unroll
                     for (int j = 0; j < PH_PT; ++j) {
-                        const uint32_t hit = (word[b][j] >> sh[j]) & 1u;             // word = 0 for a non-candidate
+                        const uint32_t hit = (word[b][j] >> (px[j] & 31)) & 1u;       // word = 0 for a non-candidate; bit = iu & 31
                         if (ONE_PLANE) bits[j] |= hit << kb[b];
                         else if (hit) s_bits[(kb[b] >> 5) * PH_WC + 4 * lane + j] |= 1u << (kb[b] & 31);
                         cnt += (int)__popcll(__ballot(hit != 0u));
@@ -610,49 +816,25 @@ __global__ __launch_bounds__(PH_THREADS) void k_project_hits(
                         else if (lane == 0) s_cnt[kb[b]] += cnt;
                     }
                 }
+              }
             }
             PH_STAMP(4);                                            // mask loop of one camera
         }
         PH_STAMP(2);
-        // results of the chunk: hit words (16 bytes per lane and plane), per-mask counts
-        int32_t *cnt_row = wc_cnt + ((size_t)f * nwc_max + chunk) * nm_cap;
+        // The chunk's results stay in registers (LDS) until the top of the next iteration (flush_results): vmcnt counts loads
+        // and stores together and in order, so a store issued here would sit in front of the very next wait -- the one for
+        // the prefetched rows -- and every chunk would pay a store's whole round trip to memory.
         if (ONE_PLANE) {
-            uint32_t *hw = hit_words + (size_t)p0 + cb + 4 * lane;
-            if (nvalid >= PH_WC) {
-                *reinterpret_cast<u4u *>(hw) = (u4u){bits[0], bits[1], bits[2], bits[3]};
-            } else {
 #pragma unroll
-                for (int j = 0; j < PH_PT; ++j)
-                    if (4 * lane + j < nvalid) hw[j] = bits[j];
-            }
-            if (lane < 32) cnt_row[lane] = mycnt;
+            for (int j = 0; j < PH_PT; ++j) pend_bits[j] = bits[j];
+            pend_cnt = mycnt;
             acc_cnt += mycnt;
-        } else {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int pl = 0; pl < planes; ++pl) {
-                const uint4 w4 = *reinterpret_cast<const uint4 *>(&s_bits[pl * PH_WC + 4 * lane]);
-                uint32_t *hw = hit_words + (size_t)pl * n_points_total + p0 + cb + 4 * lane;
-                if (nvalid >= PH_WC) {
-                    *reinterpret_cast<u4u *>(hw) = (u4u){w4.x, w4.y, w4.z, w4.w};
-                } else {
-                    const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-                    for (int j = 0; j < PH_PT; ++j)
-                        if (4 * lane + j < nvalid) hw[j] = wv[j];
-                }
-            }
-            for (int k = lane; k < nm; k += 64) {
-                const int cv = s_cnt[k];
-                cnt_row[k] = cv;
-                if (cv) atomicAdd(&hit_count[m0 + k], cv);
-            }
-            __builtin_amdgcn_wave_barrier();
         }
+        pend_chunk = chunk;
         cur = nxt;
-        PH_STAMP(5);                                                // result stores
+        PH_STAMP(5);                                                // wait for the next rows
     }
+    flush_results();
     if (ONE_PLANE && lane < nm && acc_cnt) atomicAdd(&hit_count[m0 + lane], acc_cnt);
 #ifdef CM3D_DIAG
     if ((diag & 16) && lane == 0)

@@ -26,9 +26,9 @@ st = torch.cuda.current_stream().cuda_stream
 eng.run(masks="rle")
 torch.cuda.synchronize()
 eng.check_status()
-names = {2: "no mask loop", 4: "no camera loop", 8: "synthetic rows (no raw loads)"}
+names = {2: "no mask loop", 4: "no camera loop", 8: "synthetic rows (no raw loads)", 32: "no approximate pre-test"}
 out = {}
-for flags in (0, 2, 4, 8, 12, 6, 0):
+for flags in (0, 32, 2, 4, 8, 12, 0, 32):
     L.cm3d_diag_set(flags)
     ts = []
     for _ in range(12):
@@ -43,7 +43,7 @@ for flags in (0, 2, 4, 8, 12, 6, 0):
     label = " + ".join(v for k, v in names.items() if flags & k) or "full kernel"
     out[f"{flags}: {label}"] = round(ms[len(ms) // 2] * 1e3, 1)
     print(f"flags {flags:2d}  {ms[len(ms) // 2] * 1e3:8.1f} us   {label}", flush=True)
-for flags in (16,):
+for flags in (16, 28):
     L.cm3d_diag_set(flags)
     eng.stage_begin(st)
     eng.stage_sweep_project(st)
