@@ -280,7 +280,7 @@ static inline int64_t ph_ws_layout(int n_frames, int max_pts_per_frame, int plan
     int64_t off = 0;
     char *b = (char *)base;
     if (out) out->ment = (int4 *)(b + off);
-    off += (int64_t)n_frames * nm_cap * 16;
+    off += (int64_t)n_frames * nm_cap * 32;                       // two int4 per mask entry (k_frame_tables)
     if (out) out->ft = (int32_t *)(b + off);
     off += (int64_t)n_frames * FT_WORDS * 4;
     if (out) out->wc_drop = (int32_t *)(b + off);
@@ -342,6 +342,7 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
         ft[6] = (p0 >> 5) + 8 * f;          // frames never overlap: sum ceil(n_g / 32) <= (p0 >> 5) + f, and a chunk owns 8 whole words
         ft[7] = (n + PH_WC - 1) / PH_WC;
     }
+    int ft_margin = 0;
     {
         int mg = 0;
         bool ok = false;
@@ -352,11 +353,13 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
         }
         const uint64_t okm = __ballot(ok);
         mg = cm3d_wave_max(mg);
+        ft_margin = mg;
         if (lane == 0) { ft[FT_MARGIN] = mg; ft[FT_APXOK] = (int)(uint32_t)okm; }
     }
     // the frame's masks sorted by camera: count per camera (lane c = masks of camera c), exclusive prefix, placement by
     // ballot rank.  Every mask is loaded once per pass (twice when the frame has more than 64 masks).
-    int4 *ment = ment_all + (size_t)f * nm_cap;
+    int4 *ment = ment_all + (size_t)f * nm_cap * 2;
+    const int mg = ft_margin;
     auto load_mask = [&](int k, int &cam, int4 &bb) {
         cam = -1;
         bb = make_int4(0, 0, -1, -1);
@@ -391,10 +394,17 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
         for (int c = 0; c < n_cams; ++c) {
             const uint64_t mk = __ballot(cam == c);
             const int base = __builtin_amdgcn_readlane(first, c);
-            // entry: corner and extent of the bounding box as 16-bit pairs (y in the high half, like the pixel codes),
-            // mask number inside the frame, first word of the mask in `packed` (a batch holds < 2^31 mask words)
-            if (cam == c) ment[base + cm3d_mbcnt(mk)] = make_int4(bb.x | (bb.y << 16), (bb.z - bb.x) | ((bb.w - bb.y) << 16), k,
-                                                                  (int)((uint32_t)(m0 + k) * mask_words));
+            // entry, first half: corner and extent of the bounding box as 16-bit pairs (y in the high half, like the pixel
+            // codes), mask number inside the frame, first word of the mask in `packed` (a batch holds < 2^31 mask words);
+            // second half: the box grown by the approximate projection's margin, in its pixel grid shifted by +1
+            // ([x0 + 1 - mg, x1 + 1 + mg], low end clamped at 0), again as corner and extent
+            if (cam == c) {
+                const int e = base + cm3d_mbcnt(mk);
+                const int lx = max(bb.x + 1 - mg, 0), ly = max(bb.y + 1 - mg, 0);
+                const int hx = min(bb.z + 1 + mg, 32766), hy = min(bb.w + 1 + mg, 32766);        // (approximate codes stop at 32001; -1 stays outside)
+                ment[2 * e] = make_int4(bb.x | (bb.y << 16), (bb.z - bb.x) | ((bb.w - bb.y) << 16), k, (int)((uint32_t)(m0 + k) * mask_words));
+                ment[2 * e + 1] = make_int4(lx | (ly << 16), (hx - lx) | ((hy - ly) << 16), 0, 0);
+            }
             first += lane == c ? (int)__popcll(mk) : 0;
         }
     }
@@ -549,21 +559,22 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
     if (threadIdx.x < CM3D_MAX_CAMS * 8) (&s_cone[0][0])[threadIdx.x] = reinterpret_cast<const float *>(ft + FT_CONE)[threadIdx.x];
     if (threadIdx.x <= CM3D_MAX_CAMS) s_first[threadIdx.x] = ft[FT_CAMFIRST + threadIdx.x];
     if (threadIdx.x < CM3D_MAX_CAMS * 16) (&s_apx[0][0])[threadIdx.x] = reinterpret_cast<const float *>(ft + FT_APX)[threadIdx.x];
-    const int apx_margin = ft[FT_MARGIN], apx_okmask = ft[FT_APXOK];
+    const int apx_okmask = ft[FT_APXOK];
     __syncthreads();                                                // the only one: from here on the waves are on their own
     PH_STAMP(0);                                                    // setup
 
-    const int4 *ment = ment_all + (size_t)f * nm_cap;
+    const int4 *ment = ment_all + (size_t)f * nm_cap * 2;           // two int4 per entry
     const float qnan = __int_as_float(0x7FC00000);
     constexpr int S = PhRows<STRIDE>::S;
     int acc_cnt = 0;                                                // ONE_PLANE: lane k = hits of mask k over this wave's chunks
+    int32_t *const wc_cnt_f = wc_cnt + (size_t)f * nwc_max * nm_cap;  // the frame's count rows
     uint32_t pend_bits[PH_PT] = {0u, 0u, 0u, 0u};                   // results of the previous chunk, not stored yet
     int pend_cnt = 0, pend_chunk = -1;
     // results of a chunk: hit words (16 bytes per lane and plane), per-mask counts
     auto flush_results = [&]() {
         if (pend_chunk < 0) return;                                 // uniform
         const int pcb = pend_chunk * PH_WC, pvalid = min(PH_WC, n - pcb);
-        int32_t *cnt_row = wc_cnt + ((size_t)f * nwc_max + pend_chunk) * nm_cap;
+        int32_t *cnt_row = wc_cnt_f + pend_chunk * nm_cap;
         if (ONE_PLANE) {
             uint32_t *hw = hit_words + (size_t)p0 + pcb + 4 * lane;
             if (pvalid >= PH_WC) {
@@ -717,18 +728,14 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
                 }
                 cmask = 0u;
                 for (int e = e0; e < e1; e += PH_MB) {
-                    int4 en[PH_MB];
+                    int2 en[PH_MB];                                 // the grown boxes (second half of the entries)
 #pragma unroll
-                    for (int b = 0; b < PH_MB; ++b) en[b] = ment[min(e + b, e1 - 1)];              // uniform: scalar loads
+                    for (int b = 0; b < PH_MB; ++b) en[b] = *reinterpret_cast<const int2 *>(&ment[2 * min(e + b, e1 - 1) + 1]);        // uniform: scalar loads
 #pragma unroll
                     for (int b = 0; b < PH_MB; ++b) {
                         if (e + b >= e1) continue;
-                        const int ox = __builtin_amdgcn_readfirstlane(en[b].x), ex = __builtin_amdgcn_readfirstlane(en[b].y);
-                        // the box grown by the margin, in the shifted grid: [x0 + 1 - mg, x1 + 1 + mg], low end clamped at 0
-                        const int lx = max((ox & 0xFFFF) + 1 - apx_margin, 0), ly = max((ox >> 16) + 1 - apx_margin, 0);
-                        const int hx = (ox & 0xFFFF) + (ex & 0xFFFF) + 1 + apx_margin, hy = (ox >> 16) + (ex >> 16) + 1 + apx_margin;
-                        const us2 org = __builtin_bit_cast(us2, lx | (ly << 16));
-                        const us2 ext = __builtin_bit_cast(us2, (hx - lx) | ((hy - ly) << 16));
+                        const us2 org = __builtin_bit_cast(us2, __builtin_amdgcn_readfirstlane(en[b].x));
+                        const us2 ext = __builtin_bit_cast(us2, __builtin_amdgcn_readfirstlane(en[b].y));
                         bool any = false;
 #pragma unroll
                         for (int j = 0; j < PH_PT; ++j) {
@@ -778,7 +785,7 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
                 }
                 int4 en[PH_MB];
 #pragma unroll
-                for (int b = 0; b < PH_MB; ++b) en[b] = ment[max(ei[b], e0)];                      // uniform: scalar loads
+                for (int b = 0; b < PH_MB; ++b) en[b] = ment[2 * max(ei[b], e0)];                  // uniform: scalar loads
                 uint32_t word[PH_MB][PH_PT];
                 int kb[PH_MB];
 #pragma unroll
