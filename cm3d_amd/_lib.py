@@ -44,6 +44,7 @@ SIGNATURES = {
     "cm3d_tile_work_bytes": (_i64, [_i32, _i32]),
     "cm3d_selftest_sqrt": (_i32, [C.c_uint32, C.c_uint32, _p, _p, _p]),
     "cm3d_selftest_div": (_i32, [C.c_uint64, C.c_uint64, _p, _p]),
+    "cm3d_selftest_mfma": (_i32, [C.c_uint64, _i32, _p, _p]),
     "cm3d_medoid_workspace_bytes": (_i64, [_i32, _i32]),
     "cm3d_medoid": (_i32, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _p]),
     "cm3d_lane_grid_bytes": (_i64, [_i32, _i32]),

@@ -29,7 +29,11 @@
 #define MD_LONG_MAX 100000               // ... and shorter than this (the error bound of the first pass is derived for M < 10^5)
 static __device__ __forceinline__ bool md_two_pass(int M) { return M > MD_LONG_MIN && M < MD_LONG_MAX; }
 
+#ifndef MD_APPROX_MFMA
+#define MD_APPROX_MFMA 1                 // first pass over long lists on the matrix pipe (k_medoid_approx); 0: in k_medoid_tiles
+#endif
 typedef float f2 __attribute__((ext_vector_type(2)));      // two rows side by side: v_pk_{add,mul,fma}_f32
+typedef float f16v __attribute__((ext_vector_type(16)));   // accumulator of v_mfma_f32_32x32x2_f32
 typedef int i2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 #define PK_FMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
@@ -175,9 +179,79 @@ static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float
     return s;
 }
 
+// First pass over the LONG lists (md_two_pass) on the matrix pipe.  torch.cdist's expansion is a k-sequential float32 fma
+// chain over k = 0..4 of [-2x_i, -2y_i, -2z_i, n_i, 1] . [x_j, y_j, z_j, 1, n_j] -- exactly what v_mfma_f32_32x32x2_f32
+// computes (bit for bit a k-ordered fmaf chain, one rounding per product: cdna_hip_programming.md, FP32-input MFMA), so three
+// of them (k = 0,1 | 2,3 | 4,pad) give the reference's 32 x 32 squared distances with nothing left for the vector pipe but
+// max(., 0), v_sqrt_f32 and the sum.  (cm3d_selftest_mfma compares the MFMA values with the vector chain on the device.)
+// The sums are APPROXIMATE (v_sqrt_f32 is within one ulp; each lane adds its own 16 rows of a tile, the halves of a column
+// meet at the end): the error bound of k_medoid_long holds for any summation order, and the position comes out of its exact
+// second pass.  A 64-column tile = two 32-column MFMA tiles, one wave (k_medoid_tiles); rows staged through its LDS slice as
+// {-2x, -2z, -2y, n}: lanes 0-31 feed k even (x, z, the 1), lanes 32-63 k odd (y, n, 0).
+#define MDA_STAGE 256
+static __device__ __forceinline__ float md_vsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+template <typename Fetch>
+static __device__ __forceinline__ void md_approx_tile(Fetch fetch, float *s_rows, int off, int M, int jt, float *__restrict__ approx_out)
+{
+    const int lane = cm3d_lane();
+    const bool lo = lane < 32;
+    // column operands of the two 32-column groups: lanes 0-31 carry (x, z, n), lanes 32-63 (y, 1, 0)
+    float b1[2], b2[2], b3[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int j = jt * 64 + g * 32 + (lane & 31);
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (j < M) { const float4 q = fetch(off + j); qx = q.x; qy = q.y; qz = q.z; }
+        const float qn = (qx * qx + qy * qy) + qz * qz;
+        b1[g] = lo ? qx : qy; b2[g] = lo ? qz : 1.0f; b3[g] = lo ? qn : 0.0f;
+    }
+    float s[2] = {0.f, 0.f};
+    for (int i0 = 0; i0 < M; i0 += MDA_STAGE) {
+        __builtin_amdgcn_wave_barrier();                      // the previous rows' readers are done
+        float4 g4[MDA_STAGE / 64];
+#pragma unroll
+        for (int c = 0; c < MDA_STAGE / 64; ++c)
+            if (i0 + c * 64 + lane < M) g4[c] = fetch(off + i0 + c * 64 + lane);
+#pragma unroll
+        for (int c = 0; c < MDA_STAGE / 64; ++c) {
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);       // rows past the end: all zeros, and their k = 4 factor is 0 too
+            if (i0 + c * 64 + lane < M) {
+                const float4 p = g4[c];
+                r = make_float4(-2.0f * p.x, -2.0f * p.z, -2.0f * p.y, (p.x * p.x + p.y * p.y) + p.z * p.z);
+            }
+            *reinterpret_cast<float4 *>(s_rows + 4 * (c * 64 + lane)) = r;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cnt = min(MDA_STAGE, M - i0);
+        for (int r0 = 0; r0 < cnt; r0 += 32) {
+            const int row = r0 + (lane & 31);
+            const float2 a = *reinterpret_cast<const float2 *>(s_rows + 4 * row + (lo ? 0 : 2));
+            const float a3 = (lo && row < cnt) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[g], c, 0, 0, 0);        // k = 0, 1
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b2[g], c, 0, 0, 0);        // k = 2, 3
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3[g], c, 0, 0, 0);         // k = 4, (5: 0 * 0)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s[g] += md_vsqrt(fmaxf(c[q], 0.0f));        // clamp_min_(0), root, this lane's rows
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float tot = s[g] + __shfl_xor(s[g], 32, 64);   // the two halves of the rows of column lane & 31
+        const int j = jt * 64 + g * 32 + lane;
+        if (lo && j < M) approx_out[off + j] = tot;
+    }
+}
+
 // One wave = one tile = 64 columns of one mask; rows are staged 64 at a time through the wave's own
 // LDS slice and read back as broadcasts.  No workgroup barrier: waves of a block are independent.
-__global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__restrict__ points,
+__global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__restrict__ points,
                                                               const int32_t *__restrict__ pt_off,
                                                               const int32_t *__restrict__ mask_frame, int n_masks,
                                                               const int32_t *__restrict__ tile_off,
@@ -209,7 +283,11 @@ __global__ __launch_bounds__(MD_THREADS) void k_medoid_tiles(const float4 *__res
         }
         float s = 0.f;
         const bool direct = M <= 25;
-        const bool approx = approx_opt != nullptr && md_two_pass(M);      // long list: approximate sums now, k_medoid_long later
+        const bool approx = approx_opt != nullptr && md_two_pass(M);      // long list: approximate sums (k_medoid_approx), k_medoid_long later
+        if (approx && MD_APPROX_MFMA) {
+            md_approx_tile(fetch, reinterpret_cast<float *>(s_row), off, M, jt, approx_opt);
+            continue;
+        }
         // Rows are staged MD_STAGE (512) at a time: all their index loads, then all their point gathers are in
         // flight together (two memory latencies per 512 rows; a 64-row pipeline left the longest lists -- the
         // waves the kernel waits for -- bound by one dependent gather per chunk).
@@ -290,106 +368,193 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
 }
 
 // Long lists, second pass.  k_medoid_tiles left A_j, the column sums with v_sqrt_f32 roots in place of the correctly
-// rounded ones.  With t_i the exact and t'_i the approximate terms (|t'_i - t_i| <= 2^-23 t_i, or <= 1e-15 below 1e-30)
-// and both sums accumulated in the same order in float32 (each add rounds by <= 2^-24 of a partial sum, and partial sums
-// of non-negative terms never exceed the final sum), |A_j - S_j| <= (2^-23 sum_i t_i + M 1e-15) + M 2^-24 (A_j + S_j) up to
-// factors 1 + O(M 2^-24); solved for A_j this stays below E_j = 1.01 (M + 2) 2^-23 A_j + M 2e-15 for M < 10^5.  A column can only be the (first) minimum of the
-// exact sums if A_j - E_j <= min_k (A_k + E_k); those few columns -- the points within centimetres of the medoid -- get
-// their exact float32 sums here, 64 at a time, by the same row loop as k_medoid_tiles.  A non-finite A_j makes every
-// column a candidate; lists of 10^5 points and more stay on the one-pass route.  One wave per mask.
-__global__ __launch_bounds__(64) void k_medoid_long(const float4 *__restrict__ points, const int32_t *__restrict__ pt_off,
-                                                    const int32_t *__restrict__ mask_frame, int n_masks,
-                                                    const int32_t *__restrict__ hit_off, const int32_t *__restrict__ hit_row,
-                                                    int idx_cap, const float *__restrict__ approx,
-                                                    int32_t *__restrict__ medoid_pos, float *__restrict__ centroid)
+// rounded ones, summed in some order.  With t_i the exact and t'_i the approximate terms (|t'_i - t_i| <= 2^-23 t_i, or
+// <= 1e-15 below 1e-30) and float32 sums of non-negative terms (each add rounds by <= 2^-24 of a partial sum, and partial
+// sums never exceed the final sum, whatever the order), |A_j - S_j| <= (2^-23 sum_i t_i + M 1e-15) + M 2^-24 (A_j + S_j) up to
+// factors 1 + O(M 2^-24); solved for A_j this stays below E_j = 1.01 (M + 2) 2^-23 A_j + M 2e-15 for M < 10^5.  A column can
+// only be the (first) minimum of the exact sums if A_j - E_j <= min_k (A_k + E_k); those few columns -- the points within
+// centimetres of the medoid -- get their exact float32 sums here.  A non-finite A_j makes every column a candidate; lists
+// of 10^5 points and more stay on the one-pass route.
+// One workgroup of 8 waves per long mask.  A handful of candidates (the rule) are settled ROW-parallel, one candidate per
+// wave at a time: the 64 lanes take 64 consecutive rows, compute their distances to the candidate together, and the sum
+// runs over them in ascending row order (v_readlane + v_add, the only serial part) -- the very additions, in the very
+// order, of the column-per-lane loop, at a fraction of its time when few of the 64 columns are wanted.  More than
+// MDL_MAXC candidates (lists full of duplicated points): wave 0 takes them 64 columns at a time, as k_medoid_tiles does.
+#define MDL_WAVES 8
+#define MDL_MAXC 64
+
+// exact float32 distance of this lane's row to the candidate (qx, qy, qz, qn): md_pair2<false> + the correctly rounded root
+static __device__ __forceinline__ float md_exact_dist(float4 p, float qx, float qy, float qz, float qn)
+{
+    const float n = (p.x * p.x + p.y * p.y) + p.z * p.z;
+    float acc = (-2.0f * p.x) * qx;
+    acc = fmaf(-2.0f * p.y, qy, acc);
+    acc = fmaf(-2.0f * p.z, qz, acc);
+    acc = acc + n;
+    acc = acc + qn;
+    acc = fmaxf(acc, 0.0f);
+    return md_sqrt_ok(acc) ? md_sqrt_core2((f2){acc, acc}).x : sqrtf(acc);      // both forms are the correctly rounded root
+}
+
+template <typename Fetch>
+static __device__ __forceinline__ float md_exact_colsum_rows(Fetch fetch, int off, int M, int cj)
+{
+    const int lane = cm3d_lane();
+    const float4 q = fetch(off + cj);                           // uniform
+    const float qx = q.x, qy = q.y, qz = q.z, qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
+    float s = 0.0f;
+    float4 p = lane < M ? fetch(off + lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i0 = 0; i0 < M; i0 += 64) {
+        const float4 pn = i0 + 64 + lane < M ? fetch(off + i0 + 64 + lane) : make_float4(0.f, 0.f, 0.f, 0.f);      // next rows under the chain
+        const float d = i0 + lane < M ? md_exact_dist(p, qx, qy, qz, qn) : 0.0f;
+        const int cnt = min(64, M - i0);
+        if (cnt == 64) {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), k));
+        } else {
+            for (int k = 0; k < cnt; ++k) s = s + __shfl(d, k, 64);
+        }
+        p = pn;
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(64 * MDL_WAVES) void k_medoid_long(const float4 *__restrict__ points, const int32_t *__restrict__ pt_off,
+                                                                const int32_t *__restrict__ mask_frame, int n_masks,
+                                                                const int32_t *__restrict__ hit_off, const int32_t *__restrict__ hit_row,
+                                                                int idx_cap, const float *__restrict__ approx,
+                                                                int32_t *__restrict__ medoid_pos, float *__restrict__ centroid)
 {
     __shared__ float4 s_row[MD_STAGE];
     __shared__ int s_cand[64];
-    const int m = blockIdx.x, lane = cm3d_lane();
+    __shared__ int s_list[MDL_MAXC];
+    __shared__ float s_sum[MDL_MAXC];
+    __shared__ double s_thr[MDL_WAVES];
+    __shared__ int s_n, s_all;
+    const int m = blockIdx.x, lane = cm3d_lane(), t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int off = hit_off[m], M = hit_off[m + 1] - off;
-    if (!md_two_pass(M) || off + M > idx_cap) return;
+    if (!md_two_pass(M) || off + M > idx_cap) return;                      // the whole workgroup
     const float4 *P = hit_row ? points + pt_off[mask_frame[m]] : points;
     auto fetch = [&](int q) { return hit_row ? P[hit_row[q]] : P[q]; };
     const float *A = approx + off;
     const double rel = 1.01 * (double)(M + 2) * 1.1920928955078125e-07, abs_e = (double)M * 2e-15;
-    // threshold = min_k (A_k + E_k); anything non-finite -> every column is a candidate
-    double thr = INFINITY;
-    bool all = false;
-    for (int j = lane; j < M; j += 64) {
-        const double a = (double)A[j];
-        if (!(a >= 0.0 && a < 1e300)) all = true;
-        thr = fmin(thr, a + (a * rel + abs_e));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) thr = fmin(thr, __shfl_xor(thr, o, 64));
-    all = __ballot(all) != 0;
     auto better = [](float s1, int j1, float s2, int j2) {   // is (s1,j1) ahead of (s2,j2)?  (torch.argmin order)
         const bool n1 = s1 != s1, n2 = s2 != s2;
         if (n1 != n2) return n1;
         if (!n1 && s1 != s2) return s1 < s2;
         return j1 < j2;
     };
+    if (t == 0) { s_n = 0; s_all = 0; }
+    __syncthreads();
+    // threshold = min_k (A_k + E_k); anything non-finite -> every column is a candidate
+    double thr = INFINITY;
+    bool all = false;
+    for (int j = t; j < M; j += 64 * MDL_WAVES) {
+        const double a = (double)A[j];
+        if (!(a >= 0.0 && a < 1e300)) all = true;
+        thr = fmin(thr, a + (a * rel + abs_e));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) thr = fmin(thr, __shfl_xor(thr, o, 64));
+    if (lane == 0) s_thr[wave] = thr;
+    if (__ballot(all) && lane == 0) atomicOr(&s_all, 1);
+    __syncthreads();
+    thr = s_thr[0];
+#pragma unroll
+    for (int w = 1; w < MDL_WAVES; ++w) thr = fmin(thr, s_thr[w]);
+    all = s_all != 0;
+    // the candidates (in no particular order: the final choice is a total order on (sum, index))
+    for (int j = t; j < M; j += 64 * MDL_WAVES) {
+        const double a = (double)A[j];
+        if (all || (a - (a * rel + abs_e) <= thr)) {
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < MDL_MAXC) s_list[pos] = j;
+        }
+    }
+    __syncthreads();
+    const int C = s_n;
     float best_s = INFINITY;
     int best_j = 0x7FFFFFFF;
-    int nc = 0;                                   // candidates waiting in s_cand (uniform)
-    for (int j0 = 0; j0 < M + 64; j0 += 64) {     // one extra round flushes the tail
-        const int j = j0 + lane;
-        bool cand = false;
-        if (j < M) {
-            const double a = (double)A[j];
-            cand = all || (a - (a * rel + abs_e) <= thr);
+    if (C <= MDL_MAXC) {
+        for (int c = wave; c < C; c += MDL_WAVES) {
+            const float sc = md_exact_colsum_rows(fetch, off, M, s_list[c]);
+            if (lane == 0) s_sum[c] = sc;
         }
-        const uint64_t cm = __ballot(cand);
-        const int add = (int)__popcll(cm);
-        const bool last = j0 >= M;
-        if (nc + add > 64 || (last && nc > 0)) {
-            // exact sums of the waiting candidates: lane l owns column s_cand[l]
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const bool act = lane < nc;
-            const int cj = act ? s_cand[lane] : 0;
-            float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
-            if (act) {
-                const float4 q = fetch(off + cj);
-                qx = q.x; qy = q.y; qz = q.z;
-                qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
+        __syncthreads();
+        if (wave != 0) return;
+        float bs = lane < C ? s_sum[lane] : INFINITY;
+        int bj = lane < C ? s_list[lane] : 0x7FFFFFFF;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o, 64);
+            const int oj = __shfl_xor(bj, o, 64);
+            if (better(os, oj, bs, bj)) { bs = os; bj = oj; }
+        }
+        best_s = bs; best_j = bj;
+    } else {
+        if (wave != 0) return;
+        // many candidates: 64 columns at a time, column per lane (the row loop of k_medoid_tiles)
+        int nc = 0;                                   // candidates waiting in s_cand (uniform)
+        for (int j0 = 0; j0 < M + 64; j0 += 64) {     // one extra round flushes the tail
+            const int j = j0 + lane;
+            bool cand = false;
+            if (j < M) {
+                const double a = (double)A[j];
+                cand = all || (a - (a * rel + abs_e) <= thr);
             }
-            float s = 0.f;
-            for (int i0 = 0; i0 < M; i0 += MD_STAGE) {
-                __builtin_amdgcn_wave_barrier();
-                float4 g[MD_STAGE / 64];
-#pragma unroll
-                for (int c = 0; c < MD_STAGE / 64; ++c)
-                    if (i0 + c * 64 + lane < M) g[c] = fetch(off + i0 + c * 64 + lane);
-#pragma unroll
-                for (int c = 0; c < MD_STAGE / 64; ++c) {
-                    if (i0 + c * 64 + lane < M) {
-                        float4 r = g[c];
-                        r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
-                        r.x = -2.0f * r.x; r.y = -2.0f * r.y; r.z = -2.0f * r.z;
-                        md_stage(s_row, c * 64 + lane, r);
-                    }
-                }
+            const uint64_t cm = __ballot(cand);
+            const int add = (int)__popcll(cm);
+            const bool last = j0 >= M;
+            if (nc + add > 64 || (last && nc > 0)) {
+                // exact sums of the waiting candidates: lane l owns column s_cand[l]
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                s = md_rows<false>(s_row, min(MD_STAGE, M - i0), qx, qy, qz, qn, s);
-            }
-            float bs = act ? s : INFINITY;
-            int bj = act ? cj : 0x7FFFFFFF;
+                const bool act = lane < nc;
+                const int cj = act ? s_cand[lane] : 0;
+                float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
+                if (act) {
+                    const float4 q = fetch(off + cj);
+                    qx = q.x; qy = q.y; qz = q.z;
+                    qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
+                }
+                float s = 0.f;
+                for (int i0 = 0; i0 < M; i0 += MD_STAGE) {
+                    __builtin_amdgcn_wave_barrier();
+                    float4 g[MD_STAGE / 64];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float os = __shfl_xor(bs, o, 64);
-                const int oj = __shfl_xor(bj, o, 64);
-                if (better(os, oj, bs, bj)) { bs = os; bj = oj; }
+                    for (int c = 0; c < MD_STAGE / 64; ++c)
+                        if (i0 + c * 64 + lane < M) g[c] = fetch(off + i0 + c * 64 + lane);
+#pragma unroll
+                    for (int c = 0; c < MD_STAGE / 64; ++c) {
+                        if (i0 + c * 64 + lane < M) {
+                            float4 r = g[c];
+                            r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
+                            r.x = -2.0f * r.x; r.y = -2.0f * r.y; r.z = -2.0f * r.z;
+                            md_stage(s_row, c * 64 + lane, r);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    s = md_rows<false>(s_row, min(MD_STAGE, M - i0), qx, qy, qz, qn, s);
+                }
+                float bs = act ? s : INFINITY;
+                int bj = act ? cj : 0x7FFFFFFF;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float os = __shfl_xor(bs, o, 64);
+                    const int oj = __shfl_xor(bj, o, 64);
+                    if (better(os, oj, bs, bj)) { bs = os; bj = oj; }
+                }
+                if (bj != 0x7FFFFFFF && (best_j == 0x7FFFFFFF || better(bs, bj, best_s, best_j))) { best_s = bs; best_j = bj; }
+                nc = 0;
+                __builtin_amdgcn_wave_barrier();
             }
-            if (bj != 0x7FFFFFFF && (best_j == 0x7FFFFFFF || better(bs, bj, best_s, best_j))) { best_s = bs; best_j = bj; }
-            nc = 0;
-            __builtin_amdgcn_wave_barrier();
+            if (cand) s_cand[nc + cm3d_mbcnt(cm)] = j;
+            nc += add;
         }
-        if (cand) s_cand[nc + cm3d_mbcnt(cm)] = j;
-        nc += add;
     }
     if (lane == 0) {
         const int bj = best_j == 0x7FFFFFFF ? -1 : best_j;
@@ -451,7 +616,7 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
                        n_masks, hit_off, tile_off, hit_row, idx_cap, best, tile_cap, approx ? 1 : 0, medoid_pos, centroid);
     CM3D_CHECK_LAUNCH();
     if (approx) {
-        hipLaunchKernelGGL(k_medoid_long, dim3(n_masks), dim3(64), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks, hit_off,
+        hipLaunchKernelGGL(k_medoid_long, dim3(n_masks), dim3(64 * MDL_WAVES), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks, hit_off,
                            hit_row, idx_cap, approx, medoid_pos, centroid);
         CM3D_CHECK_LAUNCH();
     }
@@ -488,6 +653,57 @@ extern "C" int cm3d_selftest_sqrt(uint32_t first_bits, uint32_t last_bits, uint6
     if (hipMemsetAsync(n_bad, 0, sizeof(uint64_t), st) != hipSuccess) return CM3D_ERR_LAUNCH;
     if (hipMemsetAsync(first_bad, 0xFF, sizeof(uint32_t), st) != hipSuccess) return CM3D_ERR_LAUNCH;
     hipLaunchKernelGGL(k_selftest_sqrt, dim3(8192), dim3(256), 0, st, first_bits, last_bits, (unsigned long long *)n_bad, first_bad);
+    CM3D_CHECK_LAUNCH();
+    return CM3D_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Diagnostic: the squared distances of k_medoid_approx (three v_mfma_f32_32x32x2_f32) against the vector pipe's fma chain
+// (md_pair2<false>, the form the exact route uses) on pseudo-random points at global-frame magnitudes: every one of the
+// 32 x 32 values of every tile must be bit-identical.  n_bad (device) = number of differing values.
+__global__ __launch_bounds__(64) void k_selftest_mfma(uint64_t seed, int tiles_per_wave, unsigned long long *n_bad)
+{
+    const int lane = cm3d_lane();
+    const bool lo = lane < 32;
+    uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * ((uint64_t)blockIdx.x * 64 + lane + 1));
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    auto coord = [&](float centre, float spread) { return centre + spread * ((float)(next() & 0xFFFFFF) * (1.0f / 8388608.0f) - 1.0f); };
+    unsigned long long bad = 0;
+    for (int t = 0; t < tiles_per_wave; ++t) {
+        // lane l < 32 owns row l and column l of this tile; magnitudes like nuScenes' global frame, objects a few metres wide
+        const float cx = 300.0f + 40.0f * (float)(t % 37), cy = 900.0f + 25.0f * (float)(t % 53), spread = (t & 1) ? 3.0f : 40.0f;
+        const float rx = coord(cx, spread), ry = coord(cy, spread), rz = coord(1.0f, 2.0f);
+        const float qx = coord(cx, spread), qy = coord(cy, spread), qz = coord(1.0f, 2.0f);
+        const float rn = (rx * rx + ry * ry) + rz * rz, qn = (qx * qx + qy * qy) + qz * qz;
+        // operands as k_medoid_approx lays them out (values of lane l & 31 in both halves)
+        const float Rx = __shfl(rx, lane & 31, 64), Ry = __shfl(ry, lane & 31, 64), Rz = __shfl(rz, lane & 31, 64), Rn = __shfl(rn, lane & 31, 64);
+        const float Qx = __shfl(qx, lane & 31, 64), Qy = __shfl(qy, lane & 31, 64), Qz = __shfl(qz, lane & 31, 64), Qn = __shfl(qn, lane & 31, 64);
+        f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? -2.0f * Rx : -2.0f * Ry, lo ? Qx : Qy, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? -2.0f * Rz : Rn, lo ? Qz : 1.0f, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? 1.0f : 0.0f, lo ? Qn : 0.0f, c, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);          // C/D map of the 32x32 shapes; column = lane & 31
+            const float ix = __shfl(rx, row, 64), iy = __shfl(ry, row, 64), iz = __shfl(rz, row, 64), in_ = __shfl(rn, row, 64);
+            float acc = (-2.0f * ix) * Qx;                                      // the reference's chain
+            acc = fmaf(-2.0f * iy, Qy, acc);
+            acc = fmaf(-2.0f * iz, Qz, acc);
+            acc = fmaf(in_, 1.0f, acc);
+            acc = fmaf(1.0f, Qn, acc);
+            // (a first product of -0 would come out of the MFMA as +0: both are clamped to 0 before the root)
+            if (__float_as_uint(acc) != __float_as_uint(c[q]) && !(acc == 0.0f && c[q] == 0.0f)) ++bad;
+        }
+    }
+    if (bad) atomicAdd(n_bad, bad);
+}
+
+extern "C" int cm3d_selftest_mfma(uint64_t seed, int32_t tiles_per_wave, uint64_t *n_bad, cm3d_stream_t stream)
+{
+    if (!n_bad || tiles_per_wave <= 0) return CM3D_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(n_bad, 0, sizeof(uint64_t), st) != hipSuccess) return CM3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_selftest_mfma, dim3(2048), dim3(64), 0, st, seed, tiles_per_wave, (unsigned long long *)n_bad);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

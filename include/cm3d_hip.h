@@ -209,6 +209,12 @@ int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_
  * rejects those points whatever the low bits are). */
 int cm3d_selftest_div(uint64_t seed, uint64_t count, uint64_t *n_bad, cm3d_stream_t stream);
 
+/* Diagnostic for the tests: the first pass over long medoid lists takes its squared distances from the matrix pipe
+ * (three v_mfma_f32_32x32x2_f32 = the reference's five-term fma chain).  2048 waves x tiles_per_wave tiles of 32 x 32 pairs of
+ * pseudo-random points at global-frame magnitudes through the MFMAs and through the vector fma chain; *n_bad (device) = values
+ * that differ in any bit (must be 0). */
+int cm3d_selftest_mfma(uint64_t seed, int32_t tiles_per_wave, uint64_t *n_bad, cm3d_stream_t stream);
+
 /* Diagnostic for the tests: runs every float32 bit pattern in [first_bits, last_bits] (positive values) that lies in
  * the medoid kernel's fast-path domain [1e-30, 1e30) through the kernel's square root, its reference form and sqrtf();
  * *n_bad (device) = number of values on which the three are not bit-identical, *first_bad = smallest such pattern. */

@@ -187,6 +187,20 @@ def test_lane_nn_grid_equals_brute_force(oracle):
         assert np.array_equal(yaws, lane32[j, 2]) and np.array_equal(coords, lane32[j, :2]), f"trial {trial}"
 
 
+def test_mfma_distances_equal_the_vector_fma_chain():
+    """The first pass over long medoid lists (k_medoid_approx) takes torch.cdist's five-term float32 fma chain from three
+    v_mfma_f32_32x32x2_f32: on 2048 x 200 tiles of 32 x 32 point pairs at global-frame magnitudes (clusters 3 m and 40 m wide)
+    every value must equal the vector pipe's chain bit for bit."""
+    import torch
+    from cm3d_amd import _lib
+    L = _lib.lib()
+    n_bad = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    for seed in (1, 0xC0FFEE):
+        _lib.check(L.cm3d_selftest_mfma(seed, 200, n_bad.data_ptr(), torch.cuda.current_stream().cuda_stream), "cm3d_selftest_mfma")
+        torch.cuda.synchronize()
+        assert int(n_bad.item()) == 0
+
+
 def test_medoid_sqrt_is_correctly_rounded_on_its_whole_domain():
     """The medoid kernel's packed square root (rsq + coupled Newton step + residual correction), its neighbour-test
     reference form and sqrtf() agree bit for bit on EVERY float32 in [1e-30, 1e30) -- 1.67e9 values, checked on

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """gpurun_out/<tag>/ (written by tools/collect_profiles.sh) -> profiles/<tag>_*  and profiles/traffic.json.
 
-HBM traffic per launch follows MI355X_MICROARCH.md 'HBM': separate --pmc passes for FETCH_SIZE and
-WRITE_SIZE (KiB); on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced (16 B/lane)
-streaming read, so kernels whose reads are such streams are doubled (listed in STREAM_READERS);
-WRITE_SIZE is taken as is."""
+HBM traffic per launch follows MI355X_MICROARCH.md 'HBM': separate --pmc passes for FETCH_SIZE and WRITE_SIZE (KiB).
+On gfx950 FETCH_SIZE reports half of the bytes of 16-byte-per-lane reads, so kernels whose reads are such loads are doubled
+(STREAM_READERS); the projection kernel is one of them: its rows arrive as 16-byte loads, its compulsory read (the raw rows,
+4 x stride x rows bytes) is known exactly, and the doubled counter lands just above it (the rest: mask words, tables).
+WRITE_SIZE is taken as is (it matches the projection's hit words + counts to the percent)."""
 import collections
 import csv
 import json
@@ -12,27 +13,24 @@ import os
 import shutil
 import sys
 
-STREAM_READERS = {"k_project_hits_unfused", "k_erode_pack"}        # float4 / uint4 coalesced point and mask streams
-# (the default pass runs k_project_hits<.., FUSED = true>, which reads the raw sweep rows dword by dword: no correction)
+STREAM_READERS = {"k_project_hits", "k_erode_pack", "k_compact_hits"}        # 16-byte-per-lane loads
 
 
 def kname(full):
-    """'void k_project_hits<true>(float4 const*, ...)' -> 'k_project_hits'"""
+    """'void k_project_hits<true, true, 5>(float const*, ...)' -> 'k_project_hits'"""
     n = full.split("(")[0].strip()
     if n.startswith("void "):
         n = n[5:]
-    base = n.split("<")[0]
-    if base == "k_project_hits" and n.replace(" ", "").endswith(",false>"):
-        return "k_project_hits_unfused"
-    return base
+    return n.split("<")[0]
 
 
 def main(tag):
     src = os.path.join("gpurun_out", tag)
     os.makedirs("profiles", exist_ok=True)
     shutil.copy(os.path.join(src, "kt", "k_kernel_stats.csv"), f"profiles/{tag}_c2_rle_kernel_stats.csv")
+    shutil.copy(os.path.join(src, "kt1", "k_kernel_stats.csv"), f"profiles/{tag}_c2_rle_one_batch_kernel_stats.csv")
     shutil.copy(os.path.join(src, "bench_profiled.json"), f"profiles/{tag}_c2_rle_bench_profiled.json")
-    shutil.copy(os.path.join(src, "bench_default.json"), f"profiles/{tag}_bench_default.json")
+    shutil.copy(os.path.join(src, "bench_profiled_one_batch.json"), f"profiles/{tag}_c2_rle_one_batch_bench_profiled.json")
     tr = collections.defaultdict(dict)
     for d, c in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         agg = collections.defaultdict(list)
@@ -53,13 +51,16 @@ def main(tag):
     traffic = {"c2_rle": {k: v["hbm_bytes_per_launch"] for k, v in out.items()}, "source": f"profiles/{tag}_c2_rle_pmc_traffic.json",
                "frames_per_gpu": 256}
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
-    rows = list(csv.DictReader(open(f"profiles/{tag}_c2_rle_kernel_stats.csv")))
-    print(f"{'kernel':42s} {'calls':>5s} {'avg_us':>9s} {'%':>6s} {'HBM MB/launch':>14s}")
-    for r in rows[:24]:
-        name = kname(r["Name"])
-        mb = out.get(name, {}).get("hbm_bytes_per_launch")
-        print(f"{name[:42]:42s} {r['Calls']:>5s} {float(r['AverageNs']) / 1e3:9.1f} {float(r['Percentage']):6.2f} {'' if mb is None else f'{mb / 1e6:14.1f}'}")
+    for label, fn in (("three batches in flight (default)", f"profiles/{tag}_c2_rle_kernel_stats.csv"),
+                      ("one batch at a time", f"profiles/{tag}_c2_rle_one_batch_kernel_stats.csv")):
+        rows = list(csv.DictReader(open(fn)))
+        print(label)
+        print(f"  {'kernel':42s} {'calls':>5s} {'avg_us':>9s} {'%':>6s} {'HBM MB/launch':>14s}")
+        for r in rows[:16]:
+            name = kname(r["Name"])
+            mb = out.get(name, {}).get("hbm_bytes_per_launch")
+            print(f"  {name[:42]:42s} {r['Calls']:>5s} {float(r['AverageNs']) / 1e3:9.1f} {float(r['Percentage']):6.2f} {'' if mb is None else f'{mb / 1e6:14.1f}'}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
