@@ -433,15 +433,19 @@ def main(argv=None):
         torch.cuda.synchronize()
         for e in pipe.engines:
             e.check_status()
+        ev_every = 1 if args.steps <= 16 else 8        # an event pair costs ~5 us of stream time: sample every 8th step
+        for _ in range(0, args.steps, ev_every):        # created (first record) outside the timed region
+            pe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pe[0].record()
+            pe[1].record()
+            ev["project"].append(pe)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ev_every = 1 if args.steps <= 16 else 8        # an event pair costs ~5 us of stream time: sample every 8th step
         for step in range(args.steps):
             pe = None
-            if step % ev_every == 0:    # HIP events around the roofline kernel only, on its launch stream
-                pe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev["project"].append(pe)
+            if step % ev_every == 0:    # HIP events around the roofline kernel only, recorded by the library on its launch stream
+                pe = ev["project"][step // ev_every]
             pipe.rerun(step % depth, masks=mode, project_events=pe)       # LiftEngine.run() on that batch's stream
         gathered = None
         if mode == modes[0]:
@@ -466,9 +470,14 @@ def main(argv=None):
                 for s in stages:
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()
-                    calls[s](st)
-                    b.record()
-                    (alone if s == "project" else ev[s]).append((a, b))
+                    if s == "project":      # the library records the pair around the projection kernel itself
+                        b.record()
+                        calls[s](st, (a, b))
+                        alone.append((a, b))
+                    else:
+                        calls[s](st)
+                        b.record()
+                        ev[s].append((a, b))
         torch.cuda.synchronize()
         stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) for s in stages}
         project_alone_ms = float(np.mean([a.elapsed_time(b) for a, b in alone]))

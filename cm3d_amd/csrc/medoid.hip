@@ -431,10 +431,13 @@ __global__ __launch_bounds__(64 * MDL_WAVES) void k_medoid_long(const float4 *__
     __shared__ float s_sum[MDL_MAXC];
     __shared__ double s_thr[MDL_WAVES];
     __shared__ int s_n, s_all;
-    const int m = blockIdx.x, lane = cm3d_lane(), t = threadIdx.x;
+    const int lane = cm3d_lane(), t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // a workgroup walks masks blockIdx.x, + gridDim.x, ...: most lists are short and cost one scalar load here
+    for (int m = blockIdx.x; m < n_masks; m += gridDim.x) {
     const int off = hit_off[m], M = hit_off[m + 1] - off;
-    if (!md_two_pass(M) || off + M > idx_cap) return;                      // the whole workgroup
+    if (!md_two_pass(M) || off + M > idx_cap) continue;                    // the whole workgroup
+    __syncthreads();                                                       // the previous long mask's LDS state is done with
     const float4 *P = hit_row ? points + pt_off[mask_frame[m]] : points;
     auto fetch = [&](int q) { return hit_row ? P[hit_row[q]] : P[q]; };
     const float *A = approx + off;
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(64 * MDL_WAVES) void k_medoid_long(const float4 *__
             if (lane == 0) s_sum[c] = sc;
         }
         __syncthreads();
-        if (wave != 0) return;
+        if (wave != 0) continue;
         float bs = lane < C ? s_sum[lane] : INFINITY;
         int bj = lane < C ? s_list[lane] : 0x7FFFFFFF;
 #pragma unroll
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(64 * MDL_WAVES) void k_medoid_long(const float4 *__
         }
         best_s = bs; best_j = bj;
     } else {
-        if (wave != 0) return;
+        if (wave != 0) continue;
         // many candidates: 64 columns at a time, column per lane (the row loop of k_medoid_tiles)
         int nc = 0;                                   // candidates waiting in s_cand (uniform)
         for (int j0 = 0; j0 < M + 64; j0 += 64) {     // one extra round flushes the tail
@@ -566,6 +569,7 @@ __global__ __launch_bounds__(64 * MDL_WAVES) void k_medoid_long(const float4 *__
         }
         centroid[3 * m + 0] = cx; centroid[3 * m + 1] = cy; centroid[3 * m + 2] = cz;
     }
+    }
 }
 
 extern "C" int64_t cm3d_tile_work_bytes(int32_t n_masks, int32_t idx_cap)
@@ -616,7 +620,7 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
                        n_masks, hit_off, tile_off, hit_row, idx_cap, best, tile_cap, approx ? 1 : 0, medoid_pos, centroid);
     CM3D_CHECK_LAUNCH();
     if (approx) {
-        hipLaunchKernelGGL(k_medoid_long, dim3(n_masks), dim3(64 * MDL_WAVES), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks, hit_off,
+        hipLaunchKernelGGL(k_medoid_long, dim3(n_masks < 512 ? n_masks : 512), dim3(64 * MDL_WAVES), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks, hit_off,
                            hit_row, idx_cap, approx, medoid_pos, centroid);
         CM3D_CHECK_LAUNCH();
     }

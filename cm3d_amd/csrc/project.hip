@@ -205,13 +205,23 @@ static __device__ __forceinline__ void project_quad(const float *cm, int ns, int
 //    *margin_px = 1 + ceil(2 max(fx, fy) delta / zmin) pixels for every point the depth test can accept.
 // A camera record the derivation does not cover (skew, non-trivial last row of K, stages that are not rigid) disables both
 // tests for that camera (the cone accepts everything, *apx_ok = false).
-static __device__ void cone_setup(const float *cm, int W, int H, float min_dist, float *out, float *apx, int *margin_px, bool *apx_ok)
+static __device__ void cone_setup(const float *cm_global, int W, int H, float min_dist, float *out, float *apx, int *margin_px, bool *apx_ok)
 {
+    // the whole record in registers first (14 independent 16-byte loads in flight at once; the record is 224 bytes and
+    // 16-byte aligned), so that the composition below never waits on memory stage by stage
+    float cm[CM3D_CAM_STRIDE];
+#pragma unroll
+    for (int q = 0; q < CM3D_CAM_STRIDE / 4; ++q) {
+        const float4 v = reinterpret_cast<const float4 *>(cm_global)[q];
+        cm[4 * q] = v.x; cm[4 * q + 1] = v.y; cm[4 * q + 2] = v.z; cm[4 * q + 3] = v.w;
+    }
     const float *K = cm + 45;
     const int ns = (int)cm[54], fl = (int)cm[55];
     // compose the stages: p_cam = M p + c
     double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, c[3] = {0, 0, 0};
-    for (int s = 0; s < ns && s < 3; ++s) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s >= ns) break;
         const float *st = cm + 15 * s, *Rm = st + 3;
         if (fl & (1 << (2 * s))) { c[0] += (double)st[0]; c[1] += (double)st[1]; c[2] += (double)st[2]; }
         double Mn[9], cn[3];
@@ -1210,7 +1220,7 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
                      int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off, const int32_t *mask_cam,
                      const int32_t *bbox, const uint32_t *packed, int32_t n_masks, int32_t W, int32_t H, float min_dist,
                      int32_t planes, uint32_t *hit_words, int32_t *hit_count, int32_t *status, void *workspace,
-                     int64_t workspace_bytes, cm3d_stream_t stream)
+                     int64_t workspace_bytes, void *ev_start, void *ev_stop, cm3d_stream_t stream)
 {
     if (!cams || !mask_off || !mask_cam || !bbox || !packed || !hit_words || !hit_count || !status || !workspace) return CM3D_ERR_ARG;
     if (n_frames <= 0 || max_pts_per_frame <= 0 || n_points_total <= 0 || n_cams <= 0 || n_cams > CM3D_MAX_CAMS ||
@@ -1268,8 +1278,11 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
         else if (stride == 4) PH_LAUNCH(ONE, true, 4);                                                                           \
         else PH_LAUNCH(ONE, true, 0);                                                                                            \
     } while (0)
+    // optional timing events around the projection kernel itself (the table kernel above is not part of it)
+    if (ev_start && hipEventRecord((hipEvent_t)ev_start, st) != hipSuccess) return CM3D_ERR_LAUNCH;
     if (one) PH_LAUNCH_S(true);
     else PH_LAUNCH_S(false);
+    if (ev_stop && hipEventRecord((hipEvent_t)ev_stop, st) != hipSuccess) return CM3D_ERR_LAUNCH;
 #undef PH_LAUNCH_S
 #undef PH_LAUNCH
     CM3D_CHECK_LAUNCH();
@@ -1281,11 +1294,12 @@ extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int
                                  const int32_t *mask_cam, const int32_t *bbox, const uint32_t *packed, int32_t n_masks,
                                  int32_t W, int32_t H, float min_dist, int32_t planes, uint32_t *hit_words,
                                  int32_t *hit_count, int32_t *status, void *workspace, int64_t workspace_bytes,
-                                 cm3d_stream_t stream)
+                                 void *ev_start, void *ev_stop, cm3d_stream_t stream)
 {
     if (!points || !pt_off) return CM3D_ERR_ARG;
     return ph_launch(nullptr, points, pt_off, n_frames, max_pts_per_frame, n_points_total, cams, n_cams, mask_off, mask_cam, bbox,
-                     packed, n_masks, W, H, min_dist, planes, hit_words, hit_count, status, workspace, workspace_bytes, stream);
+                     packed, n_masks, W, H, min_dist, planes, hit_words, hit_count, status, workspace, workspace_bytes, ev_start, ev_stop,
+                     stream);
 }
 
 extern "C" int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
@@ -1295,7 +1309,7 @@ extern "C" int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, con
                                        const float *cams, int32_t n_cams, const int32_t *mask_off, const int32_t *mask_cam,
                                        const int32_t *bbox, const uint32_t *packed, int32_t n_masks, int32_t W, int32_t H,
                                        float min_dist, int32_t planes, uint32_t *hit_words, int32_t *hit_count, int32_t *status,
-                                       void *workspace, int64_t workspace_bytes, cm3d_stream_t stream)
+                                       void *workspace, int64_t workspace_bytes, void *ev_start, void *ev_stop, cm3d_stream_t stream)
 {
     if (!raw || !sweep_row_off || !sweep_xf || !frame_sweep_off || !pt_off || !removed_bits) return CM3D_ERR_ARG;
     if (raw_stride < 4 || n_sweeps <= 0 || pt_cap <= 0 || ((uintptr_t)points & 15)) return CM3D_ERR_ARG;
@@ -1305,7 +1319,7 @@ extern "C" int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, con
     sw.frame_sweep_off = frame_sweep_off; sw.n_frames = n_frames; sw.n_sweeps = n_sweeps; sw.halfw = halfw;
     sw.points_out = (float4 *)points; sw.pt_cap = pt_cap; sw.pt_off_out = pt_off; sw.removed_bits = removed_bits;
     return ph_launch(&sw, nullptr, nullptr, n_frames, max_pts_per_frame, n_points_total, cams, n_cams, mask_off, mask_cam, bbox, packed,
-                     n_masks, W, H, min_dist, planes, hit_words, hit_count, status, workspace, workspace_bytes, stream);
+                     n_masks, W, H, min_dist, planes, hit_words, hit_count, status, workspace, workspace_bytes, ev_start, ev_stop, stream);
 }
 
 extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int32_t n_frames, int32_t max_pts_per_frame,

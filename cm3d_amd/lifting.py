@@ -400,26 +400,42 @@ class LiftEngine:
         else:
             raise ValueError(masks)
 
-    def stage_project(self, st):
+    def stage_project(self, st, events=None):
+        """events: optional pair of torch.cuda.Event (enable_timing) that the library records around the projection
+        kernel itself on the launch stream (bench.py's roofline timing)."""
         b = self.b
+        e0, e1 = self._raw_events(events)
         check(self.lib.cm3d_project_hits(_ptr(b.points), _ptr(b.pt_off), b.F, b.max_pts, b.pt_cap, _ptr(b.cams), b.hb.n_cams,
                                          _ptr(b.mask_off), _ptr(b.mask_cam), _ptr(b.bbox), _ptr(b.packed), b.M, b.W, b.H,
                                          self.min_dist, b.planes, _ptr(b.hit_words), _ptr(b.hit_count), _ptr(b.status),
-                                         _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_project_hits")
+                                         _ptr(b.pg_ws), b.pg_ws_bytes, e0, e1, st), "cm3d_project_hits")
+
+    @staticmethod
+    def _raw_events(events):
+        """torch events -> the hipEvent_t handles the C-ABI takes (created by a first record on the current stream)."""
+        if events is None:
+            return 0, 0
+        out = []
+        for ev in events:
+            if ev.cuda_event == 0 or ev.cuda_event is None:
+                ev.record()
+            out.append(int(ev.cuda_event))
+        return out[0], out[1]
 
     def can_fuse_sweeps(self):
         return self.b.fused
 
-    def stage_sweep_project(self, st):
+    def stage_sweep_project(self, st, events=None):
         """Sweep preparation folded into the projection kernel (cm3d_sweep_project_hits): same outputs as
         stage_sweeps + stage_project, the cloud crosses HBM once less.  Needs the masks of the batch (stage_masks) first."""
         b = self.b
+        e0, e1 = self._raw_events(events)
         check(self.lib.cm3d_sweep_project_hits(_ptr(b.raw), b.hb.raw_stride, _ptr(b.sweep_row_off), b.S, b.max_sweeps, _ptr(b.sweep_xf),
                                                _ptr(b.frame_sweep_off), b.halfw, _ptr(b.points), b.pt_cap, _ptr(b.pt_off),
                                                _ptr(b.removed_bits), b.F, b.max_pts, b.pt_cap, _ptr(b.cams),
                                                b.hb.n_cams, _ptr(b.mask_off), _ptr(b.mask_cam), _ptr(b.bbox), _ptr(b.packed), b.M, b.W,
                                                b.H, self.min_dist, b.planes, _ptr(b.hit_words), _ptr(b.hit_count), _ptr(b.status),
-                                               _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_sweep_project_hits")
+                                               _ptr(b.pg_ws), b.pg_ws_bytes, e0, e1, st), "cm3d_sweep_project_hits")
 
     def stage_compact(self, st):
         b = self.b
@@ -470,14 +486,10 @@ class LiftEngine:
         if not self.can_fuse_sweeps():
             self.stage_sweeps(st)
         self.stage_masks(st, masks)
-        if project_events is not None:
-            project_events[0].record()
         if not self.can_fuse_sweeps():
-            self.stage_project(st)
+            self.stage_project(st, project_events)
         else:
-            self.stage_sweep_project(st)
-        if project_events is not None:
-            project_events[1].record()
+            self.stage_sweep_project(st, project_events)
         self.stage_compact(st)
         self.stage_medoid(st)
         self.wait_lane_grid()

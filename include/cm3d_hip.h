@@ -129,14 +129,16 @@ int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int3
  *        bit (k&31) of hit_words[k>>5][p] = point p lies in mask mask_off[f]+k
  *  hit_count int32[n_masks] IN/OUT accumulated with atomics; zeroed by cm3d_batch_begin
  *  workspace: cm3d_project_workspace_bytes(F, max_pts_per_frame, planes), 16-byte aligned; it receives the per-frame
- *        tables and the per-(256-row chunk, mask) hit counts and must be handed unchanged to cm3d_compact_hits */
+ *        tables and the per-(256-row chunk, mask) hit counts and must be handed unchanged to cm3d_compact_hits
+ *  ev_start, ev_stop: optional hipEvent_t (NULL = none), recorded on `stream` right before and after the projection
+ *        kernel itself -- behind the small per-frame table kernel the call launches first -- for callers that time it */
 int64_t cm3d_project_workspace_bytes(int32_t n_frames, int32_t max_pts_per_frame, int32_t planes);
 int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
                       int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off,
                       const int32_t *mask_cam, const int32_t *bbox, const uint32_t *packed, int32_t n_masks,
                       int32_t W, int32_t H, float min_dist, int32_t planes, uint32_t *hit_words,
                       int32_t *hit_count, int32_t *status, void *workspace, int64_t workspace_bytes,
-                      cm3d_stream_t stream);
+                      void *ev_start, void *ev_stop, cm3d_stream_t stream);
 
 /* a2 + a4-a7 in one launch: cm3d_sweep_prep folded into cm3d_project_hits.  The kernel reads the raw sweep rows,
  * applies the ego-box drop and the sensor -> ego -> global chains (2d_to_3d.py:437-465) on the fly, writes pt_off, the
@@ -154,7 +156,7 @@ int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t 
                             const float *cams, int32_t n_cams, const int32_t *mask_off, const int32_t *mask_cam,
                             const int32_t *bbox, const uint32_t *packed, int32_t n_masks, int32_t W, int32_t H,
                             float min_dist, int32_t planes, uint32_t *hit_words, int32_t *hit_count, int32_t *status,
-                            void *workspace, int64_t workspace_bytes, cm3d_stream_t stream);
+                            void *workspace, int64_t workspace_bytes, void *ev_start, void *ev_stop, cm3d_stream_t stream);
 
 /* ---- a7-a8: ordered compaction of the hits ----------------------------------
  * Replaces torch.where + the two .cpu() index-tracking steps at 2d_to_3d.py:606,613-617.
