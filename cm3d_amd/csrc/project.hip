@@ -26,6 +26,9 @@
 // s_memtime sums of k_project_hits.  Nothing of this exists in the product library.
 __device__ int g_ph_diag;                         // bit1 no mask loop, bit2 no camera loop, bit3 synthetic rows, bit4 stamps
 __device__ unsigned long long g_ph_stamp[8];
+#define PH_DIAG_WAVES 16384
+__device__ unsigned long long g_ph_wave[3 * PH_DIAG_WAVES];      // bit7: s_memtime at the start and the end of every wave, XCC_ID << 32 | HW_ID
+__device__ unsigned long long g_ph_count[8];     // bit6: wave-chunks, (chunk, camera) pairs behind the cone / pre-test / projection, mask batches, masks
 static __device__ __forceinline__ unsigned long long ph_now()
 {
     unsigned long long t;
@@ -35,6 +38,7 @@ static __device__ __forceinline__ unsigned long long ph_now()
     return t;
 }
 #define PH_DIAG(bit) (diag & (bit))
+#define PH_COUNT(k, v) do { if (diag & 64) cntk[k] += (v); } while (0)
 #define PH_STAMP(k)                                                     \
     do {                                                                \
         if (diag & 16) { const unsigned long long t_ = ph_now(); acc[k] += t_ - t_prev; t_prev = t_; } \
@@ -44,7 +48,20 @@ extern "C" int cm3d_diag_set(int flags)
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_ph_diag), &flags, sizeof(int)) != hipSuccess) return CM3D_ERR_LAUNCH;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_ph_stamp), z, sizeof(z)) != hipSuccess) return CM3D_ERR_LAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ph_count), z, sizeof(z)) != hipSuccess) return CM3D_ERR_LAUNCH;
+    void *wv = nullptr;
+    if (hipGetSymbolAddress(&wv, HIP_SYMBOL(g_ph_wave)) != hipSuccess || hipMemset(wv, 0, sizeof(g_ph_wave)) != hipSuccess) return CM3D_ERR_LAUNCH;
+    if (hipDeviceSynchronize() != hipSuccess) return CM3D_ERR_LAUNCH;
     return CM3D_OK;
+}
+extern "C" int cm3d_diag_read_waves(unsigned long long *out_host, int n_waves)
+{
+    if (n_waves > PH_DIAG_WAVES) return CM3D_ERR_ARG;
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_ph_wave), 3 * (size_t)n_waves * sizeof(unsigned long long)) == hipSuccess ? CM3D_OK : CM3D_ERR_LAUNCH;
+}
+extern "C" int cm3d_diag_read_counts(unsigned long long *out_host)
+{
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_ph_count), 8 * sizeof(unsigned long long)) == hipSuccess ? CM3D_OK : CM3D_ERR_LAUNCH;
 }
 extern "C" int cm3d_diag_read(unsigned long long *out_host)
 {
@@ -53,13 +70,27 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 #else
 #define PH_DIAG(bit) 0
 #define PH_STAMP(k) do { } while (0)
+#define PH_COUNT(k, v) do { } while (0)
 #endif
 
 #ifndef PH_LOADMODE
-#define PH_LOADMODE 1          // how a full chunk's rows are fetched: 0 lane-strided non-temporal, 1 lane-strided, 2 coalesced + LDS transpose
+#define PH_LOADMODE 1          // how a full chunk's rows are fetched: 0 lane-strided non-temporal, 1 lane-strided (plain: measured faster)
 #endif
-#define PH_THREADS 256
+#define PH_THREADS 256                            // k_compact_hits
+#ifndef PHK_THREADS
+#define PHK_THREADS 256                           // k_project_hits (its waves are independent: any multiple of 64)
+#endif
+#define PHK_WAVES (PHK_THREADS / 64)
 #define PH_WAVES (PH_THREADS / 64)
+#define PH_OVERSUB_NUM 1                          // waves launched : waves resident (k_project_hits header)
+#define PH_OVERSUB_DEN 1
+#define PH_STEAL_LISTS 6                          // chunk lists of other slots a wave tries after its own (k_project_hits header)
+#ifndef PH_CG
+#define PH_CG 2                                   // cameras whose cone tests run side by side (CM3D_MAX_CAMS is a multiple)
+#endif
+#ifndef PH_MIN_BLOCKS
+#define PH_MIN_BLOCKS (1024 / PHK_THREADS)        // workgroups per CU the register budget is held to: 4 waves per SIMD
+#endif
 #define PH_PT 4                                   // consecutive rows per lane
 #define PH_WC (64 * PH_PT)                        // rows per wave-chunk
 #define PH_MB 4                                   // masks of a camera handled together in the mask loop
@@ -278,12 +309,13 @@ struct PhSweepIn {
 };
 
 // workspace of the projection / compaction pair
-struct PhWs { int4 *ment; int32_t *ft; int32_t *wc_drop; int32_t *wc_cnt; };
+struct PhWs { int4 *ment; int32_t *ft; int32_t *wc_drop; int32_t *wc_cnt; int32_t *queue; };
 static inline int ph_nm_cap(int planes)
 {
     int c = planes * 32;
     return c > CM3D_MAX_MASKS_PER_FRAME ? CM3D_MAX_MASKS_PER_FRAME : c;
 }
+static inline int ph_tpf_max(int64_t nwc_max) { return (int)((nwc_max + 1) / 2 > 1 ? (nwc_max + 1) / 2 : 1); }     // >= 2 wave-chunks per ticket
 static inline int64_t ph_ws_layout(int n_frames, int max_pts_per_frame, int planes, void *base, PhWs *out)
 {
     const int64_t nwc_max = (max_pts_per_frame + PH_WC - 1) / PH_WC, nm_cap = ph_nm_cap(planes);
@@ -297,6 +329,9 @@ static inline int64_t ph_ws_layout(int n_frames, int max_pts_per_frame, int plan
     off += ((int64_t)n_frames * nwc_max * 4 + 15) & ~(int64_t)15;
     if (out) out->wc_cnt = (int32_t *)(b + off);
     off += (int64_t)n_frames * nwc_max * nm_cap * 4;
+    off = (off + 15) & ~(int64_t)15;
+    if (out) out->queue = (int32_t *)(b + off);                   // k_project_hits: entries handed out per chunk list, [n_frames][tpf], tpf <= ph_tpf_max
+    off += ((int64_t)n_frames * ph_tpf_max(nwc_max) * 4 + 15) & ~(int64_t)15;
     return off;
 }
 
@@ -308,11 +343,13 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
                                                      const int32_t *__restrict__ mask_off, const int32_t *__restrict__ mask_cam,
                                                      const int4 *__restrict__ bbox, int W, int H, float min_dist, int nm_cap,
                                                      int max_pts_per_frame, uint32_t mask_words, int32_t *__restrict__ ft_all,
-                                                     int4 *__restrict__ ment_all,
+                                                     int4 *__restrict__ ment_all, int32_t *__restrict__ queue, int tpf,
                                                      int32_t *__restrict__ status)
 {
     const int f = blockIdx.x, lane = threadIdx.x;
     int32_t *ft = ft_all + (size_t)f * FT_WORDS;
+    for (int q = lane; q < tpf; q += 64) queue[(size_t)f * tpf + q] = 0;      // the frame's chunk lists: nothing handed out yet
+
     int p0, n, sa = 0, ns = 0;
     if (fused) {
         sa = sw.frame_sweep_off[f];
@@ -359,7 +396,10 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
         if (lane < CM3D_MAX_CAMS) {
             float *cone = reinterpret_cast<float *>(ft + FT_CONE) + 8 * lane, *apx = reinterpret_cast<float *>(ft + FT_APX) + 16 * lane;
             if (lane < n_cams) cone_setup(cams + ((size_t)f * n_cams + lane) * CM3D_CAM_STRIDE, W, H, min_dist, cone, apx, &mg, &ok);
-            else { cone[6] = INFINITY; cone[7] = 0.f; }
+            else {                           // a slot without a camera: a cone nothing is inside of (the projection kernel tests whole groups)
+                for (int q = 0; q < 6; ++q) cone[q] = 0.f;
+                cone[6] = INFINITY; cone[7] = 0.f;
+            }
         }
         const uint64_t okm = __ballot(ok);
         mg = cm3d_wave_max(mg);
@@ -434,81 +474,58 @@ static __device__ __forceinline__ void ph_xform(const float *xf, float x, float 
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));       // pixel codes / box corners: v_pk_{sub,min}_u16
 
-// The 4 rows of this lane: x, y, z, w of row j at v[j*S .. j*S+3], S = row stride in registers (5 for 5-column rows,
-// else 4).  STRIDE > 0: full chunks come as STRIDE 16-byte loads per lane (rows 4l..4l+3 are 4*STRIDE consecutive dwords);
-// STRIDE == 0 (any other row stride) and the last, partial chunk of a frame: row by row.  Slots past the end of the frame
-// read as (1e30, 1e30, 0, 0): never dropped, and turned into NaN points by the caller.
-template <int STRIDE>
-struct PhRows { static constexpr int S = STRIDE == 5 ? 5 : 4; float v[4 * S]; };
+// The 4 rows of this lane: x, y, z [, w] of row j at v[j*S .. j*S+S-1].  Only what the pass uses is fetched: 12 bytes per
+// row, 16 when the transformed cloud is kept (KEEP: its fourth column is the row's).  The registers a load writes are
+// held from the request to the use -- a whole camera loop for the rows requested one chunk ahead -- so columns nobody
+// reads would cost registers, not only bytes: a 5-column row fetched whole held 20 VGPRs per lane, this form 12.
+// The lane's rows are consecutive in memory, so the four requests of a lane touch the same cache lines as one long one.
+// STRIDE > 0: compile-time row stride (floats); 0: `stride` at run time.  Slots past the end of the frame read as
+// (1e30, 1e30, 0, 0): never dropped, and turned into NaN points by the caller.
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));        // 12 bytes at dword alignment
+template <bool KEEP>
+struct PhRows { static constexpr int S = KEEP ? 4 : 3; float v[4 * S]; };
 
-template <int STRIDE>
-static __device__ __forceinline__ void ph_load_rows(PhRows<STRIDE> &r, const float *__restrict__ src, int stride, size_t row0, int nvalid,
+template <int STRIDE, bool KEEP>
+static __device__ __forceinline__ void ph_load_rows(PhRows<KEEP> &r, const float *__restrict__ src, int stride, size_t row0, int nvalid,
                                                     int lane, int diag = 0)
 {
-    constexpr int S = PhRows<STRIDE>::S;
+    constexpr int S = PhRows<KEEP>::S;
     if (PH_DIAG(8)) {
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) {
             const int i = (int)row0 + 4 * lane + j;
             r.v[j * S] = (float)(i & 1023) * 0.05f - 20.f; r.v[j * S + 1] = (float)((i >> 10) & 63) * 0.5f - 8.f;
-            r.v[j * S + 2] = -1.f; r.v[j * S + 3] = 0.f;
+            r.v[j * S + 2] = -1.f;
+            if (KEEP) r.v[j * S + 3] = 0.f;
         }
         return;
     }
-    if (STRIDE > 0 && nvalid >= PH_WC) {
-#if PH_LOADMODE == 2
-        // the chunk's 256 x STRIDE floats as STRIDE fully coalesced 1-KiB requests (lane l: bytes [1024 q + 16 l, + 16)): every
-        // cache line is asked for once.  ph_rows_from_pieces turns the pieces into this lane's rows.
-        const f4u *p = reinterpret_cast<const f4u *>(src + row0 * STRIDE) + lane;
+    const int rs = STRIDE > 0 ? STRIDE : stride;
+    if (nvalid >= PH_WC) {
+        const float *p = src + (row0 + (size_t)(4 * lane)) * rs;
 #pragma unroll
-        for (int q = 0; q < STRIDE; ++q) {
-            const f4u t = __builtin_nontemporal_load(p + 64 * q);
-            r.v[4 * q] = t.x; r.v[4 * q + 1] = t.y; r.v[4 * q + 2] = t.z; r.v[4 * q + 3] = t.w;
+        for (int j = 0; j < PH_PT; ++j) {
+            if (KEEP) {
+                const f4u t = *reinterpret_cast<const f4u *>(p + j * rs);
+                r.v[j * S] = t.x; r.v[j * S + 1] = t.y; r.v[j * S + 2] = t.z; r.v[j * S + 3] = t.w;
+            } else {
+                const f3u t = *reinterpret_cast<const f3u *>(p + j * rs);
+                r.v[j * S] = t.x; r.v[j * S + 1] = t.y; r.v[j * S + 2] = t.z;
+            }
         }
-#else
-        const f4u *p = reinterpret_cast<const f4u *>(src + (row0 + (size_t)(4 * lane)) * STRIDE);
-#pragma unroll
-        for (int q = 0; q < STRIDE; ++q) {
-#if PH_LOADMODE == 1
-            const f4u t = p[q];
-#else
-            const f4u t = __builtin_nontemporal_load(p + q);
-#endif
-            r.v[4 * q] = t.x; r.v[4 * q + 1] = t.y; r.v[4 * q + 2] = t.z; r.v[4 * q + 3] = t.w;
-        }
-#endif
     } else {
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) {
             float x = 1e30f, y = 1e30f, z = 0.f, w = 0.f;
             if (4 * lane + j < nvalid) {
-                const float *p = src + (row0 + (size_t)(4 * lane + j)) * stride;
-                x = __builtin_nontemporal_load(p); y = __builtin_nontemporal_load(p + 1);
-                z = __builtin_nontemporal_load(p + 2); w = __builtin_nontemporal_load(p + 3);
+                const float *p = src + (row0 + (size_t)(4 * lane + j)) * rs;
+                x = p[0]; y = p[1]; z = p[2];
+                if (KEEP) w = p[3];
             }
-            r.v[j * S] = x; r.v[j * S + 1] = y; r.v[j * S + 2] = z; r.v[j * S + 3] = w;
-            if (S == 5) r.v[j * S + 4] = 0.f;
+            r.v[j * S] = x; r.v[j * S + 1] = y; r.v[j * S + 2] = z;
+            if (KEEP) r.v[j * S + 3] = w;
         }
     }
-}
-
-// PH_LOADMODE 2: the pieces of a full chunk (ph_load_rows) -> the lane's four rows, through the wave's own LDS slice
-// (STRIDE 16-byte stores at lane stride 16 B, STRIDE 16-byte loads at lane stride 16 STRIDE B: both conflict-free).
-template <int STRIDE>
-static __device__ __forceinline__ void ph_rows_from_pieces(PhRows<STRIDE> &r, float *s_tr, int lane)
-{
-#if PH_LOADMODE == 2
-    if (STRIDE > 0) {
-#pragma unroll
-        for (int q = 0; q < STRIDE; ++q)
-            *reinterpret_cast<float4 *>(s_tr + 256 * q + 4 * lane) = make_float4(r.v[4 * q], r.v[4 * q + 1], r.v[4 * q + 2], r.v[4 * q + 3]);
-#pragma unroll
-        for (int q = 0; q < STRIDE; ++q) {
-            const float4 t = *reinterpret_cast<const float4 *>(s_tr + 4 * STRIDE * lane + 4 * q);
-            r.v[4 * q] = t.x; r.v[4 * q + 1] = t.y; r.v[4 * q + 2] = t.z; r.v[4 * q + 3] = t.w;
-        }
-    }
-#endif
 }
 
 // sweep of frame-local row i (ns > 1): srow = the frame table's sweep starts
@@ -519,8 +536,20 @@ static __device__ __forceinline__ int ph_sweep_of(const int32_t *srow, int ns, i
     return k_sw;
 }
 
-// grid (G, F), 4 waves per workgroup.  Workgroup bx of frame f owns the wave-chunks [nwc bx / G, nwc (bx+1) / G) of the frame,
-// split into four contiguous runs, one per wave.  Per wave-chunk:
+// One-dimensional grid of 4-wave workgroups whose waves never synchronise.  Wave number t of the launch holds TICKET t of
+// `tpf` tickets per frame: slot = t / F of frame (t % F + W slot) % F, W = waves per workgroup -- the four waves of a workgroup work on four
+// different frames, and the tickets of one frame sit in tpf different workgroups on all XCDs.  Ticket (f, slot) OWNS the
+// wave-chunks slot, slot + tpf, slot + 2 tpf, ... of frame f (what a chunk costs depends on where its rows point, and
+// neighbouring chunks cost alike: every tpf-th one is a fair sample), and every list has its own counter in memory
+// (`taken`): whoever wants the next chunk of a list draws it with one atomic add.  A wave walks its own list and, when that
+// is used up, the lists of the next slots of the SAME frame (its tables are already staged), at most PH_STEAL_LISTS of
+// them.  Why: workgroups do not land evenly on the CUs (one launch of 768 workgroups put between two and four on a CU),
+// co-running kernels of the other batches in flight take CUs too, and with fixed shares the mean wave lived 72 % as long
+// as the longest.  Why per-list counters: returning device-scope atomics on ONE address are served one at a time at ~0.6 us
+// each (150 draws per frame counter doubled the launch); a list's counter sees its owner's ~9 draws and the odd thief.
+// Every counter only grows and every wave tries a bounded number of lists, so every wave reaches its exit; a workgroup that
+// starts late (more workgroups than fit at once) finds its lists used up and leaves.
+// Per wave-chunk:
 //   raw rows (requested one chunk ahead) -> ego-box drop + sensor -> ego -> global (FUSED) -> [cloud store] -> removed bits
 //   for every camera that can see any of the wave's points (cone test): project the 4 rows of every lane (pixel codes stay
 //   in registers), then for every mask of that camera: bounding-box test, one mask word per candidate point, bit test,
@@ -529,53 +558,83 @@ static __device__ __forceinline__ int ph_sweep_of(const int32_t *srow, int ns, i
 // lane k); otherwise in the wave's own LDS slice.
 // FUSED: `src` = raw sweep rows (a2, reference :437-465); otherwise `src` = a prepared float4 cloud (STRIDE 4) whose
 // dropped rows are NaN points.
-template <bool ONE_PLANE, bool FUSED, int STRIDE>
-__global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
+template <bool ONE_PLANE, bool FUSED, int STRIDE, bool KEEP>
+__global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
     const float *__restrict__ src, int src_stride, const float *__restrict__ sweep_xf, float halfw, float4 *__restrict__ points_out,
     uint32_t *__restrict__ removed_bits, const int32_t *__restrict__ ft_all, const int4 *__restrict__ ment_all,
     const float *__restrict__ cams, int n_cams, const uint32_t *__restrict__ packed, int W, int H, int Wp, float min_dist, int nm_cap,
-    int nwc_max, int n_points_total, uint32_t *__restrict__ hit_words, int32_t *__restrict__ hit_count, int32_t *__restrict__ wc_cnt)
+    int nwc_max, int n_points_total, uint32_t *__restrict__ hit_words, int32_t *__restrict__ hit_count, int32_t *__restrict__ wc_cnt,
+    int n_frames, int tpf, int32_t *__restrict__ queue)
 {
-    const int f = blockIdx.y;
 #ifdef CM3D_DIAG
     const int diag = g_ph_diag;
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+    int cntk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (diag & 16) t_prev = ph_now();
+    const unsigned long long t_start = (diag & 128) ? ph_now() : 0ull;
 #endif
-    const int32_t *ft = ft_all + (size_t)f * FT_WORDS;              // uniform: scalar loads
-    const int p0 = ft[0], n = ft[1], m0 = ft[2], nm = ft[3], sa = ft[4], ns = ft[5], bits_off = ft[6], nwc = ft[7];
-    const int b_lo = (int)((long long)nwc * blockIdx.x / gridDim.x), b_hi = (int)((long long)nwc * (blockIdx.x + 1) / gridDim.x);
-    if (b_lo >= b_hi) return;                                       // the whole workgroup
     const int lane = cm3d_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int c_lo = b_lo + (b_hi - b_lo) * wave / PH_WAVES, c_hi = b_lo + (b_hi - b_lo) * (wave + 1) / PH_WAVES;
-    const int planes = (nm + 31) >> 5, planes_cap = (nm_cap + 31) >> 5;
-
-    __shared__ float s_cam[CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
-    __shared__ float s_cone[CM3D_MAX_CAMS][8];
-    __shared__ float s_apx[CM3D_MAX_CAMS][16];
-    __shared__ int s_first[CM3D_MAX_CAMS + 1];
-#if PH_LOADMODE == 2
-    __shared__ __align__(16) float s_tr[PH_WAVES][PH_WC * (STRIDE > 0 ? STRIDE : 1)];      // row transposition, one slice per wave
-#endif
+    const int planes_cap = (nm_cap + 31) >> 5;
+    // per-wave copies of the frame's tables (nothing here is shared between waves, so nothing needs a workgroup barrier)
+    __shared__ __align__(16) float s_cam_all[PHK_WAVES][CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
+    __shared__ __align__(16) float s_tab_all[PHK_WAVES][FT_WORDS - FT_CONE];       // cones (8 floats per camera), approximate projections (16)
+    __shared__ int s_first_all[PHK_WAVES][CM3D_MAX_CAMS + 1];
+    float *const s_cam = s_cam_all[wave];
+    float(*const s_cone)[8] = reinterpret_cast<float(*)[8]>(s_tab_all[wave]);
+    float(*const s_apx)[16] = reinterpret_cast<float(*)[16]>(s_tab_all[wave] + (FT_APX - FT_CONE));
+    int *const s_first = s_first_all[wave];
     // dynamic LDS (several planes only), one slice per wave: hit words [planes_cap][PH_WC], counts [nm_cap]
     extern __shared__ __align__(16) unsigned char s_dyn[];
     uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_dyn) + (size_t)wave * planes_cap * PH_WC;
-    int *s_cnt = reinterpret_cast<int *>(reinterpret_cast<uint32_t *>(s_dyn) + (size_t)PH_WAVES * planes_cap * PH_WC) + wave * nm_cap;
+    int *s_cnt = reinterpret_cast<int *>(reinterpret_cast<uint32_t *>(s_dyn) + (size_t)PHK_WAVES * planes_cap * PH_WC) + wave * nm_cap;
+    const float qnan = __int_as_float(0x7FC00000);
+    constexpr int S = PhRows<KEEP>::S;
 
-    // the first chunk's rows are requested before the table staging so that both latencies overlap
-    PhRows<STRIDE> cur;
-    if (c_lo < c_hi) ph_load_rows<STRIDE>(cur, src, src_stride, (size_t)p0 + (size_t)c_lo * PH_WC, min(PH_WC, n - c_lo * PH_WC), lane, PH_DIAG(8));
-    for (int q = threadIdx.x; q < n_cams * CM3D_CAM_STRIDE; q += PH_THREADS) s_cam[q] = cams[(size_t)f * n_cams * CM3D_CAM_STRIDE + q];
-    if (threadIdx.x < CM3D_MAX_CAMS * 8) (&s_cone[0][0])[threadIdx.x] = reinterpret_cast<const float *>(ft + FT_CONE)[threadIdx.x];
-    if (threadIdx.x <= CM3D_MAX_CAMS) s_first[threadIdx.x] = ft[FT_CAMFIRST + threadIdx.x];
-    if (threadIdx.x < CM3D_MAX_CAMS * 16) (&s_apx[0][0])[threadIdx.x] = reinterpret_cast<const float *>(ft + FT_APX)[threadIdx.x];
+    const int ticket = (int)blockIdx.x * PHK_WAVES + wave;
+    if (ticket >= n_frames * tpf) return;                           // uniform (the last workgroup's spare waves)
+    const int slot = ticket / n_frames, f = (ticket - slot * n_frames + PHK_WAVES * slot) % n_frames;
+    const int32_t *ft = ft_all + (size_t)f * FT_WORDS;              // uniform: scalar loads
+    const int p0 = ft[0], n = ft[1], m0 = ft[2], nm = ft[3], sa = ft[4], ns = ft[5], bits_off = ft[6], nwc = ft[7];
+    if (slot >= nwc) return;                                        // more tickets than wave-chunks in this frame
+    const int planes = (nm + 31) >> 5;
+    // the chunk lists of the frame: taken[s] = entries of list s handed out so far (zeroed by k_frame_tables)
+    int32_t *const taken = queue + (size_t)f * tpf;
+    int list = slot, lists_left = PH_STEAL_LISTS;
+    auto draw = [&](int l) {                                        // request the next entry of list l; the answer is read later
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&taken[l], 1);
+        return v;
+    };
+    // the chunk a draw stands for, or, when that list is used up, the first chunk of the next lists that still have one
+    // (these draws are waited for: once per list a wave goes through); >= nwc: nothing left for this wave
+    auto chunk_of = [&](int drawn_v) {
+        int c = list + __builtin_amdgcn_readfirstlane(drawn_v) * tpf;
+        while (c >= nwc && lists_left > 0) {
+            --lists_left;
+            list = list + 1 == tpf ? 0 : list + 1;
+            c = list + __builtin_amdgcn_readfirstlane(draw(list)) * tpf;
+        }
+        return c;
+    };
+    int draw_v = draw(list);
+    {
+        const float4 *cg = reinterpret_cast<const float4 *>(cams + (size_t)f * n_cams * CM3D_CAM_STRIDE);
+        for (int q = lane; q < n_cams * (CM3D_CAM_STRIDE / 4); q += 64) reinterpret_cast<float4 *>(s_cam)[q] = cg[q];
+        if (lane < (FT_WORDS - FT_CONE) / 4) reinterpret_cast<float4 *>(s_tab_all[wave])[lane] = reinterpret_cast<const float4 *>(ft + FT_CONE)[lane];
+        if (lane <= CM3D_MAX_CAMS) s_first[lane] = ft[FT_CAMFIRST + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     const int apx_okmask = ft[FT_APXOK];
-    __syncthreads();                                                // the only one: from here on the waves are on their own
-    PH_STAMP(0);                                                    // setup
+    int chunk = chunk_of(draw_v);
+    if (chunk >= nwc) return;                                       // a late start: the others have been through this frame's lists
+    PhRows<KEEP> cur;
+    ph_load_rows<STRIDE, KEEP>(cur, src, src_stride, (size_t)p0 + (size_t)chunk * PH_WC, min(PH_WC, n - chunk * PH_WC), lane, PH_DIAG(8));
+    int c_nxt = chunk_of(draw(list));
+    PH_STAMP(0);                                                    // frame setup
 
     const int4 *ment = ment_all + (size_t)f * nm_cap * 2;           // two int4 per entry
-    const float qnan = __int_as_float(0x7FC00000);
-    constexpr int S = PhRows<STRIDE>::S;
     int acc_cnt = 0;                                                // ONE_PLANE: lane k = hits of mask k over this wave's chunks
     int32_t *const wc_cnt_f = wc_cnt + (size_t)f * nwc_max * nm_cap;  // the frame's count rows
     uint32_t pend_bits[PH_PT] = {0u, 0u, 0u, 0u};                   // results of the previous chunk, not stored yet
@@ -619,12 +678,11 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
             __builtin_amdgcn_wave_barrier();
         }
     };
-    for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+#pragma unroll 1
+    do {
         const int cb = chunk * PH_WC;
         const int nvalid = min(PH_WC, n - cb);                      // uniform
-#if PH_LOADMODE == 2
-        if (STRIDE > 0 && nvalid >= PH_WC) ph_rows_from_pieces<STRIDE>(cur, s_tr[wave], lane);
-#endif
+        PH_COUNT(0, 1);
         f2 X[PH_NP], Y[PH_NP], Z[PH_NP];                           // rows (2h, 2h+1) of this lane side by side
         if (FUSED) {
             // sweep of the chunk's first and last row: equal for all but the chunks that hold a sweep boundary
@@ -650,8 +708,8 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
                 const bool drop = live && fabsf(cur.v[j * S]) < halfw && fabsf(cur.v[j * S + 1]) < halfw;      // reference drops this row (2d_to_3d.py:442-445)
                 if (!live || drop) { X[j >> 1][j & 1] = qnan; Y[j >> 1][j & 1] = qnan; Z[j >> 1][j & 1] = qnan; }
                 nib |= (drop ? 1u : 0u) << j;
-                if (points_out && live)
-                    points_out[(size_t)p0 + cb + 4 * lane + j] = make_float4(X[j >> 1][j & 1], Y[j >> 1][j & 1], Z[j >> 1][j & 1], cur.v[j * S + 3]);
+                if (KEEP && live)
+                    points_out[(size_t)p0 + cb + 4 * lane + j] = make_float4(X[j >> 1][j & 1], Y[j >> 1][j & 1], Z[j >> 1][j & 1], cur.v[j * S + (KEEP ? 3 : 0)]);
             }
             if (__ballot(nib != 0u)) {
                 // this chunk's 8 words of the frame's removed-row bits (zeroed by cm3d_batch_begin): lane l holds bits 4(l&7)..+3 of word l>>3
@@ -673,8 +731,11 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
         // ago.  Right behind it go the previous chunk's result stores and the request for the next chunk's rows; both
         // have the camera loop to complete before anything waits again.
         flush_results();
-        PhRows<STRIDE> nxt;
-        if (chunk + 1 < c_hi) ph_load_rows<STRIDE>(nxt, src, src_stride, (size_t)p0 + (size_t)cb + PH_WC, min(PH_WC, n - cb - PH_WC), lane, PH_DIAG(8));
+        PhRows<KEEP> nxt;
+        if (c_nxt < nwc) {
+            ph_load_rows<STRIDE, KEEP>(nxt, src, src_stride, (size_t)p0 + (size_t)c_nxt * PH_WC, min(PH_WC, n - c_nxt * PH_WC), lane, PH_DIAG(8));
+            draw_v = draw(list);                                    // the chunk after that one: answered during the camera loop
+        }
         uint32_t bits[PH_PT];
 #pragma unroll
         for (int j = 0; j < PH_PT; ++j) bits[j] = 0;
@@ -683,15 +744,20 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
             for (int pl = 0; pl < planes; ++pl) *reinterpret_cast<uint4 *>(&s_bits[pl * PH_WC + 4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
             for (int k = lane; k < nm; k += 64) s_cnt[k] = 0;
         }
+        // conservative pre-test (a superset of the exact in-image test): is any of this wave's points inside the camera's
+        // visibility cone?  A wave's 256 rows are consecutive in the sweep, i.e. a short arc of the scan, and most cameras
+        // are rejected here for the whole wave.
+        //   inside  <=>  sdist - c6 >= 0  and  c7 * sdist^2 - r2 >= 0   (NaN compares false)
+        // PH_CG cameras at a time in straight-line code: their table reads go out together and their arithmetic interleaves
+        // (one camera alone is a dependent chain behind an LDS round trip).  Slots past n_cams hold a cone nothing is inside
+        // of (k_frame_tables).
+        uint32_t vis = 0u;
 #pragma unroll 1
-        for (int c = 0; c < (PH_DIAG(4) ? 0 : n_cams); ++c) {
-            // conservative pre-test (a superset of the exact in-image test): is any of this wave's points
-            // inside the camera's visibility cone?  A wave's 256 rows are consecutive in the sweep, i.e. a
-            // short arc of the scan, and most cameras are rejected here for the whole wave.
-            //   inside  <=>  sdist - c6 >= 0  and  c7 * sdist^2 - r2 >= 0   (NaN compares false)
-            const float *cn = s_cone[c];
-            float inside;
-            {
+        for (int cg = 0; cg < (PH_DIAG(4) ? 0 : n_cams); cg += PH_CG) {
+            float inside[PH_CG];
+#pragma unroll
+            for (int q = 0; q < PH_CG; ++q) {
+                const float *cn = s_cone[cg + q];
                 f2 m[PH_NP];
 #pragma unroll
                 for (int h = 0; h < PH_NP; ++h) {
@@ -701,14 +767,23 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
                     const f2 t = PK_FMA(cn[7] * sd, sd, -r2);
                     m[h] = __builtin_elementwise_min(sd - cn[6], t);
                 }
-                inside = fmaxf(m[0].x, m[0].y);
+                float in = fmaxf(m[0].x, m[0].y);
 #pragma unroll
-                for (int h = 1; h < PH_NP; ++h) inside = fmaxf(inside, fmaxf(m[h].x, m[h].y));
+                for (int h = 1; h < PH_NP; ++h) in = fmaxf(in, fmaxf(m[h].x, m[h].y));
+                inside[q] = in;
             }
-            PH_STAMP(2);                                            // cone tests
-            if (!__ballot(inside >= 0.0f)) continue;
+#pragma unroll
+            for (int q = 0; q < PH_CG; ++q)
+                if (__ballot(inside[q] >= 0.0f)) vis |= 1u << (cg + q);
+        }
+        PH_STAMP(2);                                                // cone tests
+#pragma unroll 1
+        while (vis) {
+            const int c = __builtin_ctz(vis);
+            vis &= vis - 1u;
             const int e0 = __builtin_amdgcn_readfirstlane(s_first[c]), e1 = __builtin_amdgcn_readfirstlane(s_first[c + 1]);
             if (e0 >= e1) continue;                                 // a camera without (non-empty) masks: nothing to hit
+            PH_COUNT(1, 1);
             // Pre-test on the approximate projection (cone_setup): which masks of this camera can any of the wave's points
             // hit?  A point in a mask lies in the mask's bounding box; its approximate pixel is within apx_margin pixels of the
             // exact one, so it lies in the box grown by that margin.  Two thirds of the (wave, camera) pairs that reach this
@@ -759,6 +834,7 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
                 PH_STAMP(3);
                 if (!cmask) continue;                               // no point of the wave near any mask of this camera
             }
+            PH_COUNT(2, 1);
             const int cns = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 54]);
             const int cfl = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 55]);
             const float *cm = s_cam + c * CM3D_CAM_STRIDE;
@@ -774,6 +850,7 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
             if (!__ballot(pxall >= 0) || PH_DIAG(2)) continue;      // no point of the wave in this image
             // px = iv << 16 | iu (two 16-bit halves; -1 = outside): byte offset of the point's word inside a mask and its bit,
             // once per camera
+            PH_COUNT(3, 1);
             uint32_t wo4[PH_PT];
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
@@ -793,6 +870,7 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
                     ei[b] = rem ? eb + __builtin_ctz(rem) : -1;
                     rem = rem ? (rem & (rem - 1)) : 0u;
                 }
+                PH_COUNT(4, 1);
                 int4 en[PH_MB];
 #pragma unroll
                 for (int b = 0; b < PH_MB; ++b) en[b] = ment[2 * max(ei[b], e0)];                  // uniform: scalar loads
@@ -804,6 +882,7 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
                     for (int j = 0; j < PH_PT; ++j) word[b][j] = 0u;
                     kb[b] = ei[b] >= 0 ? __builtin_amdgcn_readfirstlane(en[b].z) : -1;
                     if (kb[b] < 0) continue;                        // past the last candidate (wave-uniform)
+                    PH_COUNT(5, 1);
                     const us2 org = __builtin_bit_cast(us2, __builtin_amdgcn_readfirstlane(en[b].x));
                     const us2 ext = __builtin_bit_cast(us2, __builtin_amdgcn_readfirstlane(en[b].y));
                     const char *mw = reinterpret_cast<const char *>(packed) + ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane(en[b].w) << 2);
@@ -849,13 +928,27 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_project_hits(
         }
         pend_chunk = chunk;
         cur = nxt;
+        chunk = c_nxt;
+        if (c_nxt < nwc) c_nxt = chunk_of(draw_v);
         PH_STAMP(5);                                                // wait for the next rows
-    }
+    } while (chunk < nwc);
     flush_results();
     if (ONE_PLANE && lane < nm && acc_cnt) atomicAdd(&hit_count[m0 + lane], acc_cnt);
 #ifdef CM3D_DIAG
     if ((diag & 16) && lane == 0)
         for (int k = 0; k < 8; ++k) atomicAdd(&g_ph_stamp[k], k == 7 ? 1ull : acc[k]);
+    if ((diag & 64) && lane == 0) {
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_ph_count[k], (unsigned long long)cntk[k]);
+    }
+    if ((diag & 128) && lane == 0) {
+        const unsigned long long t_end = ph_now();
+        const int wid = (int)blockIdx.x * PHK_WAVES + wave;
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        if (wid < PH_DIAG_WAVES) {
+            g_ph_wave[3 * wid] = t_start; g_ph_wave[3 * wid + 1] = t_end;
+            g_ph_wave[3 * wid + 2] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
 #endif
 }
 
@@ -1198,8 +1291,7 @@ extern "C" int64_t cm3d_project_workspace_bytes(int32_t n_frames, int32_t max_pt
     return ph_ws_layout(n_frames, max_pts_per_frame, planes, nullptr, nullptr);
 }
 
-// workgroups the projection launch aims at: every CU filled exactly once with resident workgroups (a second round would
-// run on a partly filled chip), each wave walking a contiguous run of wave-chunks.  CM3D_PH_BLOCKS overrides (experiments).
+// workgroups of the projection kernel the chip holds at once.  CM3D_PH_BLOCKS overrides (experiments).
 static int ph_target_blocks(const void *kernel, size_t lds)
 {
     static int forced = -1, cus = 0;
@@ -1212,7 +1304,7 @@ static int ph_target_blocks(const void *kernel, size_t lds)
     }
     if (forced > 0) return forced;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PH_THREADS, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PHK_THREADS, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
     return cus * per_cu;
 }
 
@@ -1236,48 +1328,63 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
     const int planes_cap = (nm_cap + 31) / 32;
     PhSweepIn none = {};
     const PhSweepIn sw = fused ? *fused : none;
-    hipLaunchKernelGGL(k_frame_tables, dim3(n_frames), dim3(64), 0, st, sw, fused ? 1 : 0, pt_off, n_frames, cams, n_cams, mask_off, mask_cam,
-                       (const int4 *)bbox, W, H, min_dist, nm_cap, max_pts_per_frame, (uint32_t)H * (uint32_t)Wp, ws.ft, ws.ment, status);
-    CM3D_CHECK_LAUNCH();
     const float *src = fused ? sw.raw : points;
     const int stride = fused ? sw.raw_stride : 4;
-    const int which = !fused ? 0 : (stride == 5 ? 1 : (stride == 4 ? 2 : 3));
+    const bool keep = fused && sw.points_out != nullptr;
+    // variants: prepared cloud | raw rows of 5, 4, any number of columns, each with and without the cloud store
+    const int which = !fused ? 0 : (stride == 5 ? 1 : (stride == 4 ? 2 : 3)) + (keep ? 3 : 0);
     const bool one = planes_cap == 1;
-    const void *fn = one ? (which == 0 ? (const void *)k_project_hits<true, false, 4>
-                            : which == 1 ? (const void *)k_project_hits<true, true, 5>
-                            : which == 2 ? (const void *)k_project_hits<true, true, 4> : (const void *)k_project_hits<true, true, 0>)
-                         : (which == 0 ? (const void *)k_project_hits<false, false, 4>
-                            : which == 1 ? (const void *)k_project_hits<false, true, 5>
-                            : which == 2 ? (const void *)k_project_hits<false, true, 4> : (const void *)k_project_hits<false, true, 0>);
-    size_t lds = one ? 0 : (size_t)PH_WAVES * ((size_t)planes_cap * PH_WC * sizeof(uint32_t) + (size_t)nm_cap * sizeof(int));
+    const void *fn;
+#define PH_PICK(ONE)                                                                                                             \
+    (which == 0 ? (const void *)k_project_hits<ONE, false, 4, false>                                                             \
+     : which == 1 ? (const void *)k_project_hits<ONE, true, 5, false>                                                            \
+     : which == 2 ? (const void *)k_project_hits<ONE, true, 4, false>                                                            \
+     : which == 3 ? (const void *)k_project_hits<ONE, true, 0, false>                                                            \
+     : which == 4 ? (const void *)k_project_hits<ONE, true, 5, true>                                                             \
+     : which == 5 ? (const void *)k_project_hits<ONE, true, 4, true> : (const void *)k_project_hits<ONE, true, 0, true>)
+    if (one) fn = PH_PICK(true);
+    else fn = PH_PICK(false);
+#undef PH_PICK
+    size_t lds = one ? 0 : (size_t)PHK_WAVES * ((size_t)planes_cap * PH_WC * sizeof(uint32_t) + (size_t)nm_cap * sizeof(int));
     if (!one) {
-        static size_t lds_allowed[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+        static size_t lds_allowed[7] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
         if (lds > lds_allowed[which]) {
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CM3D_ERR_LAUNCH;
             lds_allowed[which] = lds;
         }
     }
-    static int blocks_one[4] = {0, 0, 0, 0};                        // cached for the register-only variants (no dynamic LDS)
+    static int blocks_one[7] = {0, 0, 0, 0, 0, 0, 0};                        // cached for the register-only variants (no dynamic LDS)
     int target = one ? blocks_one[which] : 0;
     if (!target) {
         target = ph_target_blocks(fn, lds);
         if (one) blocks_one[which] = target;
     }
-    int gx = (target + n_frames - 1) / n_frames;
-    const int gx_max = (nwc_max + PH_WAVES - 1) / PH_WAVES;          // at least one wave-chunk per wave
-    if (gx > gx_max) gx = gx_max;
-    if (gx < 1) gx = 1;
-#define PH_LAUNCH(ONE, FUSED, STRIDE)                                                                                            \
-    hipLaunchKernelGGL((k_project_hits<ONE, FUSED, STRIDE>), dim3(gx, n_frames), dim3(PH_THREADS), lds, st, src, stride, sw.sweep_xf, \
+    // tickets per frame: about PH_OVERSUB times as many waves as the chip holds at once (see the kernel's header), at least
+    // two wave-chunks per ticket when the frames are that long
+    static int tpf_forced = -1;
+    if (tpf_forced < 0) { const char *e = getenv("CM3D_PH_TICKETS"); tpf_forced = e ? atoi(e) : 0; }
+    int tpf = tpf_forced > 0 ? tpf_forced : (int)(((long long)PH_OVERSUB_NUM * target * PHK_WAVES / PH_OVERSUB_DEN + n_frames - 1) / n_frames);
+    if (tpf > ph_tpf_max(nwc_max)) tpf = ph_tpf_max(nwc_max);
+    if (tpf < 1) tpf = 1;
+    const int gx = (int)(((long long)n_frames * tpf + PHK_WAVES - 1) / PHK_WAVES);
+#define PH_LAUNCH(ONE, FUSED, STRIDE, KEEP)                                                                                      \
+    hipLaunchKernelGGL((k_project_hits<ONE, FUSED, STRIDE, KEEP>), dim3(gx), dim3(PHK_THREADS), lds, st, src, stride, sw.sweep_xf,       \
                        sw.halfw, sw.points_out, sw.removed_bits, ws.ft, ws.ment, cams, n_cams, packed, W, H, Wp, min_dist, nm_cap, \
-                       nwc_max, n_points_total, hit_words, hit_count, ws.wc_cnt)
+                       nwc_max, n_points_total, hit_words, hit_count, ws.wc_cnt, n_frames, tpf, ws.queue)
 #define PH_LAUNCH_S(ONE)                                                                                                         \
     do {                                                                                                                         \
-        if (!fused) PH_LAUNCH(ONE, false, 4);                                                                                    \
-        else if (stride == 5) PH_LAUNCH(ONE, true, 5);                                                                           \
-        else if (stride == 4) PH_LAUNCH(ONE, true, 4);                                                                           \
-        else PH_LAUNCH(ONE, true, 0);                                                                                            \
+        if (which == 0) PH_LAUNCH(ONE, false, 4, false);                                                                         \
+        else if (which == 1) PH_LAUNCH(ONE, true, 5, false);                                                                     \
+        else if (which == 2) PH_LAUNCH(ONE, true, 4, false);                                                                     \
+        else if (which == 3) PH_LAUNCH(ONE, true, 0, false);                                                                     \
+        else if (which == 4) PH_LAUNCH(ONE, true, 5, true);                                                                      \
+        else if (which == 5) PH_LAUNCH(ONE, true, 4, true);                                                                      \
+        else PH_LAUNCH(ONE, true, 0, true);                                                                                      \
     } while (0)
+    hipLaunchKernelGGL(k_frame_tables, dim3(n_frames), dim3(64), 0, st, sw, fused ? 1 : 0, pt_off, n_frames, cams, n_cams, mask_off, mask_cam,
+                       (const int4 *)bbox, W, H, min_dist, nm_cap, max_pts_per_frame, (uint32_t)H * (uint32_t)Wp, ws.ft, ws.ment, ws.queue, tpf,
+                       status);
+    CM3D_CHECK_LAUNCH();
     // optional timing events around the projection kernel itself (the table kernel above is not part of it)
     if (ev_start && hipEventRecord((hipEvent_t)ev_start, st) != hipSuccess) return CM3D_ERR_LAUNCH;
     if (one) PH_LAUNCH_S(true);
