@@ -84,7 +84,9 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 #define PH_WAVES (PH_THREADS / 64)
 #define PH_OVERSUB_NUM 1                          // waves launched : waves resident (k_project_hits header)
 #define PH_OVERSUB_DEN 1
+#ifndef PH_STEAL_LISTS
 #define PH_STEAL_LISTS 6                          // chunk lists of other slots a wave tries after its own (k_project_hits header)
+#endif
 #ifndef PH_CG
 #define PH_CG 2                                   // cameras whose cone tests run side by side (CM3D_MAX_CAMS is a multiple)
 #endif
@@ -594,9 +596,6 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
     if (ticket >= n_frames * tpf) return;                           // uniform (the last workgroup's spare waves)
     const int slot = ticket / n_frames, f = (ticket - slot * n_frames + PHK_WAVES * slot) % n_frames;
     const int32_t *ft = ft_all + (size_t)f * FT_WORDS;              // uniform: scalar loads
-    const int p0 = ft[0], n = ft[1], m0 = ft[2], nm = ft[3], sa = ft[4], ns = ft[5], bits_off = ft[6], nwc = ft[7];
-    if (slot >= nwc) return;                                        // more tickets than wave-chunks in this frame
-    const int planes = (nm + 31) >> 5;
     // the chunk lists of the frame: taken[s] = entries of list s handed out so far (zeroed by k_frame_tables)
     int32_t *const taken = queue + (size_t)f * tpf;
     int list = slot, lists_left = PH_STEAL_LISTS;
@@ -605,33 +604,54 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
         if (lane == 0) v = atomicAdd(&taken[l], 1);
         return v;
     };
+    // Start: everything that only needs the frame's number goes out at once -- the first two entries of the own list, the
+    // camera records and tables for this wave's LDS slice -- and then, behind the frame record, the rows of entry 0 (what the
+    // first draw returns unless a thief was faster) without waiting for the draw: two memory round trips instead of five
+    // in a row.
+    int draw_v = draw(slot);
+    const int draw2_v = draw(slot);
+    const float4 *cg = reinterpret_cast<const float4 *>(cams + (size_t)f * n_cams * CM3D_CAM_STRIDE);
+    constexpr int CAM_Q = CM3D_MAX_CAMS * (CM3D_CAM_STRIDE / 4) / 64;               // 16-byte pieces of the camera records per lane
+    float4 t_cam[CAM_Q];
+#pragma unroll
+    for (int q = 0; q < CAM_Q; ++q) t_cam[q] = lane + 64 * q < n_cams * (CM3D_CAM_STRIDE / 4) ? cg[lane + 64 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 t_tab = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < (FT_WORDS - FT_CONE) / 4) t_tab = reinterpret_cast<const float4 *>(ft + FT_CONE)[lane];
+    const int t_first = lane <= CM3D_MAX_CAMS ? ft[FT_CAMFIRST + lane] : 0;
+    const int p0 = ft[0], n = ft[1], m0 = ft[2], nm = ft[3], sa = ft[4], ns = ft[5], bits_off = ft[6], nwc = ft[7];
+    if (slot >= nwc) return;                                        // more tickets than wave-chunks in this frame
+    const int planes = (nm + 31) >> 5;
     // the chunk a draw stands for, or, when that list is used up, the first chunk of the next lists that still have one
     // (these draws are waited for: once per list a wave goes through); >= nwc: nothing left for this wave
-    auto chunk_of = [&](int drawn_v) {
-        int c = list + __builtin_amdgcn_readfirstlane(drawn_v) * tpf;
+    auto chunk_of = [&](int drawn_v, int from) {                    // from = the list the draw was made on
+        int c = from + __builtin_amdgcn_readfirstlane(drawn_v) * tpf;
         while (c >= nwc && lists_left > 0) {
-            --lists_left;
-            list = list + 1 == tpf ? 0 : list + 1;
-            c = list + __builtin_amdgcn_readfirstlane(draw(list)) * tpf;
+            if (from == list) {                                     // (else: an older draw on a list this wave has left since)
+                --lists_left;
+                list = list + 1 == tpf ? 0 : list + 1;
+            }
+            from = list;
+            c = from + __builtin_amdgcn_readfirstlane(draw(from)) * tpf;
         }
         return c;
     };
-    int draw_v = draw(list);
+    PhRows<KEEP> cur;
+    ph_load_rows<STRIDE, KEEP>(cur, src, src_stride, (size_t)p0 + (size_t)slot * PH_WC, min(PH_WC, n - slot * PH_WC), lane, PH_DIAG(8));
     {
-        const float4 *cg = reinterpret_cast<const float4 *>(cams + (size_t)f * n_cams * CM3D_CAM_STRIDE);
-        for (int q = lane; q < n_cams * (CM3D_CAM_STRIDE / 4); q += 64) reinterpret_cast<float4 *>(s_cam)[q] = cg[q];
-        if (lane < (FT_WORDS - FT_CONE) / 4) reinterpret_cast<float4 *>(s_tab_all[wave])[lane] = reinterpret_cast<const float4 *>(ft + FT_CONE)[lane];
-        if (lane <= CM3D_MAX_CAMS) s_first[lane] = ft[FT_CAMFIRST + lane];
+#pragma unroll
+        for (int q = 0; q < CAM_Q; ++q) reinterpret_cast<float4 *>(s_cam)[lane + 64 * q] = t_cam[q];
+        if (lane < (FT_WORDS - FT_CONE) / 4) reinterpret_cast<float4 *>(s_tab_all[wave])[lane] = t_tab;
+        if (lane <= CM3D_MAX_CAMS) s_first[lane] = t_first;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     const int apx_okmask = ft[FT_APXOK];
-    int chunk = chunk_of(draw_v);
+    int chunk = chunk_of(draw_v, slot);
     if (chunk >= nwc) return;                                       // a late start: the others have been through this frame's lists
-    PhRows<KEEP> cur;
-    ph_load_rows<STRIDE, KEEP>(cur, src, src_stride, (size_t)p0 + (size_t)chunk * PH_WC, min(PH_WC, n - chunk * PH_WC), lane, PH_DIAG(8));
-    int c_nxt = chunk_of(draw(list));
+    if (chunk != slot)                                              // entry 0 was gone
+        ph_load_rows<STRIDE, KEEP>(cur, src, src_stride, (size_t)p0 + (size_t)chunk * PH_WC, min(PH_WC, n - chunk * PH_WC), lane, PH_DIAG(8));
+    int c_nxt = chunk_of(draw2_v, slot);
     PH_STAMP(0);                                                    // frame setup
 
     const int4 *ment = ment_all + (size_t)f * nm_cap * 2;           // two int4 per entry
@@ -678,6 +698,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             __builtin_amdgcn_wave_barrier();
         }
     };
+    int draw_from = list;
 #pragma unroll 1
     do {
         const int cb = chunk * PH_WC;
@@ -734,6 +755,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
         PhRows<KEEP> nxt;
         if (c_nxt < nwc) {
             ph_load_rows<STRIDE, KEEP>(nxt, src, src_stride, (size_t)p0 + (size_t)c_nxt * PH_WC, min(PH_WC, n - c_nxt * PH_WC), lane, PH_DIAG(8));
+            draw_from = list;
             draw_v = draw(list);                                    // the chunk after that one: answered during the camera loop
         }
         uint32_t bits[PH_PT];
@@ -929,7 +951,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
         pend_chunk = chunk;
         cur = nxt;
         chunk = c_nxt;
-        if (c_nxt < nwc) c_nxt = chunk_of(draw_v);
+        if (c_nxt < nwc) c_nxt = chunk_of(draw_v, draw_from);
         PH_STAMP(5);                                                // wait for the next rows
     } while (chunk < nwc);
     flush_results();
