@@ -105,3 +105,34 @@ def test_native_batches_equal_the_python_reader(tmp_path):
         assert np.array_equal(getattr(x, k), getattr(y, k)), k
     assert (x.width, x.height, x.n_cams, x.raw_stride, x.max_rows_per_sweep, x.tokens, x.labels, x.ego_box) == \
            (y.width, y.height, y.n_cams, y.raw_stride, y.max_rows_per_sweep, y.tokens, y.labels, y.ego_box)
+
+
+def test_integration_md_reader_binding_runs_as_written(tmp_path):
+    """The reader stub printed in INTEGRATION.md section 3, executed verbatim (library path filled in; `pin_memory()` dropped where
+    the process has no GPU to register pages with)."""
+    import torch
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, re.S)
+    code = [b for b in blocks if "cm3d_reader_open" in b][0].replace('ctypes.CDLL("libcm3d_reader.so")', f'ctypes.CDLL({reader.LIB_PATH!r})')
+    if not torch.cuda.is_available():
+        code = code.replace(".pin_memory()", "")
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    cfg = syn.config("tiny")
+    frames = [syn.make_frame(cfg, 40 + i) for i in range(3)]
+    sweep_paths, mask_paths = [], []
+    for i, f in enumerate(frames):
+        for k, r in enumerate(f.sweeps_raw):
+            p = tmp_path / f"{i}_{k}.bin"
+            np.ascontiguousarray(r, np.float32).tofile(p)
+            sweep_paths.append(str(p))
+        p = tmp_path / f"{i}_masks.pkl"
+        pickle.dump(f.rles, open(p, "wb"))
+        mask_paths.append(str(p))
+    rows = sum(r.shape[0] for f in frames for r in f.sweeps_raw)
+    exp = [rle.string_to_counts(r["counts"]) for f in frames for r in f.rles]
+    raw, row_off, counts, rle_off, fm_off, wh = ns["load_batch"](sweep_paths, mask_paths, rows, sum(e.size for e in exp), len(exp))
+    assert row_off[-1] == rows and np.array_equal(raw.numpy()[:rows], np.concatenate([r for f in frames for r in f.sweeps_raw]).astype(np.float32))
+    assert np.array_equal(counts.numpy()[:rle_off[len(exp)]].view(np.uint32), np.concatenate(exp))
+    assert list(fm_off) == list(np.concatenate([[0], np.cumsum([len(f.rles) for f in frames])]))
+    assert (wh[:len(exp)] == [cfg.width, cfg.height]).all()
