@@ -104,12 +104,14 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 //   [8..16]  cam_first[0..8]: masks of camera c = entries [cam_first[c], cam_first[c+1]) of the frame's sorted list
 //   [24..40] frame-local first row of each sweep (fused path; ns <= PH_MAX_SWEEPS)
 //   [17] largest pixel margin of the approximate projections  [18] bit c = camera c has an approximate projection
-//   [64..127] visibility cones, 8 floats per camera
+//   [19] smallest depth the approximate projection may accept (float bits)
+//   [64..127] view wedges, 8 floats per camera
 //   [128..255] approximate projections, 16 floats per camera (cone_setup)
 #define FT_WORDS 256
 #define FT_CAMFIRST 8
 #define FT_MARGIN 17
 #define FT_APXOK 18
+#define FT_ZMIN 19
 #define FT_SROW 24
 #define FT_CONE 64
 #define FT_APX 128
@@ -228,9 +230,14 @@ static __device__ __forceinline__ void project_quad(const float *cm, int ns, int
 
 // Conservative tests of one camera, derived from its float32 record (composed in double, so that what is left is the
 // rounding of the kernels' own float32 evaluation):
-//  * visibility cone: a point can only pass the exact in-image test if it is in front of the camera by more than
-//    min_dist (minus a margin) and inside the circular cone around the optical axis that contains the whole image (plus a
-//    2 degree margin).  out: [0..2] camera centre (global), [3..5] optical axis (global), [6] min axial distance, [7] 1 + tan^2.
+//  * view wedge: a point in front of the camera can only pass the exact in-image test (0 < u < W - 1) if it lies on the inner
+//    side of the two planes through the camera centre and the image's left and right edges, u >= 0 and u <= W: in camera
+//    coordinates fx X + cx Z >= 0 and (W - cx) Z - fx X >= 0, linear in the global point.  out: [0..2] unit normal of the
+//    left plane (global), [3] its offset + margin, [4..7] the same for the right plane; a point is kept while
+//    min(n_L . p + d_L, n_R . p + d_R) >= 0.  The margin (1e-6 max|o| + 1e-3 m) covers the float32 evaluation here and in
+//    the exact chain at global magnitudes ten times over.  (The circular cone of earlier versions needed 13 packed operations
+//    per point pair and camera and circumscribes the image; the wedge needs 7 and is 10 % narrower.)
+//    *zmin_out: smallest axial distance the depth test can accept, minus a margin (the approximate projection's depth test).
 //  * approximate projection (apx, 16 floats): camera centre o [0..2], composed rotation A [3..11] (p_cam = A (p - o)),
 //    fx, fy, cx, cy of K' [12..15].  Evaluated in float32 as A (p - o) it differs from the exact chain's camera
 //    coordinates by less than `delta` = 1e-6 max|o| + 1e-4 metres (both forms round p +- 1e3-magnitude translations once or
@@ -238,7 +245,8 @@ static __device__ __forceinline__ void project_quad(const float *cm, int ns, int
 //    *margin_px = 1 + ceil(2 max(fx, fy) delta / zmin) pixels for every point the depth test can accept.
 // A camera record the derivation does not cover (skew, non-trivial last row of K, stages that are not rigid) disables both
 // tests for that camera (the cone accepts everything, *apx_ok = false).
-static __device__ void cone_setup(const float *cm_global, int W, int H, float min_dist, float *out, float *apx, int *margin_px, bool *apx_ok)
+static __device__ void cone_setup(const float *cm_global, int W, int H, float min_dist, float *out, float *apx, int *margin_px, bool *apx_ok,
+                                  float *zmin_out)
 {
     // the whole record in registers first (14 independent 16-byte loads in flight at once; the record is 224 bytes and
     // 16-byte aligned), so that the composition below never waits on memory stage by stage
@@ -270,8 +278,6 @@ static __device__ void cone_setup(const float *cm_global, int W, int H, float mi
     const double ox = -(M[0] * c[0] + M[3] * c[1] + M[6] * c[2]);
     const double oy = -(M[1] * c[0] + M[4] * c[1] + M[7] * c[2]);
     const double oz = -(M[2] * c[0] + M[5] * c[1] + M[8] * c[2]);
-    out[0] = (float)ox; out[1] = (float)oy; out[2] = (float)oz;
-    out[3] = (float)M[6]; out[4] = (float)M[7]; out[5] = (float)M[8];
     apx[0] = (float)ox; apx[1] = (float)oy; apx[2] = (float)oz;
     for (int q = 0; q < 9; ++q) apx[3 + q] = (float)M[q];
     apx[12] = K[0]; apx[13] = K[4]; apx[14] = K[2]; apx[15] = K[5];
@@ -285,19 +291,24 @@ static __device__ void cone_setup(const float *cm_global, int W, int H, float mi
             const double d = M[3 * r] * M[3 * q] + M[3 * r + 1] * M[3 * q + 1] + M[3 * r + 2] * M[3 * q + 2] - (r == q ? 1.0 : 0.0);
             dev = fmax(dev, fabs(d));
         }
-    if (!plain || !(dev < 1e-3)) { out[6] = -INFINITY; out[7] = INFINITY; return; }   // accept everything
-    float t2 = 0.f;
-    for (int cx = 0; cx < 2; ++cx)
-        for (int cy = 0; cy < 2; ++cy) {
-            const float a = ((cx ? (float)W : 0.f) - K[2]) / K[0], b = ((cy ? (float)H : 0.f) - K[5]) / K[4];
-            t2 = fmaxf(t2, a * a + b * b);
-        }
-    const float t = sqrtf(t2), tm = 0.035f;            // tan(2 deg)
-    const float tt = t * tm < 0.9f ? (t + tm) / (1.f - t * tm) : INFINITY;
     const float omax = (float)fmax(fmax(fabs(ox), fabs(oy)), fabs(oz));
     const float zmin = min_dist - 0.05f - 1e-4f * omax;
-    out[6] = zmin;
-    out[7] = 1.f + tt * tt * 1.01f;
+    *zmin_out = zmin;
+    for (int q = 0; q < 8; ++q) out[q] = (q & 3) == 3 ? 1.f : 0.f;                    // accept everything
+    if (!plain || !(dev < 1e-3)) return;
+    {
+        const double fx = (double)K[0], cxp = (double)K[2], margin = 1e-6 * (double)omax + 1e-3;
+        const double nc[2][3] = {{fx, 0.0, cxp}, {-fx, 0.0, (double)W - cxp}};         // left, right plane in camera coordinates
+        for (int e = 0; e < 2; ++e) {
+            const double len = sqrt(nc[e][0] * nc[e][0] + nc[e][2] * nc[e][2]);
+            const double a = nc[e][0] / len, b = nc[e][2] / len;                         // (the y component is 0)
+            out[4 * e + 0] = (float)(M[0] * a + M[6] * b);                               // M^T n
+            out[4 * e + 1] = (float)(M[1] * a + M[7] * b);
+            out[4 * e + 2] = (float)(M[2] * a + M[8] * b);
+            out[4 * e + 3] = (float)(a * c[0] + b * c[2] + margin);
+        }
+    }
+    (void)H;
     if (zmin > 0.1f && dev < 1e-5) {
         const float delta = 1e-6f * omax + 1e-4f;
         const float mg = 1.f + ceilf(2.f * fmaxf(K[0], K[4]) * delta / zmin);
@@ -395,18 +406,18 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
     {
         int mg = 0;
         bool ok = false;
+        float zmin = INFINITY;
         if (lane < CM3D_MAX_CAMS) {
             float *cone = reinterpret_cast<float *>(ft + FT_CONE) + 8 * lane, *apx = reinterpret_cast<float *>(ft + FT_APX) + 16 * lane;
-            if (lane < n_cams) cone_setup(cams + ((size_t)f * n_cams + lane) * CM3D_CAM_STRIDE, W, H, min_dist, cone, apx, &mg, &ok);
-            else {                           // a slot without a camera: a cone nothing is inside of (the projection kernel tests whole groups)
-                for (int q = 0; q < 6; ++q) cone[q] = 0.f;
-                cone[6] = INFINITY; cone[7] = 0.f;
-            }
+            if (lane < n_cams) cone_setup(cams + ((size_t)f * n_cams + lane) * CM3D_CAM_STRIDE, W, H, min_dist, cone, apx, &mg, &ok, &zmin);
+            else                             // a slot without a camera: a wedge nothing is inside of (the projection kernel tests whole groups)
+                for (int q = 0; q < 8; ++q) cone[q] = (q & 3) == 3 ? -1.f : 0.f;
         }
         const uint64_t okm = __ballot(ok);
         mg = cm3d_wave_max(mg);
+        zmin = -cm3d_wave_max(-zmin);        // the frame's smallest (the cameras' differ by 1e-4 of their distance from the origin)
         ft_margin = mg;
-        if (lane == 0) { ft[FT_MARGIN] = mg; ft[FT_APXOK] = (int)(uint32_t)okm; }
+        if (lane == 0) { ft[FT_MARGIN] = mg; ft[FT_APXOK] = (int)(uint32_t)okm; ft[FT_ZMIN] = __float_as_int(zmin); }
     }
     // the frame's masks sorted by camera: count per camera (lane c = masks of camera c), exclusive prefix, placement by
     // ballot rank.  Every mask is loaded once per pass (twice when the frame has more than 64 masks).
@@ -713,7 +724,9 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             const float *xf_u = sweep_xf + (size_t)(sa + sw_lo) * CM3D_SWEEP_XF_STRIDE;                    // scalar loads
             uint32_t nib = 0;
             // (scalar float32 per row: the 24 coefficients stay in scalar registers as operands; the packed form needs every
-            // one of them splatted into a VGPR pair, which costs a wave per SIMD)
+            // one of them splatted into a VGPR pair, which costs a wave per SIMD; the rotations as v_mfma_f32_4x4x1_f32 -- one
+            // fmaf per element, bit-identical, the point stays in its lane -- were 8 us slower: 24 dependent matrix
+            // instructions per chunk with their issue gaps cost more than the 72 vector instructions they replace)
             const bool uni = sw_lo >= sw_hi;
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
@@ -767,11 +780,10 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             for (int k = lane; k < nm; k += 64) s_cnt[k] = 0;
         }
         // conservative pre-test (a superset of the exact in-image test): is any of this wave's points inside the camera's
-        // visibility cone?  A wave's 256 rows are consecutive in the sweep, i.e. a short arc of the scan, and most cameras
-        // are rejected here for the whole wave.
-        //   inside  <=>  sdist - c6 >= 0  and  c7 * sdist^2 - r2 >= 0   (NaN compares false)
+        // view wedge (cone_setup)?  A wave's 256 rows are consecutive in the sweep, i.e. a short arc of the scan, and most
+        // cameras are rejected here for the whole wave.  NaN points compare false.
         // PH_CG cameras at a time in straight-line code: their table reads go out together and their arithmetic interleaves
-        // (one camera alone is a dependent chain behind an LDS round trip).  Slots past n_cams hold a cone nothing is inside
+        // (one camera alone is a dependent chain behind an LDS round trip).  Slots past n_cams hold a wedge nothing is inside
         // of (k_frame_tables).
         uint32_t vis = 0u;
 #pragma unroll 1
@@ -783,11 +795,9 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
                 f2 m[PH_NP];
 #pragma unroll
                 for (int h = 0; h < PH_NP; ++h) {
-                    const f2 vx = X[h] - cn[0], vy = Y[h] - cn[1], vz = Z[h] - cn[2];
-                    f2 sd = cn[3] * vx; sd = PK_FMA((f2)(cn[4]), vy, sd); sd = PK_FMA((f2)(cn[5]), vz, sd);
-                    f2 r2 = vx * vx; r2 = PK_FMA(vy, vy, r2); r2 = PK_FMA(vz, vz, r2);
-                    const f2 t = PK_FMA(cn[7] * sd, sd, -r2);
-                    m[h] = __builtin_elementwise_min(sd - cn[6], t);
+                    f2 l = PK_FMA((f2)(cn[2]), Z[h], (f2)(cn[3])); l = PK_FMA((f2)(cn[1]), Y[h], l); l = PK_FMA((f2)(cn[0]), X[h], l);
+                    f2 r = PK_FMA((f2)(cn[6]), Z[h], (f2)(cn[7])); r = PK_FMA((f2)(cn[5]), Y[h], r); r = PK_FMA((f2)(cn[4]), X[h], r);
+                    m[h] = __builtin_elementwise_min(l, r);
                 }
                 float in = fmaxf(m[0].x, m[0].y);
 #pragma unroll
@@ -815,7 +825,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             uint32_t cmask = ne >= 32 ? 0xFFFFFFFFu : ((1u << ne) - 1u);          // bit i = entry e0 + i is a candidate
             if (pretest) {
                 const float *ap = s_apx[c];
-                const float zmin = s_cone[c][6];
+                const float zmin = __int_as_float(ft[FT_ZMIN]);
                 int pa[PH_PT];
 #pragma unroll
                 for (int h = 0; h < PH_NP; ++h) {
