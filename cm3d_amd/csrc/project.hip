@@ -834,12 +834,12 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
                     f2 yc = ap[6] * vx; yc = PK_FMA((f2)(ap[7]), vy, yc); yc = PK_FMA((f2)(ap[8]), vz, yc);
                     f2 zc = ap[9] * vx; zc = PK_FMA((f2)(ap[10]), vy, zc); zc = PK_FMA((f2)(ap[11]), vz, zc);
                     const f2 r = {__builtin_amdgcn_rcpf(zc.x), __builtin_amdgcn_rcpf(zc.y)};
-                    const f2 ua = PK_FMA(ap[12] * xc, r, (f2)(ap[14])), va = PK_FMA(ap[13] * yc, r, (f2)(ap[15]));
+                    // pixel grid shifted by +1 (folded into the principal point) and clamped to [0, 32001], so that both halves are
+                    // unsigned 16-bit values; points behind zmin (NaN ones with them) become 0xFFFF, 0xFFFF: outside every box
+                    const f2 ua = PK_FMA(ap[12] * xc, r, (f2)(ap[14] + 1.f)), va = PK_FMA(ap[13] * yc, r, (f2)(ap[15] + 1.f));
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        // pixel grid shifted by +1 and clamped, so that both halves are unsigned 16-bit values; NaN and
-                        // points behind zmin become 0xFFFF, 0xFFFF: outside every box
-                        const int iu = (int)(fminf(fmaxf(ua[q], -1.f), 32000.f) + 1.f), iv = (int)(fminf(fmaxf(va[q], -1.f), 32000.f) + 1.f);
+                        const int iu = (int)__builtin_amdgcn_fmed3f(ua[q], 0.f, 32001.f), iv = (int)__builtin_amdgcn_fmed3f(va[q], 0.f, 32001.f);
                         pa[2 * h + q] = zc[q] > zmin ? ((iv << 16) | iu) : -1;
                     }
                 }
