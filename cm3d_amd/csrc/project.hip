@@ -723,10 +723,11 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             if (ns > 1) { sw_lo = ph_sweep_of(srow, ns, cb); sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1); }
             const float *xf_u = sweep_xf + (size_t)(sa + sw_lo) * CM3D_SWEEP_XF_STRIDE;                    // scalar loads
             uint32_t nib = 0;
-            // (scalar float32 per row: the 24 coefficients stay in scalar registers as operands; the packed form needs every
-            // one of them splatted into a VGPR pair, which costs a wave per SIMD; the rotations as v_mfma_f32_4x4x1_f32 -- one
-            // fmaf per element, bit-identical, the point stays in its lane -- were 8 us slower: 24 dependent matrix
-            // instructions per chunk with their issue gaps cost more than the 72 vector instructions they replace)
+            // (scalar float32 per row, the 24 coefficients as scalar operands.  Measured alternatives: the packed form -- half the
+            // instructions, but a v_pk_*_f32 occupies the vector pipe like two scalar ones and the rows have to be re-paired first:
+            // 62 -> 67 us; the rotations as v_mfma_f32_4x4x1_f32 -- one fmaf per element, bit-identical, the point stays in its
+            // lane: 62 -> 70 us, 24 dependent matrix instructions per chunk with their issue gaps cost more than the 72 vector
+            // instructions they replace)
             const bool uni = sw_lo >= sw_hi;
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
