@@ -104,7 +104,7 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 //   [8..16]  cam_first[0..8]: masks of camera c = entries [cam_first[c], cam_first[c+1]) of the frame's sorted list
 //   [24..40] frame-local first row of each sweep (fused path; ns <= PH_MAX_SWEEPS)
 //   [17] largest pixel margin of the approximate projections  [18] bit c = camera c has an approximate projection
-//   [19] smallest depth the approximate projection may accept (float bits)
+//   [19] smallest depth the approximate projection may accept (float bits)  [20] bit c = camera c has a non-empty mask
 //   [64..127] view wedges, 8 floats per camera
 //   [128..255] approximate projections, 16 floats per camera (cone_setup)
 #define FT_WORDS 256
@@ -112,6 +112,7 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 #define FT_MARGIN 17
 #define FT_APXOK 18
 #define FT_ZMIN 19
+#define FT_CAMHAS 20
 #define FT_SROW 24
 #define FT_CONE 64
 #define FT_APX 128
@@ -449,6 +450,10 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
     int first = cm3d_wave_incl_scan(lane < n_cams ? cnt : 0) - (lane < n_cams ? cnt : 0);       // lane c: first entry of camera c
     const int run = __builtin_amdgcn_readlane(first, CM3D_MAX_CAMS - 1) + __builtin_amdgcn_readlane(lane < n_cams ? cnt : 0, CM3D_MAX_CAMS - 1);
     if (lane < n_cams) ft[FT_CAMFIRST + lane] = first;
+    {
+        const uint64_t has = __ballot(lane < n_cams && cnt > 0);
+        if (lane == 0) ft[FT_CAMHAS] = (int)(uint32_t)has;
+    }
     for (int k0 = 0; k0 < nm; k0 += 64) {
         int cam = cam0;
         int4 bb = bb0;
@@ -658,6 +663,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     const int apx_okmask = ft[FT_APXOK];
+    const uint32_t cam_has = (uint32_t)ft[FT_CAMHAS];                // bit c: camera c has a non-empty mask in this frame
     int chunk = chunk_of(draw_v, slot);
     if (chunk >= nwc) return;                                       // a late start: the others have been through this frame's lists
     if (chunk != slot)                                              // entry 0 was gone
@@ -789,6 +795,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
         uint32_t vis = 0u;
 #pragma unroll 1
         for (int cg = 0; cg < (PH_DIAG(4) ? 0 : n_cams); cg += PH_CG) {
+            if (!((cam_has >> cg) & ((1u << PH_CG) - 1u))) continue;                    // no camera of the group has anything to hit
             float inside[PH_CG];
 #pragma unroll
             for (int q = 0; q < PH_CG; ++q) {
