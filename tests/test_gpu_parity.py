@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded
 frames.  Bit-exact for indices / integer outputs and for float32 centroids; 1e-4 (north_star)
 on the float64 box parameters, in practice ~1e-12."""
+import os
+
 import numpy as np
 import pytest
 
@@ -240,6 +242,45 @@ def test_frame_without_points(oracle):
         m0, m1 = hb.mask_off[f], hb.mask_off[f + 1]
         assert got["pt_off"][f + 1] == got["pt_off"][f] and (got["flags"][m0:m1] == 0).all()
     assert (got["flags"][:hb.mask_off[1]] != 0).any() and (got["flags"][hb.mask_off[3]:] != 0).any()
+
+
+_SPLIT_SCRIPT = """
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+from cm3d_amd import lifting, synthetic as syn
+cfg = syn.config("tiny", n_points=9000, n_sweeps=3, n_masks=40, width=512, height=288, ratio=0.32)
+frames = [syn.make_frame(cfg, 70 + i) for i in range(5)]
+lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 2000, seed=1)]
+eng = lifting.LiftEngine()
+eng.upload(lifting.pack_frames(frames, lanes, [0] * 5))
+eng.run(masks="rle")
+torch.cuda.synchronize()
+eng.check_status()
+got = eng.download()
+h = hashlib.sha256()
+for k in sorted(got):
+    h.update(k.encode()); h.update(np.ascontiguousarray(got[k]).tobytes())
+print("DIGEST", h.hexdigest(), int(got["hit_off"][-1]))
+"""
+
+
+def test_work_split_of_the_projection_changes_no_result():
+    """How the projection launch deals its wave-chunks out (tickets per frame, workgroups, who steals what) must not show in any
+    output: the same batch under very different splits -- one list per frame, odd list counts, far more lists than resident
+    waves, a launch of eight workgroups -- gives byte-identical downloads."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for env in ({}, {"CM3D_PH_TICKETS": "1"}, {"CM3D_PH_TICKETS": "7"}, {"CM3D_PH_TICKETS": "18"}, {"CM3D_PH_BLOCKS": "8"}):
+        r = subprocess.run([sys.executable, "-c", _SPLIT_SCRIPT.format(root=root)], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0].split()
+        assert int(line[2]) > 1000                      # the batch has in-mask points at all
+        digests.append(line[1])
+    assert len(set(digests)) == 1, digests
 
 
 def test_second_pass_is_identical(oracle):
