@@ -730,7 +730,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             const float *xf_u = sweep_xf + (size_t)(sa + sw_lo) * CM3D_SWEEP_XF_STRIDE;                    // scalar loads
             uint32_t nib = 0;
             // (scalar float32 per row, the 24 coefficients as scalar operands.  Measured alternatives: the packed form -- half the
-            // instructions, but a v_pk_*_f32 occupies the vector pipe like two scalar ones and the rows have to be re-paired first:
+            // instructions, but the rows have to be re-paired first and every coefficient becomes a 64-bit scalar operand:
             // 62 -> 67 us; the rotations as v_mfma_f32_4x4x1_f32 -- one fmaf per element, bit-identical, the point stays in its
             // lane: 62 -> 70 us, 24 dependent matrix instructions per chunk with their issue gaps cost more than the 72 vector
             // instructions they replace)

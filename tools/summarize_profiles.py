@@ -2,9 +2,9 @@
 """gpurun_out/<tag>/ (written by tools/collect_profiles.sh) -> profiles/<tag>_*  and profiles/traffic.json.
 
 HBM traffic per launch follows MI355X_MICROARCH.md 'HBM': separate --pmc passes for FETCH_SIZE and WRITE_SIZE (KiB).
-On gfx950 FETCH_SIZE reports half of the bytes of 16-byte-per-lane reads, so kernels whose reads are such loads are doubled
-(STREAM_READERS); the projection kernel is one of them: its rows arrive as 16-byte loads, its compulsory read (the raw rows,
-4 x stride x rows bytes) is known exactly, and the doubled counter lands just above it (the rest: mask words, tables).
+On gfx950 FETCH_SIZE reports half of the bytes of requests that pull whole 128-byte lines as a stream, so kernels whose reads
+are such streams are doubled (STREAM_READERS).  For the projection kernel the factor is calibrated on a launch with known bytes
+(tools/pmc_fetch_calibration.sh: camera loop off, 179.2 MB of raw rows read, FETCH_SIZE = 94.2 MB).
 WRITE_SIZE is taken as is (it matches the projection's hit words + counts to the percent)."""
 import collections
 import csv
