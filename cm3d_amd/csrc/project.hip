@@ -6,7 +6,7 @@
 // eroded masks of that camera (bounding-box test first, so only points that can hit a mask touch mask memory).
 // Layout of the work: a WAVE owns "wave-chunks" of 256 consecutive rows, lane l the 4 consecutive rows 4l..4l+3 -- so a
 // lane's rows are one contiguous run of bytes (4 x raw_stride dwords: `raw_stride` 16-byte loads, nothing fetched twice)
-// and its four hit words one 16-byte store.  Waves never talk to each other: per-frame tables (visibility cones, masks
+// and its four hit words one 16-byte store.  Waves never talk to each other: per-frame tables (view wedges, masks
 // sorted by camera with their bounding boxes, row ranges) are built once per frame by k_frame_tables, staged into LDS
 // behind the only workgroup barrier, and every wave writes its own results:
 //   hit_words  one 32-bit word per row per 32 masks
@@ -28,7 +28,7 @@ __device__ int g_ph_diag;                         // bit1 no mask loop, bit2 no 
 __device__ unsigned long long g_ph_stamp[8];
 #define PH_DIAG_WAVES 16384
 __device__ unsigned long long g_ph_wave[3 * PH_DIAG_WAVES];      // bit7: s_memtime at the start and the end of every wave, XCC_ID << 32 | HW_ID
-__device__ unsigned long long g_ph_count[8];     // bit6: wave-chunks, (chunk, camera) pairs behind the cone / pre-test / projection, mask batches, masks
+__device__ unsigned long long g_ph_count[8];     // bit6: wave-chunks, (chunk, camera) pairs behind the wedge / pre-test / projection, mask batches, masks
 static __device__ __forceinline__ unsigned long long ph_now()
 {
     unsigned long long t;
@@ -88,7 +88,7 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 #define PH_STEAL_LISTS 6                          // chunk lists of other slots a wave tries after its own (k_project_hits header)
 #endif
 #ifndef PH_CG
-#define PH_CG 2                                   // cameras whose cone tests run side by side (CM3D_MAX_CAMS is a multiple)
+#define PH_CG 2                                   // cameras whose wedge tests run side by side (CM3D_MAX_CAMS is a multiple)
 #endif
 #ifndef PH_MIN_BLOCKS
 #define PH_MIN_BLOCKS (1024 / PHK_THREADS)        // workgroups per CU the register budget is held to: 4 waves per SIMD
@@ -106,7 +106,7 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 //   [17] largest pixel margin of the approximate projections  [18] bit c = camera c has an approximate projection
 //   [19] smallest depth the approximate projection may accept (float bits)  [20] bit c = camera c has a non-empty mask
 //   [64..127] view wedges, 8 floats per camera
-//   [128..255] approximate projections, 16 floats per camera (cone_setup)
+//   [128..255] approximate projections, 16 floats per camera (wedge_setup)
 #define FT_WORDS 256
 #define FT_CAMFIRST 8
 #define FT_MARGIN 17
@@ -114,7 +114,7 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 #define FT_ZMIN 19
 #define FT_CAMHAS 20
 #define FT_SROW 24
-#define FT_CONE 64
+#define FT_WEDGE 64
 #define FT_APX 128
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));        // 16 bytes at dword alignment
@@ -245,8 +245,8 @@ static __device__ __forceinline__ void project_quad(const float *cm, int ns, int
 //    twice: ~6e-5 m at nuScenes' global magnitudes, so the bound has a factor of several to spare), i.e. by less than
 //    *margin_px = 1 + ceil(2 max(fx, fy) delta / zmin) pixels for every point the depth test can accept.
 // A camera record the derivation does not cover (skew, non-trivial last row of K, stages that are not rigid) disables both
-// tests for that camera (the cone accepts everything, *apx_ok = false).
-static __device__ void cone_setup(const float *cm_global, int W, int H, float min_dist, float *out, float *apx, int *margin_px, bool *apx_ok,
+// tests for that camera (the wedge accepts everything, *apx_ok = false).
+static __device__ void wedge_setup(const float *cm_global, int W, int H, float min_dist, float *out, float *apx, int *margin_px, bool *apx_ok,
                                   float *zmin_out)
 {
     // the whole record in registers first (14 independent 16-byte loads in flight at once; the record is 224 bytes and
@@ -349,7 +349,7 @@ static inline int64_t ph_ws_layout(int n_frames, int max_pts_per_frame, int plan
     return off;
 }
 
-// One wave per frame: row / mask ranges, visibility cones, and the frame's masks sorted by camera with their bounding
+// One wave per frame: row / mask ranges, view wedges, and the frame's masks sorted by camera with their bounding
 // boxes (empty masks and masks of an out-of-range camera are left out: they can get no point).  Also what the sweep
 // kernel leaves behind for the later stages in the fused form (pt_off, status[1]).
 __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fused, const int32_t *__restrict__ pt_off, int n_frames,
@@ -409,10 +409,10 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
         bool ok = false;
         float zmin = INFINITY;
         if (lane < CM3D_MAX_CAMS) {
-            float *cone = reinterpret_cast<float *>(ft + FT_CONE) + 8 * lane, *apx = reinterpret_cast<float *>(ft + FT_APX) + 16 * lane;
-            if (lane < n_cams) cone_setup(cams + ((size_t)f * n_cams + lane) * CM3D_CAM_STRIDE, W, H, min_dist, cone, apx, &mg, &ok, &zmin);
+            float *wedge = reinterpret_cast<float *>(ft + FT_WEDGE) + 8 * lane, *apx = reinterpret_cast<float *>(ft + FT_APX) + 16 * lane;
+            if (lane < n_cams) wedge_setup(cams + ((size_t)f * n_cams + lane) * CM3D_CAM_STRIDE, W, H, min_dist, wedge, apx, &mg, &ok, &zmin);
             else                             // a slot without a camera: a wedge nothing is inside of (the projection kernel tests whole groups)
-                for (int q = 0; q < 8; ++q) cone[q] = (q & 3) == 3 ? -1.f : 0.f;
+                for (int q = 0; q < 8; ++q) wedge[q] = (q & 3) == 3 ? -1.f : 0.f;
         }
         const uint64_t okm = __ballot(ok);
         mg = cm3d_wave_max(mg);
@@ -569,7 +569,7 @@ static __device__ __forceinline__ int ph_sweep_of(const int32_t *srow, int ns, i
 // starts late (more workgroups than fit at once) finds its lists used up and leaves.
 // Per wave-chunk:
 //   raw rows (requested one chunk ahead) -> ego-box drop + sensor -> ego -> global (FUSED) -> [cloud store] -> removed bits
-//   for every camera that can see any of the wave's points (cone test): project the 4 rows of every lane (pixel codes stay
+//   for every camera that can see any of the wave's points (wedge test): project the 4 rows of every lane (pixel codes stay
 //   in registers), then for every mask of that camera: bounding-box test, one mask word per candidate point, bit test,
 //   hit count  -> hit words, per-(chunk, mask) counts.
 // ONE_PLANE (<= 32 masks per frame): the hit word of a row and the count of a mask live in registers (count of mask k in
@@ -595,11 +595,11 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
     const int planes_cap = (nm_cap + 31) >> 5;
     // per-wave copies of the frame's tables (nothing here is shared between waves, so nothing needs a workgroup barrier)
     __shared__ __align__(16) float s_cam_all[PHK_WAVES][CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
-    __shared__ __align__(16) float s_tab_all[PHK_WAVES][FT_WORDS - FT_CONE];       // cones (8 floats per camera), approximate projections (16)
+    __shared__ __align__(16) float s_tab_all[PHK_WAVES][FT_WORDS - FT_WEDGE];       // wedges (8 floats per camera), approximate projections (16)
     __shared__ int s_first_all[PHK_WAVES][CM3D_MAX_CAMS + 1];
     float *const s_cam = s_cam_all[wave];
-    float(*const s_cone)[8] = reinterpret_cast<float(*)[8]>(s_tab_all[wave]);
-    float(*const s_apx)[16] = reinterpret_cast<float(*)[16]>(s_tab_all[wave] + (FT_APX - FT_CONE));
+    float(*const s_wedge)[8] = reinterpret_cast<float(*)[8]>(s_tab_all[wave]);
+    float(*const s_apx)[16] = reinterpret_cast<float(*)[16]>(s_tab_all[wave] + (FT_APX - FT_WEDGE));
     int *const s_first = s_first_all[wave];
     // dynamic LDS (several planes only), one slice per wave: hit words [planes_cap][PH_WC], counts [nm_cap]
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
 #pragma unroll
     for (int q = 0; q < CAM_Q; ++q) t_cam[q] = lane + 64 * q < n_cams * (CM3D_CAM_STRIDE / 4) ? cg[lane + 64 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 t_tab = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < (FT_WORDS - FT_CONE) / 4) t_tab = reinterpret_cast<const float4 *>(ft + FT_CONE)[lane];
+    if (lane < (FT_WORDS - FT_WEDGE) / 4) t_tab = reinterpret_cast<const float4 *>(ft + FT_WEDGE)[lane];
     const int t_first = lane <= CM3D_MAX_CAMS ? ft[FT_CAMFIRST + lane] : 0;
     const int p0 = ft[0], n = ft[1], m0 = ft[2], nm = ft[3], sa = ft[4], ns = ft[5], bits_off = ft[6], nwc = ft[7];
     if (slot >= nwc) return;                                        // more tickets than wave-chunks in this frame
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
     {
 #pragma unroll
         for (int q = 0; q < CAM_Q; ++q) reinterpret_cast<float4 *>(s_cam)[lane + 64 * q] = t_cam[q];
-        if (lane < (FT_WORDS - FT_CONE) / 4) reinterpret_cast<float4 *>(s_tab_all[wave])[lane] = t_tab;
+        if (lane < (FT_WORDS - FT_WEDGE) / 4) reinterpret_cast<float4 *>(s_tab_all[wave])[lane] = t_tab;
         if (lane <= CM3D_MAX_CAMS) s_first[lane] = t_first;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             for (int k = lane; k < nm; k += 64) s_cnt[k] = 0;
         }
         // conservative pre-test (a superset of the exact in-image test): is any of this wave's points inside the camera's
-        // view wedge (cone_setup)?  A wave's 256 rows are consecutive in the sweep, i.e. a short arc of the scan, and most
+        // view wedge (wedge_setup)?  A wave's 256 rows are consecutive in the sweep, i.e. a short arc of the scan, and most
         // cameras are rejected here for the whole wave.  NaN points compare false.
         // PH_CG cameras at a time in straight-line code: their table reads go out together and their arithmetic interleaves
         // (one camera alone is a dependent chain behind an LDS round trip).  Slots past n_cams hold a wedge nothing is inside
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             float inside[PH_CG];
 #pragma unroll
             for (int q = 0; q < PH_CG; ++q) {
-                const float *cn = s_cone[cg + q];
+                const float *cn = s_wedge[cg + q];
                 f2 m[PH_NP];
 #pragma unroll
                 for (int h = 0; h < PH_NP; ++h) {
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             for (int q = 0; q < PH_CG; ++q)
                 if (__ballot(inside[q] >= 0.0f)) vis |= 1u << (cg + q);
         }
-        PH_STAMP(2);                                                // cone tests
+        PH_STAMP(2);                                                // wedge tests
 #pragma unroll 1
         while (vis) {
             const int c = __builtin_ctz(vis);
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             const int e0 = __builtin_amdgcn_readfirstlane(s_first[c]), e1 = __builtin_amdgcn_readfirstlane(s_first[c + 1]);
             if (e0 >= e1) continue;                                 // a camera without (non-empty) masks: nothing to hit
             PH_COUNT(1, 1);
-            // Pre-test on the approximate projection (cone_setup): which masks of this camera can any of the wave's points
+            // Pre-test on the approximate projection (wedge_setup): which masks of this camera can any of the wave's points
             // hit?  A point in a mask lies in the mask's bounding box; its approximate pixel is within apx_margin pixels of the
             // exact one, so it lies in the box grown by that margin.  Two thirds of the (wave, camera) pairs that reach this
             // point end here, and the exact projection below then only meets the masks that have a candidate.

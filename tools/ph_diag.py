@@ -52,7 +52,7 @@ for flags in (16, 28):
     L.cm3d_diag_read(buf)
     v = np.array(list(buf), np.float64)
     tot = v[:7].sum()
-    ph = ["setup", "raw wait+xform", "cone tests", "projection", "mask loop", "result stores", "-"]
+    ph = ["setup", "raw wait+xform", "wedge tests", "projection", "mask loop", "result stores", "-"]
     print(f"stamps (flags {flags}): {int(v[7])} waves, {tot / max(v[7], 1):.0f} cycles per wave")
     for k in range(7):
         print(f"   {ph[k]:24s} {100 * v[k] / tot:5.1f} %   {v[k] / max(v[7], 1):9.0f} cycles/wave")
@@ -68,7 +68,7 @@ print(f"counting launch: {a.elapsed_time(b) * 1e3:.1f} us")
 buf = (C.c_ulonglong * 8)()
 L.cm3d_diag_read_counts(buf)
 v = [int(x) for x in buf]
-print(f"counts: {v[0]} wave-chunks; per chunk: {v[1] / v[0]:.3f} cameras behind the cone, {v[2] / v[0]:.3f} behind the pre-test, "
+print(f"counts: {v[0]} wave-chunks; per chunk: {v[1] / v[0]:.3f} cameras behind the wedge, {v[2] / v[0]:.3f} behind the pre-test, "
       f"{v[3] / v[0]:.3f} with a point in the image, {v[4] / v[0]:.3f} mask batches, {v[5] / v[0]:.3f} masks")
 out["counts"] = v
 L.cm3d_diag_set(128)
