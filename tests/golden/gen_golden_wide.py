@@ -6,6 +6,8 @@ container (where /root/reference exists); never runs on the GPU box.  Writes
                       1024x576 at ratio 0.64, 24 masks): the per-mask loop body of src/nuscenes/2d_to_3d.py:543-617 re-run
                       on the imported LidarPointCloud / view_points -> one index list per mask.  The inputs are the
                       committed generator's frame (config + index below) and are pinned by a checksum.
+  g2c_c2_frame.npz    the same on a frame of the headline configuration (BASELINE C2: 35 k points, 6 cameras, 20 masks of
+                      1600x900 at ratio 1.0).
   g3b_medoid_lists.npz  G3 on REAL in-mask lists: the reference's get_medoid (:116-119, torch.cdist + sum + argmin) on the
                       global-frame points of >= 300 masks of c1-shaped frames, a third of them with duplicated points;
                       per list the reference's index, the oracle's index and the oracle's best/second-best margin.
@@ -29,6 +31,7 @@ from cm3d_amd import rle as rlemod, synthetic as syn  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 G2B = dict(config="c1", index=11, over=dict(n_masks=24))
+G2C = dict(config="c2", index=5, over=dict())
 G3B_FRAMES = [dict(config="c1", index=100 + i, over=dict(n_masks=24)) for i in range(16)]
 
 
@@ -55,21 +58,23 @@ def main():
     pcd, ref = gg._load_reference()
     report = json.load(open(os.path.join(HERE, "gen_report.json")))
 
-    # ---------------- G2b
-    cfg, f, P = frame_cloud(G2B)
-    assert (cfg.width, cfg.height, cfg.ratio) == (1024, 576, 0.64) and P.shape[0] > 100000
-    lists, n_mis = [], 0
-    for r, c in zip(f.rles, f.cam_nums):
-        m = rlemod.counts_to_dense(rlemod.string_to_counts(r["counts"]), f.width, f.height)
-        er = orc.erode3x3(m)
-        tp, _ = gg.reference_mask_body(pcd, P, f.cams[c], er)
-        n_mis += int(not np.array_equal(tp, orc.points_in_mask(P, f.cams[c], er)))
-        lists.append(tp)
-    np.savez_compressed(os.path.join(HERE, "g2b_c1_frame.npz"), spec=json.dumps(G2B), sha256=frame_checksum(f, P),
-                        idx=np.concatenate(lists).astype(np.int32), idx_off=np.concatenate([[0], np.cumsum([l.size for l in lists])]).astype(np.int32),
-                        n_points=np.int64(P.shape[0]))
-    report["G2b c1-shaped frame: masks / points / in-mask points"] = [len(lists), int(P.shape[0]), int(sum(l.size for l in lists))]
-    report["G2b index-list mismatches (oracle vs reference body)"] = n_mis
+    # ---------------- G2b, G2c
+    for tag, spec, fn, shape in (("G2b c1-shaped frame", G2B, "g2b_c1_frame.npz", (1024, 576, 0.64)),
+                                 ("G2c c2-shaped frame", G2C, "g2c_c2_frame.npz", (1600, 900, 1.0))):
+        cfg, f, P = frame_cloud(spec)
+        assert (cfg.width, cfg.height, cfg.ratio) == shape
+        lists, n_mis = [], 0
+        for r, c in zip(f.rles, f.cam_nums):
+            m = rlemod.counts_to_dense(rlemod.string_to_counts(r["counts"]), f.width, f.height)
+            er = orc.erode3x3(m)
+            tp, _ = gg.reference_mask_body(pcd, P, f.cams[c], er)
+            n_mis += int(not np.array_equal(tp, orc.points_in_mask(P, f.cams[c], er)))
+            lists.append(tp)
+        np.savez_compressed(os.path.join(HERE, fn), spec=json.dumps(spec), sha256=frame_checksum(f, P),
+                            idx=np.concatenate(lists).astype(np.int32),
+                            idx_off=np.concatenate([[0], np.cumsum([l.size for l in lists])]).astype(np.int32), n_points=np.int64(P.shape[0]))
+        report[f"{tag}: masks / points / in-mask points"] = [len(lists), int(P.shape[0]), int(sum(l.size for l in lists))]
+        report[f"{tag[:3]} index-list mismatches (oracle vs reference body)"] = n_mis
 
     # ---------------- G3b
     rng = np.random.default_rng(20240202)
@@ -106,7 +111,7 @@ def main():
     report["G3b disagreements that pick the same coordinates (duplicated rows)"] = int((~agree & same_point).sum())
     report["G3b disagreements: list length, rel margin"] = [[int(lens[k]), float(margin[k])] for k in np.flatnonzero(~agree)]
     json.dump(report, open(os.path.join(HERE, "gen_report.json"), "w"), indent=1)
-    print(json.dumps({k: v for k, v in report.items() if k.startswith(("G2b", "G3b"))}, indent=1))
+    print(json.dumps({k: v for k, v in report.items() if k.startswith(("G2b", "G2c", "G3b"))}, indent=1))
 
 
 if __name__ == "__main__":

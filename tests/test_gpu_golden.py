@@ -29,13 +29,15 @@ def test_g2_index_lists_from_reference_body():
                 assert np.array_equal(lists[m], g[f"idx{k}"][ioff[m]:ioff[m + 1]]), f"frame {k} mask {m} ({path})"
 
 
-def test_g2b_reference_resolution_frame_index_lists():
-    """G2 at the reference's own configuration (104 k points, 1024x576 masks at ratio 0.64, 24 masks): the whole-frame kernel
-    path -- fused sweep preparation, projection, compaction -- against the index lists the reference's loop body produced."""
+@pytest.mark.parametrize("fixture", ["g2b_c1_frame.npz", "g2c_c2_frame.npz"])
+def test_g2b_reference_resolution_frame_index_lists(fixture):
+    """G2 at the reference's own configuration (104 k points, 1024x576 masks at ratio 0.64, 24 masks) and at the headline
+    one (35 k points, 20 masks of 1600x900): the whole-frame kernel path -- fused sweep preparation, projection, compaction --
+    against the index lists the reference's loop body produced."""
     import torch
     from cm3d_amd import lifting, synthetic as syn
     from tests.test_oracle_golden import _g2b_frame
-    cfg, f, P, g = _g2b_frame()
+    cfg, f, P, g = _g2b_frame(fixture)
     lanes = [syn.make_lane_table(f.ego_xyz[:2], 2000, seed=1)]
     hb = lifting.pack_frames([f], lanes, [0])
     for masks in ("rle", "dense"):

@@ -40,10 +40,10 @@ def test_g2_index_lists_bit_exact(oracle):
     assert total > 1000
 
 
-def _g2b_frame():
+def _g2b_frame(fixture="g2b_c1_frame.npz"):
     """The frame tests/golden/gen_golden_wide.py ran the reference's loop body on, rebuilt from the committed generator and
     pinned by the fixture's checksum (inputs are not stored: 104 k float32 points do not compress)."""
-    g = np.load(os.path.join(G, "g2b_c1_frame.npz"))
+    g = np.load(os.path.join(G, fixture))
     fs = json.loads(str(g["spec"]))
     from cm3d_amd import rle, synthetic as syn
     from oracle import oracle as orc
@@ -54,7 +54,7 @@ def _g2b_frame():
     h = hashlib.sha256()
     for a in [P, f.cams, np.array(f.cam_nums, np.int32)] + [rle.string_to_counts(r["counts"]) for r in f.rles]:
         h.update(np.ascontiguousarray(a).tobytes())
-    assert h.hexdigest() == str(g["sha256"]), "the synthetic generator changed: regenerate tests/golden/g2b_c1_frame.npz"
+    assert h.hexdigest() == str(g["sha256"]), f"the synthetic generator changed: regenerate tests/golden/{fixture}"
     return cfg, f, P, g
 
 
@@ -69,6 +69,19 @@ def test_g2b_reference_resolution_frame_index_lists(oracle):
         got = oracle.points_in_mask(P, f.cams[c], oracle.erode3x3(mask))
         assert np.array_equal(got, g["idx"][off[m]:off[m + 1]]), f"mask {m}"
     assert off[-1] > 5000
+
+
+def test_g2c_headline_configuration_frame_index_lists(oracle):
+    """G2 at BASELINE's C2 frame shape: 35 k points, 6 cameras, 20 masks of 1600x900 at ratio 1.0."""
+    from cm3d_amd import rle
+    cfg, f, P, g = _g2b_frame("g2c_c2_frame.npz")
+    assert (cfg.width, cfg.height, cfg.ratio) == (1600, 900, 1.0) and P.shape[0] == int(g["n_points"]) > 30000 and len(f.rles) == 20
+    off = g["idx_off"]
+    for m, (r, c) in enumerate(zip(f.rles, f.cam_nums)):
+        mask = rle.counts_to_dense(rle.string_to_counts(r["counts"]), f.width, f.height)
+        got = oracle.points_in_mask(P, f.cams[c], oracle.erode3x3(mask))
+        assert np.array_equal(got, g["idx"][off[m]:off[m + 1]]), f"mask {m}"
+    assert off[-1] > 1000
 
 
 def test_g3b_medoid_on_real_in_mask_lists(oracle):
