@@ -1,6 +1,7 @@
 """GPU parity campaign: randomly drawn batch shapes (points, sweeps, cameras, mask counts and sizes, row order, both
 mask paths) through the HIP path and the oracle, every output compared as in tests/test_gpu_parity.py.
-CM3D_CAMPAIGN_SEEDS sets the number of drawn shapes (default 10; a 200-shape run is recorded in DESIGN.md section 4)."""
+CM3D_CAMPAIGN_SEEDS sets the number of drawn shapes (default 10; the long runs are recorded in DESIGN.md section 4),
+CM3D_CAMPAIGN_FIRST moves the seed, CM3D_CAMPAIGN_MAX_SWEEPS (default 4) widens the number of sweeps per frame."""
 import os
 
 import numpy as np
@@ -16,7 +17,8 @@ pytestmark = pytest.mark.gpu
 def _draw(rng):
     w, h, ratio = [(256, 144, 0.16), (512, 288, 0.32), (1024, 576, 0.64), (1600, 900, 1.0), (333, 207, 0.2)][int(rng.integers(0, 5))]
     n_masks = int(rng.choice([1, 3, 8, 20, 31, 32, 33, 50, 70]))
-    return dict(n_points=int(rng.choice([64, 700, 1023, 1024, 1025, 5000, 12000, 35000])), n_sweeps=int(rng.integers(1, 5)), n_masks=n_masks,
+    max_sweeps = int(os.environ.get("CM3D_CAMPAIGN_MAX_SWEEPS", "4"))      # 17 and more: past the fused launch's limit, the two-launch path
+    return dict(n_points=int(rng.choice([64, 700, 1023, 1024, 1025, 5000, 12000, 35000])), n_sweeps=int(rng.integers(1, max_sweeps + 1)), n_masks=n_masks,
                 n_cams=int(rng.integers(1, 7)), width=w, height=h, ratio=ratio, n_beams=int(rng.choice([16, 32, 64])),
                 min_area=float(rng.choice([4.0, 30.0, 200.0])), max_area=float(rng.choice([400.0, 3000.0, 60000.0])),
                 point_order=str(rng.choice(["ring", "firing"])), empty_mask_prob=float(rng.choice([0.0, 0.1, 0.5])),
