@@ -5,6 +5,8 @@ reference leans on at its boundary with the kernels (reference
 src/nuscenes/2d_to_3d.py:451-457,570-577,585-587).  The kernels consume the
 float32 matrices produced here, never quaternions.
 """
+import math
+
 import numpy as np
 
 CAM_STRIDE = 64          # floats per camera record (include/cm3d_hip.h CM3D_CAM_STRIDE)
@@ -16,8 +18,9 @@ def quat_to_rotmat(q_wxyz):
     """Unit-quaternion (w,x,y,z) -> 3x3 float64 rotation matrix
     (pyquaternion `Quaternion(q).rotation_matrix`; the quaternion is normalised first)."""
     q = np.asarray(q_wxyz, np.float64)
-    q = q / np.linalg.norm(q)
-    w, x, y, z = q
+    # |q| = sqrt(q.q) as np.linalg.norm computes it; the elements as Python floats (the same IEEE double arithmetic without
+    # numpy's scalar overhead: this runs twenty times per frame in the entry points' table walk)
+    w, x, y, z = (q / math.sqrt(q.dot(q))).tolist()
     return np.array([
         [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],

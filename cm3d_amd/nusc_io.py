@@ -27,7 +27,9 @@ ANNOTATION_TABLES = ["category", "attribute", "instance", "sample_annotation"]  
 
 
 class NuscTables:
-    def __init__(self, version, dataroot):
+    def __init__(self, version, dataroot, annotations=True):
+        """annotations=False: skip the ground-truth tables (the lifting path never reads them; on trainval they are the
+        bulk of the JSON)."""
         self.version, self.dataroot = version, dataroot
         self.cam_templates = {}          # (calibrated_sensor token, ratio) -> camera record with the sensor's half filled in
         base = os.path.join(dataroot, version)
@@ -36,7 +38,7 @@ class NuscTables:
             with open(os.path.join(base, name + ".json")) as f:
                 rows = json.load(f)
             self.t[name] = {r["token"]: r for r in rows}
-        for name in ANNOTATION_TABLES:
+        for name in ANNOTATION_TABLES if annotations else []:
             fn = os.path.join(base, name + ".json")
             if os.path.exists(fn):
                 with open(fn) as f:
@@ -135,7 +137,12 @@ def scene_manifest(tables: NuscTables, scene, mask_dir, n_sweeps=3, ratio=0.64, 
             tmpl = tables.cam_templates.get(key)
             if tmpl is None:
                 cs = tables.get("calibrated_sensor", csd["calibrated_sensor_token"])
-                tmpl = geo.nusc_cam_record([0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], cs["translation"], cs["rotation"], cs["camera_intrinsic"], ratio)
+                # (rows that differ only in their token -- a table with one row per frame -- share the record as well)
+                ckey = (tuple(cs["translation"]), tuple(cs["rotation"]), tuple(map(tuple, cs["camera_intrinsic"])), ratio)
+                tmpl = tables.cam_templates.get(ckey)
+                if tmpl is None:
+                    tmpl = geo.nusc_cam_record([0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], cs["translation"], cs["rotation"], cs["camera_intrinsic"], ratio)
+                    tables.cam_templates[ckey] = tmpl
                 tables.cam_templates[key] = tmpl
             rec = tmpl.copy()
             rec[0:3] = (-np.asarray(pose["translation"], np.float64)).astype(np.float32)

@@ -48,7 +48,7 @@ def prepare_scene_batch(task):
     t0 = time.time()
     key = (version, dataroot)
     if key not in _WORKER_TABLES:
-        _WORKER_TABLES[key] = nusc_io.NuscTables(version, dataroot)
+        _WORKER_TABLES[key] = nusc_io.NuscTables(version, dataroot, annotations=False)
     tables = _WORKER_TABLES[key]
     classes = lifting.ClassTable.nuscenes(priors)
     native = task[9] if len(task) > 9 else None
@@ -137,6 +137,31 @@ def _release(keep):
     keep.clear()
 
 
+def _ahead(it, depth=1):
+    """Iterates `it` in a background thread, `depth` items ahead.  The native loader releases the interpreter lock while its
+    threads read, so the Python half of the next batch (table walk, packing) runs under the file reads of this one."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    end = object()
+
+    def work():
+        try:
+            for x in it:
+                q.put(x)
+            q.put(end)
+        except BaseException as exc:       # handed to the consumer
+            q.put(exc)
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        x = q.get()
+        if x is end:
+            return
+        if isinstance(x, BaseException):
+            raise x
+        yield x
+
+
 def sample_tokens(tables, scene_names):
     """The job's sample tokens in output order (scenes in the given order, samples in scene order): every rank derives the
     same list from the tables alone, so a shipped record only needs its index into it."""
@@ -181,6 +206,8 @@ def lift_scenes(tables, scene_names, mask_dir, classes, device, n_sweeps=3, rati
             prepared = pool.imap(prepare_scene_batch, [t + (True, int(per)) for t in tasks])
         else:
             prepared = pool.imap(prepare_scene_batch, [t + (True,) for t in tasks])
+    elif reader_threads >= 0 and len(tasks) > 1:
+        prepared = _ahead(map(prepare_scene_batch, tasks))       # the table walk of the next batch under this batch's file reads
     else:
         prepared = map(prepare_scene_batch, tasks)
     try:
@@ -234,8 +261,9 @@ def main(argv=None):
     if os.environ.get("CM3D_SINGLE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box (with CM3D_DIST_BACKEND=gloo)
         local_rank = 0
     device = f"cuda:{local_rank}"
-    timer = {"io": 0.0, "gpu lifting": 0.0, "gather": 0.0, "total": 0.0}
-    tables = nusc_io.NuscTables(args.version, args.dataroot)
+    timer = {"tables": 0.0, "io": 0.0, "gpu lifting": 0.0, "gather": 0.0, "write": 0.0, "total": 0.0}
+    tables = nusc_io.NuscTables(args.version, args.dataroot, annotations=False)
+    timer["tables"] = time.time() - total_start
     names = [s for s in args.scenes.split(",") if s] or [n for n in MINI_VAL]
     known = {s["name"] for s in tables.scenes()}
     if not args.scenes and not all(n in known for n in names):
@@ -261,14 +289,16 @@ def main(argv=None):
     if rank != 0:
         return 0
     rec = torch.cat([g.cpu() for g in gathered], 0).numpy()
-    results = lifting.nuscenes_boxes_from_records(rec, tokens, classes)
     timer["gather"] = time.time() - t0
 
-    final_predictions = {"meta": dict(META), "results": results}
+    # the writer (:929-930): the records straight to the text json.dump would produce for the reference's dict of box lists
+    t0 = time.time()
+    text, _ = lifting.nuscenes_results_json(rec, tokens, classes, dict(META))
     os.makedirs(args.output_dir, exist_ok=True)
     with open(os.path.join(args.output_dir, args.output_name), "w") as f:
-        json.dump(final_predictions, f)
-    print(f"wrote {len(results)} samples.")
+        f.write(text)
+    timer["write"] = time.time() - t0
+    print(f"wrote {len(tokens)} samples.")
     timer["total"] = time.time() - total_start
     for op, v in timer.items():
         print(op, ":\t\t", v)

@@ -110,7 +110,9 @@ class Reader:
                 raise ReaderError(rc, "cm3d_reader_load_sweeps", bad.value)
         out = raw[:rows * stride].reshape(rows, stride)
         if owner is not None:
-            self._keep = [owner] + self._keep[:7]          # the numpy view does not own pinned memory: keep the last few alive
+            self._keep = [owner] + self._keep[:1]          # the numpy view does not own pinned memory: keep the last few alive
+            # (few: a released buffer goes back to torch's page-locked cache, and the next batch takes it from there instead of
+            # pinning 200 MB afresh)
             out = _Owned(out, owner)
         return out, off
 
@@ -133,7 +135,7 @@ class Reader:
                 nc, nm = int(need[0]), int(need[1])
                 c = counts[:nc]
                 if owner is not None:
-                    self._keep = [owner] + self._keep[:7]
+                    self._keep = [owner] + self._keep[:1]
                     c = _Owned(c, owner)
                 return c, rle_off[:nm + 1].copy(), fmo, wh[:nm].copy()
             if rc != ERR_CAPACITY:

@@ -207,6 +207,28 @@ def test_gathered_records_rebuild_the_box_dicts():
     json.dumps(got)
 
 
+def test_direct_json_writer_equals_json_dumps_of_the_dicts():
+    """lifting.nuscenes_results_json writes the result file's text straight from the box records; it must be, character for
+    character, json.dumps of the reference-shaped dicts (key order, separators, float repr, Infinity / NaN spelling, escaped
+    tokens, samples without boxes)."""
+    from cm3d_amd import lifting
+    rng = np.random.default_rng(12)
+    for n, nt in ((0, 3), (1, 1), (40, 5), (3000, 64)):
+        rec = rng.normal(size=(n, 10)) * rng.choice([1e-9, 1.0, 1e3, 1e17], size=(n, 1))
+        if n:
+            rec[:, lifting.REC_FRAME_A] = rng.integers(0, nt, n)
+            rec[:, 8] = rng.integers(0, 10, n)
+            rec[0, 0] = np.inf
+            rec[n // 2, 7] = np.nan
+            rec[n - 1, 4] = -0.0
+        tokens = [f'tok"{i}\\' for i in range(nt)]
+        meta = {"use_camera": False, "use_lidar": True}
+        want = json.dumps({"meta": meta, "results": lifting.nuscenes_boxes_from_records(rec, tokens)})
+        got, n_boxes = lifting.nuscenes_results_json(rec, tokens, meta=meta)
+        assert got == want and n_boxes == n
+        assert json.loads(got.replace("Infinity", "1e999").replace("NaN", "null"))["results"].keys() == set(tokens)
+
+
 def test_prepare_scene_batch_in_reader_processes(tmp_path):
     """pipeline_nuscenes.prepare_scene_batch (file reads + RLE strings + packing; no GPU) gives the same host batches in
     spawned reader processes as in this process."""
