@@ -39,6 +39,33 @@ _WORKER_TABLES = {}
 _WORKER_READER = None
 
 
+def _batch_manifest(tables, names, mask_dir, n_sweeps, ratio, missing_ok):
+    """The table walk of one batch of scenes (no bulk data): frame manifests, lane tables, lane table of every frame."""
+    man, lanes, frame_lane = [], [], []
+    for k, name in enumerate(names):
+        scene = tables.scene_by_name(name)
+        ms = nusc_io.scene_manifest(tables, scene, mask_dir, n_sweeps=n_sweeps, ratio=ratio, missing_ok=missing_ok)
+        lanes.append(nusc_io.load_lane_points(tables.dataroot, tables.location(scene)))
+        man.extend(ms)
+        frame_lane.extend([k] * len(ms))
+    return man, lanes, frame_lane
+
+
+def _with_manifest(task):
+    """task -> task + (its manifest,): the first of the two host stages when they run on threads of their own (lift_scenes)."""
+    version, dataroot, mask_dir, names, n_sweeps, ratio, missing_ok = task[:7]
+    t0 = time.time()
+    tables = _WORKER_TABLES[(version, dataroot)]
+    man = _batch_manifest(tables, names, mask_dir, n_sweeps, ratio, missing_ok)
+    return task + (man, time.time() - t0)
+
+
+def _load_prepared(task):
+    """Second host stage: prepare_scene_batch on a task that brings its manifest; adds the first stage's time."""
+    tokens, batches, io_s = prepare_scene_batch(task[:11])
+    return tokens, batches, io_s + task[11]
+
+
 def prepare_scene_batch(task):
     """Host side of one batch of scenes: reads the frames' files, decodes the RLE strings and packs one HostBatch per mask
     size.  Pure numpy -- never touches the GPU -- so `lift_scenes(workers=N)` can run it in N reader processes.
@@ -62,13 +89,7 @@ def prepare_scene_batch(task):
     if native is not None:
         # the native loader (libcm3d_reader.so): this thread only walks the tables and the small json files; sweeps and mask
         # pickles of the whole batch are read and parsed by the loader's thread pool, into page-locked staging buffers
-        man, lanes, frame_lane = [], [], []
-        for k, name in enumerate(names):
-            scene = tables.scene_by_name(name)
-            ms = nusc_io.scene_manifest(tables, scene, mask_dir, n_sweeps=n_sweeps, ratio=ratio, missing_ok=missing_ok)
-            lanes.append(nusc_io.load_lane_points(tables.dataroot, tables.location(scene)))
-            man.extend(ms)
-            frame_lane.extend([k] * len(ms))
+        man, lanes, frame_lane = task[10] if len(task) > 10 else _batch_manifest(tables, names, mask_dir, n_sweeps, ratio, missing_ok)
         from .reader import ERR_FORMAT, ReaderError
         segs = []
 
@@ -207,7 +228,9 @@ def lift_scenes(tables, scene_names, mask_dir, classes, device, n_sweeps=3, rati
         else:
             prepared = pool.imap(prepare_scene_batch, [t + (True,) for t in tasks])
     elif reader_threads >= 0 and len(tasks) > 1:
-        prepared = _ahead(map(prepare_scene_batch, tasks))       # the table walk of the next batch under this batch's file reads
+        # three host threads in a row: the table walk (Python) of batch k+2, the file reads (native threads, no interpreter
+        # lock) and packing of batch k+1, and this one, which uploads and launches batch k
+        prepared = _ahead(map(_load_prepared, _ahead(map(_with_manifest, tasks))))
     else:
         prepared = map(prepare_scene_batch, tasks)
     try:
