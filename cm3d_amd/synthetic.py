@@ -48,6 +48,9 @@ class SyntheticConfig:
                                    # image rows); "firing" = azimuth step by azimuth step, all beams of one firing
                                    # together (how the HDL-32E packets of a nuScenes LIDAR_TOP .pcd.bin are laid out,
                                    # the ring index in column 4 cycling 0..31)
+    ego_magnitude: float = None    # distance of the ego pose from the map origin in metres (None: the ~1.7 km of
+                                   # _ego_pose's default; 0: a vehicle-frame dataset like Waymo/KITTI; nuScenes maps
+                                   # reach ~4 km).  What the float32 global-frame cancellation scales with.
 
 
 @dataclass
@@ -66,8 +69,13 @@ class Frame:
     meta: dict = field(default_factory=dict)
 
 
-def _ego_pose(rng):
-    t = np.array([600.0 + rng.uniform(-200, 200), 1600.0 + rng.uniform(-200, 200), rng.uniform(0.0, 2.0)])
+def _ego_pose(rng, magnitude=None):
+    if magnitude is None:
+        cx, cy, jit = 600.0, 1600.0, 200.0
+    else:       # same direction from the origin as the default, `magnitude` metres out; the same three draws
+        cx, cy = 0.3511234 * float(magnitude), 0.9363291 * float(magnitude)
+        jit = 200.0 if magnitude >= 1000.0 else 5.0
+    t = np.array([cx + rng.uniform(-jit, jit), cy + rng.uniform(-jit, jit), rng.uniform(0.0, 2.0)])
     yaw = rng.uniform(-np.pi, np.pi)
     R = geo.rot_z(yaw) @ geo.quat_to_rotmat([1.0, rng.normal() * 0.004, rng.normal() * 0.004, 0.0])
     return t, geo.rotmat_to_quat(R), yaw
@@ -137,7 +145,7 @@ def make_frame(cfg: SyntheticConfig, index: int) -> Frame:
     # --- rig
     lidar_cs_t = np.array([0.943713, 0.0, 1.84023])
     lidar_cs_q = geo.rotmat_to_quat(geo.rot_z(np.deg2rad(-89.85)) @ geo.quat_to_rotmat([1.0, 0.003, -0.002, 0.0]))
-    ego_t, ego_q, ego_yaw = _ego_pose(rng)
+    ego_t, ego_q, ego_yaw = _ego_pose(rng, cfg.ego_magnitude)
     # --- objects (sensor-frame cylinders), one per mask that is not "empty"
     n = cfg.n_masks
     cls = rng.integers(0, len(CLASSES), size=n)

@@ -1,5 +1,5 @@
 """GPU parity campaign: randomly drawn batch shapes (points, sweeps, cameras, mask counts and sizes, row order, both
-mask paths) through the HIP path and the oracle, every output compared as in tests/test_gpu_parity.py.
+mask paths, distance of the ego pose from the map origin: 0 / 1.7 / 4 / 10 km) through the HIP path and the oracle, every output compared as in tests/test_gpu_parity.py.
 CM3D_CAMPAIGN_SEEDS sets the number of drawn shapes (default 10; the long runs are recorded in DESIGN.md section 4),
 CM3D_CAMPAIGN_FIRST moves the seed, CM3D_CAMPAIGN_MAX_SWEEPS (default 4) widens the number of sweeps per frame."""
 import os
@@ -22,7 +22,10 @@ def _draw(rng):
                 n_cams=int(rng.integers(1, 7)), width=w, height=h, ratio=ratio, n_beams=int(rng.choice([16, 32, 64])),
                 min_area=float(rng.choice([4.0, 30.0, 200.0])), max_area=float(rng.choice([400.0, 3000.0, 60000.0])),
                 point_order=str(rng.choice(["ring", "firing"])), empty_mask_prob=float(rng.choice([0.0, 0.1, 0.5])),
-                duplicate_prob=float(rng.choice([0.0, 0.2, 0.6])), seed=int(rng.integers(0, 1 << 30)))
+                duplicate_prob=float(rng.choice([0.0, 0.2, 0.6])), seed=int(rng.integers(0, 1 << 30)),
+                # distance of the ego pose from the map origin (None: the generator's ~1.7 km): the float32 chains and the
+                # projection kernel's culling margins scale with it
+                ego_magnitude=[None, 0.0, 4000.0, 10000.0][int(rng.integers(0, 4))])
 
 
 def test_random_shapes_against_oracle(oracle):

@@ -80,6 +80,52 @@ def test_g3b_medoid_on_real_in_mask_lists():
         assert ops.get_medoid(p.T, via_rows=True) == int(g["ref_index"][k]) == ops.get_medoid(p.T), k
 
 
+def test_g2d_index_lists_at_0_4_and_10_km():
+    """G2 with the ego pose 0 m / 4 km / 10 km from the map origin: the whole-frame kernel path (culling by view wedge and
+    approximate projection included -- their margins scale with the magnitude) against the reference's loop body."""
+    import torch
+    from cm3d_amd import lifting, synthetic as syn
+    from tests.test_oracle_golden import _g2d_frames
+    for mag, cfg, f, P, idx, off in _g2d_frames():
+        lanes = [syn.make_lane_table(f.ego_xyz[:2], 2000, seed=1)]
+        hb = lifting.pack_frames([f], lanes, [0])
+        for masks in ("rle", "dense"):
+            eng = lifting.LiftEngine(keep_cloud=masks == "dense")
+            eng.upload(hb)
+            if masks == "dense":
+                eng.decode_masks_dense()
+            eng.run(masks=masks)
+            torch.cuda.synchronize()
+            got = eng.download()
+            assert np.array_equal(got["hit_off"], off) and np.array_equal(got["hit_idx"], idx), (mag, masks)
+            assert np.array_equal(got["hit_xyz"].view(np.uint32), P[idx].view(np.uint32)), (mag, masks)
+
+
+def test_g3c_medoid_at_0_4_and_10_km():
+    """The reference's get_medoid on real in-mask lists at 0 m / 4 km / 10 km, all lists in one call (two-pass route, matrix
+    pipe first pass for the long ones): the reference's index on every list."""
+    import torch
+    from cm3d_amd import _lib
+    g = np.load(os.path.join(G, "g3c_medoid_magnitude.npz"))
+    off = g["off"].astype(np.int32)
+    n, tot = len(off) - 1, int(off[-1])
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    xyz = torch.zeros(tot, 4, dtype=torch.float32, device=dev)
+    xyz[:, :3] = torch.from_numpy(g["pts"]).to(dev)
+    hit_off = torch.from_numpy(off).to(dev)
+    tiles = (np.diff(off) + _lib.MEDOID_TILE - 1) // _lib.MEDOID_TILE
+    tile_off = torch.from_numpy(np.concatenate([[0], np.cumsum(tiles)]).astype(np.int32)).to(dev)
+    med, cen = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, 3, dtype=torch.float32, device=dev)
+    ws = torch.empty(int(L.cm3d_medoid_workspace_bytes(n, tot)), dtype=torch.uint8, device=dev)
+    _lib.check(L.cm3d_medoid(xyz.data_ptr(), 0, 0, n, hit_off.data_ptr(), tile_off.data_ptr(), 0, tot, 0, med.data_ptr(), cen.data_ptr(), 0,
+                             ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "cm3d_medoid")
+    got = med.cpu().numpy()
+    bad = np.flatnonzero(got != g["ref_index"])
+    assert bad.size == 0, [(int(k), float(g["ego_magnitude"][k]), int(off[k + 1] - off[k])) for k in bad]
+    assert np.array_equal(cen.cpu().numpy().view(np.uint32), g["pts"][off[:-1] + g["ref_index"]].view(np.uint32))
+
+
 def test_g3_get_medoid():
     from cm3d_amd import ops
     cases = json.load(open(os.path.join(G, "g3_medoid.json")))

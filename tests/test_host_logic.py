@@ -375,3 +375,29 @@ def test_waymo_objects_parse_with_the_protobuf_runtime():
     # our decoder (used by the GPU tests) reads the same values
     for d, w in zip(wm.decode_objects(blob), want):
         assert d["center"] == list(w["center"]) and d["type"] == w["type_id"] and d["timestamp_micros"] == w["timestamp_micros"]
+
+
+@pytest.mark.parametrize("mag", [0.0, 4000.0, 10000.0])
+def test_crafted_boundary_rows_fall_on_both_sides(oracle, mag):
+    """tests/magnitude_cases.py crafts rows onto the limits the projection kernel's culling relies on (the image's accept
+    limits behind the view wedge, the edges of a mask's bounding box, the minimum depth).  For the GPU test built on them to
+    mean anything, the reference arithmetic (the oracle) must put a fair share of every kind on EACH side of its limit."""
+    from cm3d_amd import rle
+    from tests.magnitude_cases import H, N_EACH, N_KINDS, RECT, W, crafted_frames
+    frames, crafted = crafted_frames(mag, n_frames=1)
+    fr, rows = frames[0], crafted[0]
+    x = fr.sweep_xf[0]
+    P = oracle.sweep_prep(rows, x[0:9], x[9:12], x[12:21], x[21:24], np.float32(0.0))
+    assert P.shape[0] == rows.shape[0] == fr.cams.shape[0] * N_KINDS * N_EACH
+    full = oracle.erode3x3(np.ones((H, W), np.uint8))
+    rect = np.zeros((H, W), np.uint8)
+    rect[RECT[1]:RECT[3] + 1, RECT[0]:RECT[2] + 1] = 1
+    rect = oracle.erode3x3(rect)
+    for c in range(fr.cams.shape[0]):
+        base = c * N_KINDS * N_EACH
+        in_img = np.zeros(P.shape[0], bool); in_img[oracle.points_in_mask(P, fr.cams[c], full)] = True
+        in_rect = np.zeros(P.shape[0], bool); in_rect[oracle.points_in_mask(P, fr.cams[c], rect)] = True
+        for kind in range(N_KINDS):
+            sel = slice(base + kind * N_EACH, base + (kind + 1) * N_EACH)
+            inside = (in_rect if kind in (4, 5, 6, 7, 9) else in_img)[sel]
+            assert 3 <= int(inside.sum()) <= N_EACH - 3, (mag, c, kind, int(inside.sum()))

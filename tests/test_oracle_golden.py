@@ -98,6 +98,55 @@ def test_g3b_medoid_on_real_in_mask_lists(oracle):
         assert oracle.medoid(P4, np.arange(p.shape[0])) == int(g["ref_index"][k]), f"list {k} (M = {p.shape[0]})"
 
 
+def _g2d_frames():
+    """The frames tests/golden/gen_golden_magnitude.py ran the reference's loop body on (ego pose 0 / 4 / 10 km from the map
+    origin), rebuilt from the committed generator and pinned by the fixture's checksums."""
+    import hashlib
+    from cm3d_amd import rle, synthetic as syn
+    from oracle import oracle as orc
+    g = np.load(os.path.join(G, "g2d_magnitude_frames.npz"))
+    out = []
+    for k in range(int(g["n"])):
+        fs = json.loads(str(g[f"spec{k}"]))
+        cfg = syn.config(fs["config"], **fs["over"])
+        f = syn.make_frame(cfg, fs["index"])
+        P = np.concatenate([orc.sweep_prep(r, x[0:9], x[9:12], x[12:21], x[21:24]) for r, x in zip(f.sweeps_raw, f.sweep_xf)], 0)
+        h = hashlib.sha256()
+        for a in [P, f.cams, np.array(f.cam_nums, np.int32)] + [rle.string_to_counts(r["counts"]) for r in f.rles]:
+            h.update(np.ascontiguousarray(a).tobytes())
+        assert h.hexdigest() == str(g[f"sha256_{k}"]), "the synthetic generator changed: regenerate tests/golden/g2d_magnitude_frames.npz"
+        out.append((fs["over"]["ego_magnitude"], cfg, f, P, g[f"idx{k}"], g[f"idx_off{k}"]))
+    return out
+
+
+def test_g2d_index_lists_at_0_4_and_10_km(oracle):
+    """G2 with the ego pose 0 m, 4 km and 10 km from the map origin (every other fixture sits at ~1.7 km): the reference's loop
+    body on a c1-shaped frame (104 k points, 24 masks of 1024x576) per magnitude."""
+    from cm3d_amd import rle
+    frames = _g2d_frames()
+    assert [m for m, *_ in frames] == [0.0, 4000.0, 10000.0]
+    for mag, cfg, f, P, idx, off in frames:
+        assert abs(float(np.hypot(*f.ego_xyz[:2])) - mag) < 300.0 and P.shape[0] > 100000
+        for m, (r, c) in enumerate(zip(f.rles, f.cam_nums)):
+            mask = rle.counts_to_dense(rle.string_to_counts(r["counts"]), f.width, f.height)
+            got = oracle.points_in_mask(P, f.cams[c], oracle.erode3x3(mask))
+            assert np.array_equal(got, idx[off[m]:off[m + 1]]), f"{mag:.0f} m, mask {m}"
+        assert off[-1] > 5000
+
+
+def test_g3c_medoid_at_0_4_and_10_km(oracle):
+    """The reference's get_medoid on 174 real in-mask lists at 0 m / 4 km / 10 km (torch.cdist's expansion loses decimetres at
+    10 km; that arithmetic IS the reference): the oracle picks the reference's index on every list."""
+    g = np.load(os.path.join(G, "g3c_medoid_magnitude.npz"))
+    off = g["off"]
+    assert len(off) - 1 >= 150 and set(g["ego_magnitude"].tolist()) == {0.0, 4000.0, 10000.0}
+    assert np.array_equal(g["ref_index"], g["oracle_index"])
+    for k in range(len(off) - 1):
+        p = g["pts"][off[k]:off[k + 1]]
+        P4 = np.concatenate([p, np.zeros((p.shape[0], 1), np.float32)], 1)
+        assert oracle.medoid(P4, np.arange(p.shape[0])) == int(g["ref_index"][k]), f"list {k} (M = {p.shape[0]}, {g['ego_magnitude'][k]:.0f} m)"
+
+
 def test_g3_medoid_matches_reference(oracle):
     cases = json.load(open(os.path.join(G, "g3_medoid.json")))
     g = np.load(os.path.join(G, "g3_medoid.npz"))
