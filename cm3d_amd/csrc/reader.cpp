@@ -125,7 +125,7 @@ int64_t rle_from_string(const uint8_t *s, int64_t len, uint32_t *out, int64_t ca
             more = (c & 0x20) != 0;
             ++p;
             ++k;
-            if (!more && (c & 0x10)) x |= (long long)(~0ull << (5 * k));
+            if (!more && (c & 0x10) && 5 * k < 64) x |= (long long)(~0ull << (5 * k));     // (13 groups fill all 64 bits: nothing to extend)
         }
         if (m > 2) x += prev2;
         if (x < 0 || x > 0xFFFFFFFFll) return CM3D_RD_ERR_FORMAT;
@@ -151,18 +151,25 @@ struct Val {
 };
 
 struct Unpickler {
-    const uint8_t *b, *e;
+    const uint8_t *b, *e, *b0;
     std::vector<Val> stack, memo;
     std::vector<std::vector<Val>> lists;                       // LIST nodes (tuples too)
     std::vector<std::vector<std::pair<Val, Val>>> dicts;       // DICT nodes
     std::vector<std::string> arena;                            // bytes rebuilt from protocol-2 str pickles
     bool ok = true;
 
-    Unpickler(const uint8_t *data, size_t n) : b(data), e(data + n) {}
+    Unpickler(const uint8_t *data, size_t n) : b(data), e(data + n), b0(data) {}
     bool need(size_t n) { if ((size_t)(e - b) < n) { ok = false; return false; } return true; }
     uint64_t le(int n) { uint64_t v = 0; for (int k = 0; k < n; ++k) v |= (uint64_t)b[k] << (8 * k); b += n; return v; }
     Val bytes_of(size_t n) { Val v; v.kind = Val::BYTES; v.p = b; v.len = (int64_t)n; b += n; return v; }
-    void put(size_t idx, const Val &v) { if (memo.size() <= idx) memo.resize(idx + 1); memo[idx] = v; }
+    // memo slots are numbered by the pickler in the order it meets objects, so a valid index never exceeds the number of
+    // bytes read so far; anything larger is a corrupt (or hostile) file, not a reason to allocate gigabytes
+    void put(size_t idx, const Val &v)
+    {
+        if (idx > (size_t)(b - b0)) { ok = false; return; }
+        if (memo.size() <= idx) memo.resize(idx + 1);
+        memo[idx] = v;
+    }
     int mark_pos()
     {
         for (int k = (int)stack.size() - 1; k >= 0; --k)
@@ -383,30 +390,36 @@ extern "C" int cm3d_reader_load_sweeps(cm3d_reader *r, const char *const *paths,
 {
     if (!r || !paths || n_files < 0 || stride <= 0 || !sweep_row_off || (!raw_out && cap_rows > 0)) return CM3D_RD_ERR_ARG;
     if (bad_index) *bad_index = -1;
-    // sizes first (serial: a few microseconds per file), then every file straight to its place
-    std::vector<int> fds((size_t)n_files, -1);
-    auto close_all = [&] { for (int fd : fds) if (fd >= 0) close(fd); };
-    int64_t rows = 0;
-    sweep_row_off[0] = 0;
-    const int64_t row_bytes = (int64_t)stride * 4;
-    for (int i = 0; i < n_files; ++i) {
-        struct stat st;
-        fds[i] = paths[i] ? open(paths[i], O_RDONLY) : -1;
-        if (fds[i] < 0 || fstat(fds[i], &st) != 0) { if (bad_index) *bad_index = i; close_all(); return CM3D_RD_ERR_IO; }
-        if (st.st_size % row_bytes) { if (bad_index) *bad_index = i; close_all(); return CM3D_RD_ERR_FORMAT; }
-        rows += st.st_size / row_bytes;
-        if (rows > 0x7FFFFFFF) { if (bad_index) *bad_index = i; close_all(); return CM3D_RD_ERR_CAPACITY; }
-        sweep_row_off[i + 1] = (int32_t)rows;
+    // sizes first (stat, serial: a few microseconds per file), then every file opened, read straight to its place and closed
+    // inside its own task: a batch may name thousands of sweeps, far more than a process may hold open at once
+    try {
+        int64_t rows = 0;
+        sweep_row_off[0] = 0;
+        const int64_t row_bytes = (int64_t)stride * 4;
+        for (int i = 0; i < n_files; ++i) {
+            struct stat st;
+            if (!paths[i] || stat(paths[i], &st) != 0 || !S_ISREG(st.st_mode)) { if (bad_index) *bad_index = i; return CM3D_RD_ERR_IO; }
+            if (st.st_size % row_bytes) { if (bad_index) *bad_index = i; return CM3D_RD_ERR_FORMAT; }
+            rows += st.st_size / row_bytes;
+            if (rows > 0x7FFFFFFF) { if (bad_index) *bad_index = i; return CM3D_RD_ERR_CAPACITY; }
+            sweep_row_off[i + 1] = (int32_t)rows;
+        }
+        if (rows > cap_rows) return CM3D_RD_ERR_CAPACITY;
+        std::atomic<int> bad{-1};
+        r->pool.run(n_files, [&](int i) {
+            const int64_t a = sweep_row_off[i], n = sweep_row_off[i + 1] - a;
+            if (n == 0) return;
+            const int fd = open(paths[i], O_RDONLY);
+            struct stat st;
+            // (a file that changed size between the two looks is an I/O error, not a buffer overrun)
+            if (fd < 0 || fstat(fd, &st) != 0 || st.st_size != n * row_bytes || !read_fully(fd, raw_out + a * stride, (size_t)(n * row_bytes))) bad = i;
+            if (fd >= 0) close(fd);
+        });
+        if (bad >= 0) { if (bad_index) *bad_index = bad; return CM3D_RD_ERR_IO; }
+        return CM3D_RD_OK;
+    } catch (...) {
+        return CM3D_RD_ERR_IO;
     }
-    if (rows > cap_rows) { close_all(); return CM3D_RD_ERR_CAPACITY; }
-    std::atomic<int> bad{-1};
-    r->pool.run(n_files, [&](int i) {
-        const int64_t a = sweep_row_off[i], n = sweep_row_off[i + 1] - a;
-        if (!read_fully(fds[i], raw_out + a * stride, (size_t)(n * row_bytes))) bad = i;
-    });
-    close_all();
-    if (bad >= 0) { if (bad_index) *bad_index = bad; return CM3D_RD_ERR_IO; }
-    return CM3D_RD_OK;
 }
 
 extern "C" int cm3d_reader_load_masks(cm3d_reader *r, const char *const *paths, int32_t n_files, uint32_t *counts_out, int64_t cap_counts,
@@ -415,36 +428,44 @@ extern "C" int cm3d_reader_load_masks(cm3d_reader *r, const char *const *paths, 
 {
     if (!r || !paths || n_files < 0 || !frame_mask_off || !needed) return CM3D_RD_ERR_ARG;
     if (bad_index) *bad_index = -1;
-    struct PerFile { std::vector<uint32_t> cnts; std::vector<int64_t> off; std::vector<int32_t> wh; int rc = CM3D_RD_OK; };
-    std::vector<PerFile> pf((size_t)n_files);
-    r->pool.run(n_files, [&](int i) {
-        if (!paths[i] || !paths[i][0]) return;                 // a frame without detections has no file
-        std::vector<uint8_t> buf;
-        if (!read_file(paths[i], buf)) { pf[i].rc = CM3D_RD_ERR_IO; return; }
-        pf[i].rc = parse_mask_file(buf, pf[i].cnts, pf[i].off, pf[i].wh);
-    });
-    int64_t total_counts = 0, total_masks = 0;
-    for (int i = 0; i < n_files; ++i) {
-        if (pf[i].rc != CM3D_RD_OK) { if (bad_index) *bad_index = i; return pf[i].rc; }
-        total_counts += (int64_t)pf[i].cnts.size();
-        total_masks += (int64_t)pf[i].off.size();
-    }
-    needed[0] = total_counts;
-    needed[1] = total_masks;
-    if (total_counts > cap_counts || total_masks > cap_masks || total_counts > 0x7FFFFFFF || !counts_out || !rle_off || !mask_wh)
-        return CM3D_RD_ERR_CAPACITY;
-    // exclusive offsets, then every file's share copied in parallel
-    std::vector<int64_t> c0((size_t)n_files + 1, 0), m0((size_t)n_files + 1, 0);
-    for (int i = 0; i < n_files; ++i) { c0[i + 1] = c0[i] + (int64_t)pf[i].cnts.size(); m0[i + 1] = m0[i] + (int64_t)pf[i].off.size(); }
-    for (int i = 0; i <= n_files; ++i) frame_mask_off[i] = (int32_t)m0[i];
-    rle_off[0] = 0;
-    r->pool.run(n_files, [&](int i) {
-        if (!pf[i].cnts.empty()) memcpy(counts_out + c0[i], pf[i].cnts.data(), pf[i].cnts.size() * sizeof(uint32_t));
-        for (size_t k = 0; k < pf[i].off.size(); ++k) {
-            rle_off[m0[i] + (int64_t)k + 1] = (int32_t)(c0[i] + pf[i].off[k]);
-            mask_wh[2 * (m0[i] + (int64_t)k)] = pf[i].wh[2 * k];
-            mask_wh[2 * (m0[i] + (int64_t)k) + 1] = pf[i].wh[2 * k + 1];
+    try {
+        struct PerFile { std::vector<uint32_t> cnts; std::vector<int64_t> off; std::vector<int32_t> wh; int rc = CM3D_RD_OK; };
+        std::vector<PerFile> pf((size_t)n_files);
+        r->pool.run(n_files, [&](int i) {
+            if (!paths[i] || !paths[i][0]) return;                 // a frame without detections has no file
+            try {                                                  // (no exception may leave a pool thread or the C ABI)
+                std::vector<uint8_t> buf;
+                if (!read_file(paths[i], buf)) { pf[i].rc = CM3D_RD_ERR_IO; return; }
+                pf[i].rc = parse_mask_file(buf, pf[i].cnts, pf[i].off, pf[i].wh);
+            } catch (...) {
+                pf[i].rc = CM3D_RD_ERR_FORMAT;                     // out of memory on a file-controlled size: treat the file as malformed
+            }
+        });
+        int64_t total_counts = 0, total_masks = 0;
+        for (int i = 0; i < n_files; ++i) {
+            if (pf[i].rc != CM3D_RD_OK) { if (bad_index) *bad_index = i; return pf[i].rc; }
+            total_counts += (int64_t)pf[i].cnts.size();
+            total_masks += (int64_t)pf[i].off.size();
         }
-    });
-    return CM3D_RD_OK;
+        needed[0] = total_counts;
+        needed[1] = total_masks;
+        if (total_counts > cap_counts || total_masks > cap_masks || total_counts > 0x7FFFFFFF || !counts_out || !rle_off || !mask_wh)
+            return CM3D_RD_ERR_CAPACITY;
+        // exclusive offsets, then every file's share copied in parallel
+        std::vector<int64_t> c0((size_t)n_files + 1, 0), m0((size_t)n_files + 1, 0);
+        for (int i = 0; i < n_files; ++i) { c0[i + 1] = c0[i] + (int64_t)pf[i].cnts.size(); m0[i + 1] = m0[i] + (int64_t)pf[i].off.size(); }
+        for (int i = 0; i <= n_files; ++i) frame_mask_off[i] = (int32_t)m0[i];
+        rle_off[0] = 0;
+        r->pool.run(n_files, [&](int i) {
+            if (!pf[i].cnts.empty()) memcpy(counts_out + c0[i], pf[i].cnts.data(), pf[i].cnts.size() * sizeof(uint32_t));
+            for (size_t k = 0; k < pf[i].off.size(); ++k) {
+                rle_off[m0[i] + (int64_t)k + 1] = (int32_t)(c0[i] + pf[i].off[k]);
+                mask_wh[2 * (m0[i] + (int64_t)k)] = pf[i].wh[2 * k];
+                mask_wh[2 * (m0[i] + (int64_t)k) + 1] = pf[i].wh[2 * k + 1];
+            }
+        });
+        return CM3D_RD_OK;
+    } catch (...) {
+        return CM3D_RD_ERR_FORMAT;
+    }
 }

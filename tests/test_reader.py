@@ -136,3 +136,44 @@ def test_integration_md_reader_binding_runs_as_written(tmp_path):
     assert np.array_equal(counts.numpy()[:rle_off[len(exp)]].view(np.uint32), np.concatenate(exp))
     assert list(fm_off) == list(np.concatenate([[0], np.cumsum([len(f.rles) for f in frames])]))
     assert (wh[:len(exp)] == [cfg.width, cfg.height]).all()
+
+
+def test_more_sweep_files_than_open_file_descriptors(tmp_path):
+    """A batch may name thousands of sweeps (4 scenes x 40 frames x 10 sweeps): the loader must not hold a descriptor per
+    file.  1200 files under RLIMIT_NOFILE = 256."""
+    import resource
+    rng = np.random.default_rng(0)
+    paths, rows = [], []
+    for i in range(1200):
+        a = rng.random((int(rng.integers(1, 6)), 5)).astype(np.float32)
+        p = tmp_path / f"{i}.bin"
+        a.tofile(p)
+        paths.append(str(p)); rows.append(a)
+    soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+    resource.setrlimit(resource.RLIMIT_NOFILE, (256, hard))
+    try:
+        rd = reader.Reader(8, pinned=False)
+        raw, row_off = rd.load_sweeps(paths, 5)
+    finally:
+        resource.setrlimit(resource.RLIMIT_NOFILE, (soft, hard))
+    assert np.array_equal(raw[:row_off[-1]], np.concatenate(rows)) and np.array_equal(np.diff(row_off), [r.shape[0] for r in rows])
+
+
+def test_malformed_mask_files_are_errors_not_crashes(tmp_path):
+    """A memo index out of any plausible range (BINPUT / LONG_BINPUT are file-controlled), a truncated file and an RLE string
+    of 13 five-bit groups: each comes back as an error code (the Python side falls back to pickle.load or raises), never as an
+    exception through the C ABI or a gigabyte allocation."""
+    bad = {"memo.pkl": b"\x80\x02]r\xff\xff\xff\xff.", "trunc.pkl": pickle.dumps([{"size": [4, 4], "counts": b"04"}])[:-7],
+           "notalist.pkl": pickle.dumps({"size": [4, 4]})}
+    rd = reader.Reader(2, pinned=False)
+    for name, blob in bad.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        with pytest.raises(reader.ReaderError) as e:
+            rd.load_masks([str(p)])
+        assert e.value.code == reader.ERR_FORMAT, name
+    # 13 groups: 65 bits of payload -- a value no mask can hold, rejected; 12 groups still parse
+    for groups in (12, 13, 40):
+        with pytest.raises(ValueError):
+            reader.string_to_counts(b"o" * groups + b"0")
+    assert list(reader.string_to_counts(b"o" * 5 + b"0")) == [0x1FFFFFF]
