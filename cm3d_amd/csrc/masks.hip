@@ -432,6 +432,250 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
     if (threadIdx.x < 4) bbox[4 * m + threadIdx.x] = s_bb[threadIdx.x];
 }
 
+// ---------------------------------------------------------------------------
+// f1, the form for ordinary masks (a few hundred runs): one workgroup per mask whose WAVES NEVER SYNCHRONISE until the mask's
+// bounding box is put together at the very end.  k_rle_erode_pack above gives a mask 256 threads and pays for it with eight
+// barriers while three lanes in four have no run to scan (an instance mask of 1600x900 has 20..600 runs).  Here the mask's
+// rows are cut into up to four BANDS, one wave each (a mask of up to 128 runs is one band: the other waves leave at once);
+// every wave of a mask scans all its runs itself (8 per lane, one wave scan per 512 runs -- a few hundred instructions,
+// cheaper than a barrier and a hand-over), paints the runs that touch its band into its own LDS tile, and erodes it with a
+// sliding window: a lane owns one word column of a stretch of rows and walks down it, keeping the horizontal AND of the
+// previous two rows in registers -- 3 LDS reads per output word instead of 9.  The launch is bound by instruction issue and by
+// its longest wave (measured: one wave for a whole 60 000-pixel mask runs 20 us by itself), hence the bands.
+// Same outputs bit for bit (tests/test_gpu_golden.py runs both forms against the oracle).
+#define RW_WAVES 4
+#define RW_THREADS (64 * RW_WAVES)
+#define RW_PER 8
+#define RW_CHUNK (64 * RW_PER)
+#define RW_LDS_WORDS 1024      // per wave
+#define RW_BAND_RUNS 128       // runs per band a mask is cut into (two runs per row: 64 rows)
+
+static __device__ __forceinline__ void rw_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// runs [base + 8 lane, +8) of the mask; returns the start pixel of the lane's first run, advances carry (uniform)
+static __device__ __forceinline__ int rw_chunk_scan(const uint32_t *__restrict__ cnts, int n, int base, int lane, int (&v)[RW_PER], int &carry)
+{
+    const int i0 = base + lane * RW_PER;
+    int sum = 0;
+    if (i0 + RW_PER <= n && ((((uintptr_t)(cnts + i0)) & 15) == 0)) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(cnts + i0), b = *reinterpret_cast<const uint4 *>(cnts + i0 + 4);
+        v[0] = (int)a.x; v[1] = (int)a.y; v[2] = (int)a.z; v[3] = (int)a.w; v[4] = (int)b.x; v[5] = (int)b.y; v[6] = (int)b.z; v[7] = (int)b.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < RW_PER; ++q) v[q] = i0 + q < n ? (int)cnts[i0 + q] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < RW_PER; ++q) sum += v[q];
+    const int inc = cm3d_wave_incl_scan(sum);
+    const int start = carry + inc - sum;
+    carry += __builtin_amdgcn_readlane(inc, 63);
+    return start;
+}
+
+// pixel index -> row: s / W through a float reciprocal and one correction each way (exact: the estimate is off by less
+// than one for W * H < 2^31, H < 2^23); the compiler's 32-bit division costs three times the instructions and registers
+static __device__ __forceinline__ int rw_row_of(uint32_t s, int W, float rcpW)
+{
+    int y = (int)((float)s * rcpW);
+    y -= (uint32_t)y * (uint32_t)W > s ? 1 : 0;
+    y += (uint32_t)(y + 1) * (uint32_t)W <= s ? 1 : 0;
+    return y;
+}
+
+// the (at most four) 1-runs among a lane's eight runs as (start pixel, length), from the start pixel of its first run
+static __device__ __forceinline__ void rw_one_runs(int run, const int (&v)[RW_PER], int (&s1)[RW_PER / 2], int (&l1)[RW_PER / 2])
+{
+#pragma unroll
+    for (int q = 0; q < RW_PER / 2; ++q) {
+        s1[q] = run + v[2 * q];
+        l1[q] = v[2 * q + 1];
+        run += v[2 * q] + v[2 * q + 1];
+    }
+}
+
+__global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uint32_t *__restrict__ cnts_all, const int32_t *__restrict__ rle_off,
+                                                                        int n_masks, int W, int H, int Wp, int lds_words,
+                                                                        uint32_t *__restrict__ packed, int32_t *__restrict__ bbox, int max_bands, int diag)
+{
+    extern __shared__ __align__(16) uint32_t s_all[];
+    __shared__ int s_part[RW_WAVES][4];                         // the bands' shares of the bounding box
+    const int lane = cm3d_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // max_bands > 1: one workgroup per mask, wave w its band w; 1: four masks per workgroup, one wave each
+    const int m = max_bands > 1 ? (int)blockIdx.x : (int)blockIdx.x * RW_WAVES + wave;
+    if (m >= n_masks) return;                                   // (max_bands == 1 only; such a workgroup meets no barrier)
+    const int band = max_bands > 1 ? wave : 0;
+    uint32_t *s_rows = s_all + (size_t)wave * lds_words;
+    const int o = rle_off[m], n = rle_off[m + 1] - o;
+    const uint32_t *cnts = cnts_all + o;
+    const int nb = max(1, min(max_bands, (n + RW_BAND_RUNS - 1) / RW_BAND_RUNS));     // bands = waves at work on this mask
+    int bminx = 0x7FFFFFFF, bminy = 0x7FFFFFFF, bmaxx = -1, bmaxy = -1;               // bounding box of the band's eroded pixels
+    if (band < nb) {
+    const float rcpW = 1.0f / (float)W;
+    // ---- pass 1: rectangle of the set pixels (the 1-runs of the first chunk stay in registers)
+    int s0[RW_PER / 2], l0[RW_PER / 2];
+    int ylo = 0x7FFFFFFF, yhi = -1, xlo = 0x7FFFFFFF, xhi = -1;
+    int carry0 = 0;                             // pixels covered by the first chunk of runs
+    {
+        int carry = 0;
+#pragma unroll 1
+        for (int base = 0; base < n; base += RW_CHUNK) {
+            int v[RW_PER], s1[RW_PER / 2], l1[RW_PER / 2];
+            const int run = rw_chunk_scan(cnts, n, base, lane, v, carry);
+            rw_one_runs(run, v, s1, l1);
+            if (base == 0) {
+                carry0 = carry;
+#pragma unroll
+                for (int q = 0; q < RW_PER / 2; ++q) { s0[q] = s1[q]; l0[q] = l1[q]; }
+            }
+#pragma unroll 1
+            for (int q = 0; q < RW_PER / 2; ++q) {
+                const int s = s1[0], len = l1[0];
+#pragma unroll
+                for (int r = 0; r + 1 < RW_PER / 2; ++r) { s1[r] = s1[r + 1]; l1[r] = l1[r + 1]; }
+                if (len > 0) {                                          // a 1-run [s, s + len)
+                    const int ys = rw_row_of((uint32_t)s, W, rcpW), ye = rw_row_of((uint32_t)(s + len - 1), W, rcpW);
+                    ylo = min(ylo, ys); yhi = max(yhi, ye);
+                    if (ys == ye) { xlo = min(xlo, s - ys * W); xhi = max(xhi, s + len - 1 - ys * W); }
+                    else { xlo = 0; xhi = W - 1; }
+                }
+            }
+        }
+        ylo = __builtin_amdgcn_readfirstlane(cm3d_wave_min(ylo)); xlo = __builtin_amdgcn_readfirstlane(cm3d_wave_min(xlo));
+        yhi = __builtin_amdgcn_readfirstlane(cm3d_wave_max(yhi)); xhi = __builtin_amdgcn_readfirstlane(cm3d_wave_max(xhi));
+    }
+    if (!(yhi < 0 || (diag & 8))) {             // (an empty mask: nothing to paint, the box stays empty)
+    const int my0 = ylo, my1 = min(yhi, H - 1);                        // rows of the mask's set pixels; this wave's band of them:
+    const int bandr = (my1 - my0 + nb) / nb;
+    const int ry0 = my0 + band * bandr, ry1 = min(my1, ry0 + bandr - 1);
+    const int xw0 = xlo >> 5, wc = (min(xhi, W - 1) >> 5) - xw0 + 1, lw = wc + 2;
+    int br = lds_words / lw - 2;                // output rows per tile
+    br = min(br, ry1 - ry0 + 1);
+    const uint32_t pad = (W & 31) ? ~((1u << (W & 31)) - 1u) : 0u;
+    const uint32_t tail_mask = ~pad;
+    uint32_t *out_mask = packed + (size_t)m * H * Wp;
+    // (bounding box of the eroded pixels: per lane the OR of its column's words and its first / last non-empty row)
+    const int nseg = max(1, 64 / wc);           // stretches of rows a tile is cut into (one lane per stretch and word column)
+    for (int y0 = ry0; y0 <= ry1; y0 += br) {
+        const int rows = min(br, ry1 - y0 + 1);
+        const int lrows = rows + 2;
+        const int ya = y0 - 1;                  // image row of LDS row 0
+        rw_lds_sync();                          // the previous tile's readers are done
+        // initial tile: zeros inside the image (16 bytes per lane and step), then the few places that are ones
+        {
+            const int nq = (lrows * lw + 3) >> 2;
+            for (int q = lane; q < nq; q += 64) reinterpret_cast<uint4 *>(s_rows)[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (xw0 == 0 || xw0 + wc == Wp || ya < 0 || ya + lrows - 1 >= H) {          // the rectangle touches the image's border (uniform)
+                rw_lds_sync();
+                if (xw0 == 0) for (int r = lane; r < lrows; r += 64) s_rows[r * lw] = 0xFFFFFFFFu;                       // left of the image
+                if (xw0 + wc == Wp) {
+                    for (int r = lane; r < lrows; r += 64) { s_rows[r * lw + lw - 1] = 0xFFFFFFFFu; if (pad) s_rows[r * lw + lw - 2] = pad; }
+                }
+                rw_lds_sync();
+                if (ya < 0) for (int c = lane; c < lw; c += 64) s_rows[c] = 0xFFFFFFFFu;                                  // above the image
+                if (ya + lrows - 1 >= H) for (int c = lane; c < lw; c += 64) s_rows[(lrows - 1) * lw + c] = 0xFFFFFFFFu;  // below it
+            }
+        }
+        rw_lds_sync();
+        const int yc0 = max(ya, 0), yc1 = min(ya + lrows - 1, H - 1);            // image rows held in LDS
+        const uint32_t px0 = (uint32_t)yc0 * W, px1 = (uint32_t)(yc1 + 1) * W;   // pixel range [px0, px1)
+        {
+            int carry = 0;
+#pragma unroll 1
+            for (int base = 0; base < ((diag & 4) ? 0 : n); base += RW_CHUNK) {
+                int s1[RW_PER / 2], l1[RW_PER / 2];
+                if (base == 0) {                                    // uniform
+#pragma unroll
+                    for (int q = 0; q < RW_PER / 2; ++q) { s1[q] = s0[q]; l1[q] = l0[q]; }
+                } else {
+                    int v[RW_PER];
+                    const int run = rw_chunk_scan(cnts, n, base, lane, v, carry);
+                    rw_one_runs(run, v, s1, l1);
+                }
+#pragma unroll 1
+                for (int q = 0; q < RW_PER / 2; ++q) {
+                    const uint32_t rs = (uint32_t)s1[0], re = rs + (uint32_t)l1[0];
+#pragma unroll
+                    for (int r = 0; r + 1 < RW_PER / 2; ++r) { s1[r] = s1[r + 1]; l1[r] = l1[r + 1]; }
+                    uint32_t ps = max(rs, px0);
+                    const uint32_t pe = min(re, px1);
+                    while (ps < pe) {                               // (one round per image row the run touches)
+                        const int y = rw_row_of(ps, W, rcpW);
+                        const uint32_t x = ps - (uint32_t)y * W;
+                        const uint32_t xe = min((uint32_t)W, x + (pe - ps));   // exclusive end within this row
+                        uint32_t *row = s_rows + (y - ya) * lw + 1 - xw0;      // row[xw] = packed word xw
+                        const uint32_t w0 = x >> 5, w1 = (xe - 1) >> 5;
+                        const uint32_t m0 = 0xFFFFFFFFu << (x & 31);
+                        const uint32_t m1 = 0xFFFFFFFFu >> (31 - ((xe - 1) & 31));
+                        if (w0 == w1) atomicOr(&row[w0], m0 & m1);
+                        else {
+                            atomicOr(&row[w0], m0);
+                            for (uint32_t w = w0 + 1; w < w1; ++w) atomicOr(&row[w], 0xFFFFFFFFu);
+                            atomicOr(&row[w1], m1);
+                        }
+                        ps += xe - x;
+                    }
+                }
+                if (base == 0) carry = carry0;                      // pixels covered by the first chunk (pass 1)
+                if ((uint32_t)carry >= px1) break;                  // uniform: the rest lies below the tile
+            }
+        }
+        rw_lds_sync();
+        // erosion, sliding window down a word column: h(r) = centre & left & right of LDS row r; out(r) = h(r-1) & h(r) & h(r+1)
+        const int rps = (rows + nseg - 1) / nseg;           // output rows per band
+        for (int cb = 0; cb < ((diag & 2) ? 0 : wc); cb += 64) {
+            const int seg = wc >= 64 ? 0 : lane / wc, c = wc >= 64 ? cb + lane : lane - seg * wc;
+            const int r0 = seg * rps, r1 = min(rows, r0 + rps);                  // output rows [r0, r1) of the tile (LDS rows r0+1 .. r1)
+            if (c < wc && seg < nseg && r0 < r1) {
+                const uint32_t *row = s_rows + r0 * lw + c;
+                auto hrow = [&](const uint32_t *rw) {
+                    const uint32_t ce = rw[1];
+                    return ce & ((ce << 1) | (rw[0] >> 31)) & ((ce >> 1) | (rw[2] << 31));
+                };
+                uint32_t h0 = hrow(row), h1 = hrow(row + lw);
+                row += 2 * lw;
+                const int xw = xw0 + c;
+                const uint32_t keep = xw == Wp - 1 ? tail_mask : 0xFFFFFFFFu;
+                uint32_t *dst = out_mask + (size_t)(ya + 1 + r0) * Wp + xw;
+                uint32_t colany = 0u;
+                int first = 0x7FFFFFFF, last = -1;
+                for (int r = r0; r < r1; ++r, row += lw, dst += Wp) {
+                    const uint32_t h2 = hrow(row);
+                    const uint32_t e = h0 & h1 & h2 & keep;
+                    h0 = h1; h1 = h2;
+                    if (!(diag & 1)) *dst = e;
+                    colany |= e;
+                    if (e) { first = min(first, r); last = r; }
+                }
+                if (colany) {
+                    bminx = min(bminx, xw * 32 + __builtin_ctz(colany));
+                    bmaxx = max(bmaxx, xw * 32 + 31 - __builtin_clz(colany));
+                    bminy = min(bminy, ya + 1 + first);
+                    bmaxy = max(bmaxy, ya + 1 + last);
+                }
+            }
+        }
+    }
+    }
+    }
+    bminx = cm3d_wave_min(bminx); bminy = cm3d_wave_min(bminy); bmaxx = cm3d_wave_max(bmaxx); bmaxy = cm3d_wave_max(bmaxy);
+    if (nb == 1) {                              // uniform over the workgroup (or max_bands == 1): one band, no hand-over
+        if (band == 0 && lane < 4) bbox[4 * m + lane] = lane == 0 ? bminx : lane == 1 ? bminy : lane == 2 ? bmaxx : bmaxy;
+        return;
+    }
+    if (lane < 4) s_part[wave][lane] = lane == 0 ? bminx : lane == 1 ? bminy : lane == 2 ? bmaxx : bmaxy;
+    __syncthreads();
+    if (wave == 0 && lane < 4) {
+        int v = s_part[0][lane];
+        for (int w = 1; w < RW_WAVES; ++w) v = lane < 2 ? min(v, s_part[w][lane]) : max(v, s_part[w][lane]);
+        bbox[4 * m + lane] = v;
+    }
+}
+
 static inline size_t rle_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 extern "C" int64_t cm3d_rle_workspace_bytes(int32_t total_runs)
@@ -475,8 +719,35 @@ extern "C" int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rl
     if (!lds_words) { const char *e = getenv("CM3D_RLE_LDS_WORDS"); lds_words = e ? atoi(e) : RLE_LDS_WORDS; }
     if (lds_words / (Wp + 2) - 2 < 1) return CM3D_ERR_ARG;      // tile height of a full-width mask
     (void)workspace;                                            // reserved (the run ends are not materialised)
-    hipLaunchKernelGGL(k_rle_erode_pack, dim3(n_masks), dim3(EP_THREADS), (size_t)lds_words * 4, st, rle_counts, rle_off, W, H, Wp,
-                       lds_words, packed, bbox);
+    // ordinary masks (on average at most 1024 runs): one wave per mask; lists of thousands of runs: one workgroup per mask
+    static int form = -1, lds_wave = 0, rle_diag = 0, bands = 1;
+    if (form < 0) {
+        const char *bd = getenv("CM3D_RLE_BANDS");                // 1: a wave per mask; 2..4: a workgroup per mask, its rows in up to that many bands
+        bands = bd ? atoi(bd) : 1;
+        if (bands < 1 || bands > RW_WAVES) bands = 1;
+        const char *dg = getenv("CM3D_RLE_DIAG");                 // experiments only: 1 no stores, 2 no erosion, 4 no paint, 8 stop behind pass 1
+        rle_diag = dg ? atoi(dg) : 0;
+        const char *e = getenv("CM3D_RLE_FORM");                  // "wave" / "block" force one form (experiments, tests)
+        form = e ? (e[0] == 'w' ? 1 : 2) : 0;
+        const char *w = getenv("CM3D_RLEW_LDS_WORDS");
+        lds_wave = w ? atoi(w) : RW_LDS_WORDS;
+        if (lds_wave < 3 * (EP_MAX_WP + 2)) lds_wave = 3 * (EP_MAX_WP + 2);
+        lds_wave = (lds_wave + 3) & ~3;
+    }
+    const bool wave_form = form == 1 || (form == 0 && (int64_t)total_runs <= (int64_t)n_masks * 1024);
+    if (wave_form) {
+        const size_t lds = (size_t)RW_WAVES * lds_wave * 4;
+        static size_t lds_allowed = 48 * 1024;
+        if (lds > lds_allowed) {
+            if (hipFuncSetAttribute((const void *)k_rle_erode_pack_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CM3D_ERR_LAUNCH;
+            lds_allowed = lds;
+        }
+        hipLaunchKernelGGL(k_rle_erode_pack_wave, dim3(bands > 1 ? n_masks : (n_masks + RW_WAVES - 1) / RW_WAVES), dim3(RW_THREADS), lds, st,
+                           rle_counts, rle_off, n_masks, W, H, Wp, lds_wave, packed, bbox, bands, rle_diag);
+    } else {
+        hipLaunchKernelGGL(k_rle_erode_pack, dim3(n_masks), dim3(EP_THREADS), (size_t)lds_words * 4, st, rle_counts, rle_off, W, H, Wp,
+                           lds_words, packed, bbox);
+    }
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

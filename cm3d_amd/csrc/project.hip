@@ -10,9 +10,11 @@
 // sorted by camera with their bounding boxes, row ranges) are built once per frame by k_frame_tables, staged into LDS
 // behind the only workgroup barrier, and every wave writes its own results:
 //   hit_words  one 32-bit word per row per 32 masks
-//   wc_cnt     one count per (wave-chunk, mask); their exclusive scan (k_hit_offsets) gives every wave-chunk its exact
-//              output offset, and k_compact_hits writes the ascending index lists with ballot + mbcnt ranks
-//              (no atomics on the output order: deterministic)
+//   wc_cnt     one count per (wave-chunk, mask), and the same counts summed over groups of 16 wave-chunks (integer atomics:
+//              order-free) -- k_compact_hits turns them into every wave-chunk's exact output offset itself and writes the
+//              ascending index lists with ballot + mbcnt ranks (no atomics on the output order: deterministic)
+//   wc_info    per wave-chunk: does it hold a hit at all (the compaction never touches the hit words of the others),
+//              how many of its rows the reference drops
 //   removed_bits  one bit per row the reference drops (ego box, :442-445)
 // The transformed cloud is optional (`points` may be NULL): the medoid stage only needs the in-mask points, and
 // k_compact_hits re-derives their coordinates from the raw rows (same fma chains, same bits) into hit_xyz.
@@ -105,6 +107,7 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 //   [24..40] frame-local first row of each sweep (fused path; ns <= PH_MAX_SWEEPS)
 //   [17] largest pixel margin of the approximate projections  [18] bit c = camera c has an approximate projection
 //   [19] smallest depth the approximate projection may accept (float bits)  [20] bit c = camera c has a non-empty mask
+//   [21] 1 = fused sweep preparation (the launch counts the dropped rows of every wave-chunk)
 //   [64..127] view wedges, 8 floats per camera
 //   [128..255] approximate projections, 16 floats per camera (wedge_setup)
 #define FT_WORDS 256
@@ -113,6 +116,7 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 #define FT_APXOK 18
 #define FT_ZMIN 19
 #define FT_CAMHAS 20
+#define FT_FUSED 21                              // 1: the launch prepares the sweeps itself and counts the dropped rows (wc_info, group sums)
 #define FT_SROW 24
 #define FT_WEDGE 64
 #define FT_APX 128
@@ -323,7 +327,13 @@ struct PhSweepIn {
 };
 
 // workspace of the projection / compaction pair
-struct PhWs { int4 *ment; int32_t *ft; int32_t *wc_drop; int32_t *wc_cnt; int32_t *queue; };
+//   wc_cnt   [F][nwc_max][nm_cap]  hits per (wave-chunk, mask)
+//   wc_info  [F][nwc_max]          per wave-chunk: bit 31 = holds a hit, low bits = rows of the chunk the reference drops
+//   grp      [F][zstride]          per frame, zeroed by k_frame_tables: [ngrp_max][nm_cap] hits per (group of PH_GRP wave-chunks, mask),
+//                                  then [ngrp_max] dropped rows per group -- the second level of the compaction's prefix sums
+//   frame_hits [F]                 in-mask points of the frame (all masks)
+#define PH_GRP 16
+struct PhWs { int4 *ment; int32_t *ft; int32_t *wc_info; int32_t *wc_cnt; int32_t *queue; int32_t *grp; int32_t *frame_hits; int zstride; };
 static inline int ph_nm_cap(int planes)
 {
     int c = planes * 32;
@@ -333,19 +343,25 @@ static inline int ph_tpf_max(int64_t nwc_max) { return (int)((nwc_max + 1) / 2 >
 static inline int64_t ph_ws_layout(int n_frames, int max_pts_per_frame, int planes, void *base, PhWs *out)
 {
     const int64_t nwc_max = (max_pts_per_frame + PH_WC - 1) / PH_WC, nm_cap = ph_nm_cap(planes);
+    const int64_t ngrp_max = (nwc_max + PH_GRP - 1) / PH_GRP;
+    const int64_t zstride = (ngrp_max * (nm_cap + 1) + 3) & ~(int64_t)3;           // whole 16-byte pieces per frame
     int64_t off = 0;
     char *b = (char *)base;
     if (out) out->ment = (int4 *)(b + off);
     off += (int64_t)n_frames * nm_cap * 32;                       // two int4 per mask entry (k_frame_tables)
     if (out) out->ft = (int32_t *)(b + off);
     off += (int64_t)n_frames * FT_WORDS * 4;
-    if (out) out->wc_drop = (int32_t *)(b + off);
+    if (out) out->wc_info = (int32_t *)(b + off);
     off += ((int64_t)n_frames * nwc_max * 4 + 15) & ~(int64_t)15;
     if (out) out->wc_cnt = (int32_t *)(b + off);
     off += (int64_t)n_frames * nwc_max * nm_cap * 4;
     off = (off + 15) & ~(int64_t)15;
     if (out) out->queue = (int32_t *)(b + off);                   // k_project_hits: entries handed out per chunk list, [n_frames][tpf], tpf <= ph_tpf_max
     off += ((int64_t)n_frames * ph_tpf_max(nwc_max) * 4 + 15) & ~(int64_t)15;
+    if (out) { out->grp = (int32_t *)(b + off); out->zstride = (int)zstride; }
+    off += (int64_t)n_frames * zstride * 4;
+    if (out) out->frame_hits = (int32_t *)(b + off);
+    off += ((int64_t)n_frames * 4 + 15) & ~(int64_t)15;
     return off;
 }
 
@@ -358,11 +374,17 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
                                                      const int4 *__restrict__ bbox, int W, int H, float min_dist, int nm_cap,
                                                      int max_pts_per_frame, uint32_t mask_words, int32_t *__restrict__ ft_all,
                                                      int4 *__restrict__ ment_all, int32_t *__restrict__ queue, int tpf,
+                                                     int32_t *__restrict__ grp, int zstride, int32_t *__restrict__ frame_hits,
                                                      int32_t *__restrict__ status)
 {
     const int f = blockIdx.x, lane = threadIdx.x;
     int32_t *ft = ft_all + (size_t)f * FT_WORDS;
     for (int q = lane; q < tpf; q += 64) queue[(size_t)f * tpf + q] = 0;      // the frame's chunk lists: nothing handed out yet
+    {                                                                           // the frame's group sums (project adds into them)
+        uint4 *z = reinterpret_cast<uint4 *>(grp + (size_t)f * zstride);
+        for (int q = lane; q < (zstride >> 2); q += 64) z[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (lane == 0) frame_hits[f] = 0;
+    }
 
     int p0, n, sa = 0, ns = 0;
     if (fused) {
@@ -402,6 +424,7 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
         ft[0] = p0; ft[1] = n; ft[2] = m0; ft[3] = nm; ft[4] = sa; ft[5] = ns;
         ft[6] = (p0 >> 5) + 8 * f;          // frames never overlap: sum ceil(n_g / 32) <= (p0 >> 5) + f, and a chunk owns 8 whole words
         ft[7] = (n + PH_WC - 1) / PH_WC;
+        ft[FT_FUSED] = fused ? 1 : 0;
     }
     int ft_margin = 0;
     {
@@ -582,7 +605,8 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
     uint32_t *__restrict__ removed_bits, const int32_t *__restrict__ ft_all, const int4 *__restrict__ ment_all,
     const float *__restrict__ cams, int n_cams, const uint32_t *__restrict__ packed, int W, int H, int Wp, float min_dist, int nm_cap,
     int nwc_max, int n_points_total, uint32_t *__restrict__ hit_words, int32_t *__restrict__ hit_count, int32_t *__restrict__ wc_cnt,
-    int n_frames, int tpf, int32_t *__restrict__ queue)
+    int n_frames, int tpf, int32_t *__restrict__ queue, int32_t *__restrict__ wc_info, int32_t *__restrict__ grp, int zstride,
+    int32_t *__restrict__ frame_hits)
 {
 #ifdef CM3D_DIAG
     const int diag = g_ph_diag;
@@ -674,13 +698,18 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
     const int4 *ment = ment_all + (size_t)f * nm_cap * 2;           // two int4 per entry
     int acc_cnt = 0;                                                // ONE_PLANE: lane k = hits of mask k over this wave's chunks
     int32_t *const wc_cnt_f = wc_cnt + (size_t)f * nwc_max * nm_cap;  // the frame's count rows
+    int32_t *const wc_info_f = wc_info + (size_t)f * nwc_max;
+    int32_t *const grp_f = grp + (size_t)f * zstride;               // [ngrp_max][nm_cap] hits, then [ngrp_max] dropped rows
+    const int ngrp_max = (nwc_max + PH_GRP - 1) / PH_GRP;
     uint32_t pend_bits[PH_PT] = {0u, 0u, 0u, 0u};                   // results of the previous chunk, not stored yet
-    int pend_cnt = 0, pend_chunk = -1;
+    int pend_cnt = 0, pend_chunk = -1, pend_drop = 0;
+    int acc_multi = 0;                                              // !ONE_PLANE: hits this lane has reported (all masks it handled)
     // results of a chunk: hit words (16 bytes per lane and plane), per-mask counts
     auto flush_results = [&]() {
         if (pend_chunk < 0) return;                                 // uniform
         const int pcb = pend_chunk * PH_WC, pvalid = min(PH_WC, n - pcb);
         int32_t *cnt_row = wc_cnt_f + pend_chunk * nm_cap;
+        bool any = false, mine = false;
         if (ONE_PLANE) {
             uint32_t *hw = hit_words + (size_t)p0 + pcb + 4 * lane;
             if (pvalid >= PH_WC) {
@@ -690,7 +719,11 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
                 for (int j = 0; j < PH_PT; ++j)
                     if (4 * lane + j < pvalid) hw[j] = pend_bits[j];
             }
-            if (lane < 32) cnt_row[lane] = pend_cnt;
+            if (lane < 32) {
+                cnt_row[lane] = pend_cnt;
+                if (pend_cnt) atomicAdd(&grp_f[(pend_chunk / PH_GRP) * nm_cap + lane], pend_cnt);
+            }
+            any = __ballot(pend_cnt != 0) != 0ull;
         } else {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -710,9 +743,20 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             for (int k = lane; k < nm; k += 64) {
                 const int cv = s_cnt[k];
                 cnt_row[k] = cv;
-                if (cv) atomicAdd(&hit_count[m0 + k], cv);
+                if (cv) {
+                    atomicAdd(&hit_count[m0 + k], cv);
+                    atomicAdd(&grp_f[(pend_chunk / PH_GRP) * nm_cap + k], cv);
+                    acc_multi += cv;
+                    mine = true;
+                }
             }
+            any = __ballot(mine) != 0ull;
             __builtin_amdgcn_wave_barrier();
+        }
+        // what the compaction wants to know about the chunk before it touches anything else of it
+        if (lane == 0) {
+            wc_info_f[pend_chunk] = pend_drop | (any ? (int)0x80000000 : 0);
+            if (pend_drop) atomicAdd(&grp_f[ngrp_max * nm_cap + pend_chunk / PH_GRP], pend_drop);
         }
     };
     int draw_from = list;
@@ -722,6 +766,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
         const int nvalid = min(PH_WC, n - cb);                      // uniform
         PH_COUNT(0, 1);
         f2 X[PH_NP], Y[PH_NP], Z[PH_NP];                           // rows (2h, 2h+1) of this lane side by side
+        int drop_now = 0;                                           // rows of this chunk the reference drops (uniform)
         if (FUSED) {
             // sweep of the chunk's first and last row: equal for all but the chunks that hold a sweep boundary
             const int32_t *srow = ft + FT_SROW;
@@ -752,7 +797,9 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
                 if (KEEP && live)
                     points_out[(size_t)p0 + cb + 4 * lane + j] = make_float4(X[j >> 1][j & 1], Y[j >> 1][j & 1], Z[j >> 1][j & 1], cur.v[j * S + (KEEP ? 3 : 0)]);
             }
+            drop_now = 0;
             if (__ballot(nib != 0u)) {
+                drop_now = __builtin_amdgcn_readfirstlane(cm3d_wave_sum(__popc(nib)));
                 // this chunk's 8 words of the frame's removed-row bits (zeroed by cm3d_batch_begin): lane l holds bits 4(l&7)..+3 of word l>>3
                 uint32_t vv = nib << (4 * (lane & 7));
                 vv |= (uint32_t)__shfl_xor((int)vv, 1, 64); vv |= (uint32_t)__shfl_xor((int)vv, 2, 64); vv |= (uint32_t)__shfl_xor((int)vv, 4, 64);
@@ -967,6 +1014,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             acc_cnt += mycnt;
         }
         pend_chunk = chunk;
+        pend_drop = drop_now;
         cur = nxt;
         chunk = c_nxt;
         if (c_nxt < nwc) c_nxt = chunk_of(draw_v, draw_from);
@@ -974,6 +1022,10 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
     } while (chunk < nwc);
     flush_results();
     if (ONE_PLANE && lane < nm && acc_cnt) atomicAdd(&hit_count[m0 + lane], acc_cnt);
+    {
+        const int tot = cm3d_wave_sum(ONE_PLANE ? (lane < nm ? acc_cnt : 0) : acc_multi);
+        if (lane == 0 && tot) atomicAdd(&frame_hits[f], tot);
+    }
 #ifdef CM3D_DIAG
     if ((diag & 16) && lane == 0)
         for (int k = 0; k < 8; ++k) atomicAdd(&g_ph_stamp[k], k == 7 ? 1ull : acc[k]);
@@ -992,258 +1044,229 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
 #endif
 }
 
-// One workgroup per frame: exclusive scans of hit_count and of the medoid tile counts for the frame's masks
-// (the frame's base = sum over all earlier masks, recomputed by every workgroup -- n_masks loads from L2 are
-// cheaper than a launch boundary), then every mask's per-chunk counts turned into exclusive output offsets, in place
-// (32 masks x 32 runs of chunks at a time: run sums, their prefix through LDS, second pass writes), and the number of
-// dropped rows before every chunk.  Status bookkeeping by the last workgroup.
-__global__ __launch_bounds__(1024) void k_hit_offsets(const int32_t *__restrict__ hit_count, int n_masks,
-                                                      const int32_t *__restrict__ ft_all, const int32_t *__restrict__ mask_off,
-                                                      int n_frames, int nm_cap, int nwc_max, int32_t *__restrict__ hit_off,
-                                                      int32_t *__restrict__ tile_off, int32_t *wc_cnt, int32_t *__restrict__ wc_drop,
-                                                      const uint32_t *__restrict__ removed_bits, int idx_cap,
-                                                      int32_t *__restrict__ status)
-{
-    __shared__ int s_part[16];
-    __shared__ int s_red[2][16];
-    __shared__ int s_base[CM3D_MAX_MASKS_PER_FRAME];
-    __shared__ int s_seg[32][33];
-    const int f = blockIdx.x, t = threadIdx.x;
-    const int32_t *ft = ft_all + (size_t)f * FT_WORDS;
-    const int m0 = mask_off[f];
-    const int m1 = f == n_frames - 1 ? n_masks : mask_off[f + 1];
-    const int nm = ft[3], nwc = ft[7], bits_off = ft[6];
-    // base offsets of the frame
-    int a = 0, b = 0;
-    for (int i = t; i < m0; i += 1024) {
-        const int v = hit_count[i];
-        a += v;
-        b += (v + CM3D_MEDOID_TILE - 1) / CM3D_MEDOID_TILE;
-    }
-    a = cm3d_wave_sum(a); b = cm3d_wave_sum(b);
-    if (cm3d_lane() == 0) { s_red[0][t >> 6] = a; s_red[1][t >> 6] = b; }
-    __syncthreads();
-    int carry = 0, tcarry = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) { carry += s_red[0][w]; tcarry += s_red[1][w]; }
-    for (int kb = 0; kb < m1 - m0; kb += 1024) {
-        const int k = kb + t;
-        const bool live = k < m1 - m0;
-        const int v = live ? hit_count[m0 + k] : 0;
-        const int tl = (v + CM3D_MEDOID_TILE - 1) / CM3D_MEDOID_TILE;
-        int tot, ttot;
-        const int ex = cm3d_block1024_excl_scan(v, s_part, tot);
-        const int tex = cm3d_block1024_excl_scan(tl, s_part, ttot);
-        if (live) { hit_off[m0 + k] = carry + ex; tile_off[m0 + k] = tcarry + tex; }
-        if (k < nm) s_base[k] = carry + ex;
-        carry += tot; tcarry += ttot;
-        __syncthreads();
-    }
-    // per-chunk counts -> exclusive output offsets: thread (seg, q) sums / rewrites the chunks [seg cps, (seg+1) cps) of mask 32 pl + q
-    const int seg = t >> 5, q = t & 31;
-    const int cps = (nwc + 31) >> 5, c0 = min(nwc, seg * cps), c1 = min(nwc, c0 + cps);
-    for (int pl = 0; pl * 32 < nm; ++pl) {
-        const int k = pl * 32 + q;
-        int32_t *p = wc_cnt + (size_t)f * nwc_max * nm_cap + k;
-        int sum = 0;
-        if (k < nm) {
-            int c = c0;
-            for (; c + 8 <= c1; c += 8) {
-                int v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(c + u) * nm_cap];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) sum += v[u];
-            }
-            for (; c < c1; ++c) sum += p[(size_t)c * nm_cap];
-        }
-        s_seg[seg][q] = sum;
-        __syncthreads();
-        if (k < nm) {
-            int run = s_base[k];
-            for (int s2 = 0; s2 < seg; ++s2) run += s_seg[s2][q];
-            int c = c0;
-            for (; c + 8 <= c1; c += 8) {
-                int v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(c + u) * nm_cap];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { p[(size_t)(c + u) * nm_cap] = run; run += v[u]; }
-            }
-            for (; c < c1; ++c) {
-                const int v = p[(size_t)c * nm_cap];
-                p[(size_t)c * nm_cap] = run;
-                run += v;
-            }
-        }
-        __syncthreads();
-    }
-    // dropped rows before every chunk (the emitted index of a point is its row minus the dropped rows before it)
-    if (removed_bits) {
-        int dcarry = 0;
-        for (int cb = 0; cb < nwc; cb += 1024) {
-            const int c = cb + t;
-            int v = 0;
-            if (c < nwc) {
-                const uint32_t *w = removed_bits + (size_t)bits_off + 8 * c;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v += __popc(w[u]);
-            }
-            int tot;
-            const int ex = cm3d_block1024_excl_scan(v, s_part, tot);
-            if (c < nwc) wc_drop[(size_t)f * nwc_max + c] = dcarry + ex;
-            dcarry += tot;
-            __syncthreads();
-        }
-    }
-    if (f == n_frames - 1 && t == 0) {
-        hit_off[n_masks] = carry;
-        tile_off[n_masks] = tcarry;
-        status[2] = carry;
-        status[3] = tcarry;
-        if (carry > idx_cap) atomicOr(&status[0], 2);
-    }
-}
-
-// grid (ceil(nwc_max / 4), F [+ 1]): one WAVE per wave-chunk, the same lane <-> row map as k_project_hits (lane l owns rows
-// 4l..4l+3, so ascending row order = (lane, j) order).  Per present mask bit: four ballots, rank = hits in lower lanes +
-// own hits in earlier rows, on top of the chunk's exclusive offset.  Every hit also gets its coordinates (hit_xyz, for the
-// medoid): gathered from the cloud when there is one, else re-derived from the raw row with the projection kernel's very
-// fma chains.  No workgroup barrier on this path.
+// The compaction: hit words -> ascending index lists (hit_idx) and the coordinates of every listed point (hit_xyz).
+// grid (ceil(ceil(nwc_max / CP_SPAN) / 4), F + 1), one launch for everything behind the projection:
+//  * row 0 of the grid (dispatched first): the per-mask hit counts -> hit_off, tile_off, their totals, the overflow flag and the
+//    medoid stage's work list (md_build_from_counts; each workgroup its own share, without talking to the others);
+//  * rows 1..F: one WAVE per CP_SPAN consecutive wave-chunks of a frame, the same lane <-> row map as k_project_hits (lane l
+//    owns rows 4l..4l+3, so ascending row order = (lane, j) order).  What the projection left per wave-chunk (wc_info) says
+//    which chunks hold a hit at all -- two thirds do not on the headline shape, and their hit words are never read.  A wave
+//    that has work computes its own output offsets: in-mask points of the frames before (frame_hits), of the frame's masks
+//    before (hit_count), of the groups of 16 wave-chunks before its own (the group sums) and of the chunks before it inside
+//    its group (wc_cnt) -- a few dozen loads that all go out together; no scan kernel, no second launch.  Then per present
+//    mask bit: four ballots, rank = hits in lower lanes + own hits in earlier rows.  Every hit also gets its coordinates
+//    (gathered from the cloud when there is one, else re-derived from the raw row with the projection kernel's very fma
+//    chains).  No workgroup barrier on this path; no atomics on anything that is an output.
 struct PhXyzSrc { const float *raw; int raw_stride; const float *sweep_xf; const float4 *points; };
+// CP_SPAN: consecutive wave-chunks per wave (a template parameter; divides PH_GRP)
 
-__global__ __launch_bounds__(PH_THREADS) void k_compact_hits(const uint32_t *__restrict__ hit_words, int n_points_total,
+template <int CP_SPAN>
+__global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *__restrict__ hit_words, int n_points_total,
                                                              const int32_t *__restrict__ ft_all, int nm_cap, int nwc_max,
-                                                             const int32_t *__restrict__ wc_base, const int32_t *__restrict__ wc_drop,
+                                                             const int32_t *__restrict__ wc_cnt, const int32_t *__restrict__ wc_info,
+                                                             const int32_t *__restrict__ grp, int zstride,
+                                                             const int32_t *__restrict__ frame_hits,
+                                                             const int32_t *__restrict__ hit_count,
                                                              const uint32_t *__restrict__ removed_bits, const PhXyzSrc xs,
                                                              int32_t *__restrict__ hit_idx, int32_t *__restrict__ hit_row,
                                                              float4 *__restrict__ hit_xyz, int idx_cap, int n_frames, int n_masks,
-                                                             const int32_t *__restrict__ hit_off,
-                                                             const int32_t *__restrict__ tile_off, int tile_cap,
-                                                             TileDesc *__restrict__ tile_work)
+                                                             int32_t *__restrict__ hit_off, int32_t *__restrict__ tile_off, int tile_cap,
+                                                             TileDesc *__restrict__ tile_work, int32_t *__restrict__ status)
 {
-    const int row0 = tile_work ? 1 : 0;
-    if (tile_work && blockIdx.y == 0) {
-        // extra row of the grid, dispatched first: its workgroups build the medoid stage's work list from the offsets
-        // the previous launch wrote (each its own share, without talking to each other), beside -- and hidden under --
-        // the compaction of the hit words
-        __shared__ int s_hist[MD_CLASSES], s_cur[MD_CLASSES];
-        md_build_worklist<PH_THREADS, 2>(n_masks, hit_off, tile_off, idx_cap, tile_cap, tile_work, s_hist, s_cur, (int)blockIdx.x,
-                                      (int)gridDim.x);
+    __shared__ __align__(8) int s_run_all[PH_WAVES][CM3D_MAX_MASKS_PER_FRAME];      // per wave: next output position of every mask of the frame
+    if (blockIdx.y == 0) {
+        md_build_from_counts<PH_THREADS>(n_masks, hit_count, idx_cap, tile_cap, hit_off, tile_off, tile_work, status, &s_run_all[0][0],
+                                         (int)blockIdx.x, (int)gridDim.x);
         return;
     }
-    const int f = (int)blockIdx.y - row0;
+    const int f = (int)blockIdx.y - 1;
     const int lane = cm3d_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int chunk = blockIdx.x * PH_WAVES + wave;
+    const int c0 = ((int)blockIdx.x * PH_WAVES + wave) * CP_SPAN;
     const int32_t *ft = ft_all + (size_t)f * FT_WORDS;
-    const int p0 = ft[0], n = ft[1], nm = ft[3], sa = ft[4], ns = ft[5], bits_off = ft[6];
-    const int cb = chunk * PH_WC;
-    if (cb >= n) return;
-    const int nvalid = min(PH_WC, n - cb);
+    const int nwc = ft[7];
+    if (c0 >= nwc) return;
+    const int32_t *info_f = wc_info + (size_t)f * nwc_max;
+    const int info = (lane < CP_SPAN && c0 + lane < nwc) ? info_f[c0 + lane] : 0;
+    const uint32_t has = (uint32_t)__ballot(info < 0);                 // bit j: wave-chunk c0 + j holds a hit
+    if (!has) return;
+    const int p0 = ft[0], n = ft[1], m0 = ft[2], nm = ft[3], sa = ft[4], ns = ft[5], bits_off = ft[6], fused = ft[FT_FUSED];
     const int planes = (nm + 31) >> 5;
-    // hit words of plane 0 and the chunk's output offsets are requested first
-    auto load_words = [&](int plane, uint32_t (&w)[PH_PT]) {
+    int *s_run = s_run_all[wave];
+    const int g = c0 / PH_GRP, cg0 = g * PH_GRP;                       // the wave's group; its first wave-chunk
+    const int32_t *grp_f = grp + (size_t)f * zstride;
+    const int ngrp_max = (nwc_max + PH_GRP - 1) / PH_GRP;
+    // ---- everything the offsets are made of is requested at once
+    int fsum = 0;                                                      // in-mask points of the frames before this one
+    for (int q = lane; q < f; q += 64) fsum += frame_hits[q];
+    int dsum = 0;                                                      // dropped rows before wave-chunk c0 (fused: counted by the projection)
+    if (fused) {
+        for (int q = lane; q < g; q += 64) dsum += grp_f[ngrp_max * nm_cap + q];
+        if (lane < c0 - cg0) dsum += info_f[cg0 + lane] & 0xFFFF;
+    } else if (removed_bits) {
+        for (int q = lane; q < 8 * c0; q += 64) dsum += __popc(removed_bits[(size_t)bits_off + q]);
+    }
+    const int32_t *cnt_f = wc_cnt + (size_t)f * nwc_max * nm_cap;
+    int carry = 0;
+    for (int k0 = 0; k0 < nm; k0 += 64) {
+        const int k = k0 + lane;
+        int cnt = 0, pre = 0;
+        if (k < nm) {
+            cnt = hit_count[m0 + k];
+            int q = 0;
+            for (; q + 4 <= g; q += 4) {                               // groups before the wave's
+                const int a0 = grp_f[(q + 0) * nm_cap + k], a1 = grp_f[(q + 1) * nm_cap + k], a2 = grp_f[(q + 2) * nm_cap + k], a3 = grp_f[(q + 3) * nm_cap + k];
+                pre += (a0 + a1) + (a2 + a3);
+            }
+            for (; q < g; ++q) pre += grp_f[q * nm_cap + k];
+            for (int c = cg0; c < c0; ++c) pre += cnt_f[(size_t)c * nm_cap + k];         // wave-chunks before it inside its group (< PH_GRP)
+        }
+        const int inc = cm3d_wave_incl_scan(cnt);
+        if (k < nm) s_run[k] = carry + inc - cnt + pre;                // + the frame's base, below
+        carry += __builtin_amdgcn_readlane(inc, 63);
+    }
+    const int fbase = __builtin_amdgcn_readfirstlane(cm3d_wave_sum(fsum));
+    int dbase = __builtin_amdgcn_readfirstlane(cm3d_wave_sum(dsum));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int32_t *srow = ft + FT_SROW;
+    // Hit words (plane 0) of every wave-chunk of the span that holds a hit: all requested before the first is used.  The
+    // arrays below are only ever indexed at [0] / [1] and rotated, so they stay in registers without unrolling the loop.
+    uint32_t wq[CP_SPAN][PH_PT];
+    auto load_words = [&](int chunk, int plane, uint32_t (&w)[PH_PT]) {
+        const int cb = chunk * PH_WC, nvalid = min(PH_WC, n - cb);
         const uint32_t *hw = hit_words + (size_t)plane * n_points_total + p0 + cb + 4 * lane;
         if (nvalid >= PH_WC) {
             const u4u t = *reinterpret_cast<const u4u *>(hw);
             w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) w[j] = 4 * lane + j < nvalid ? hw[j] : 0u;
+            for (int jj = 0; jj < PH_PT; ++jj) w[jj] = 4 * lane + jj < nvalid ? hw[jj] : 0u;
         }
     };
-    uint32_t w0[PH_PT];
-    load_words(0, w0);
-    const int32_t *base_row = wc_base + ((size_t)f * nwc_max + chunk) * nm_cap;
-    const int run_first = lane < min(nm, 32) ? base_row[lane] : 0;
-    uint32_t rowany[PH_PT] = {w0[0], w0[1], w0[2], w0[3]};
-    for (int pl = 1; pl < planes; ++pl) {
-        uint32_t w[PH_PT];
-        load_words(pl, w);
 #pragma unroll
-        for (int j = 0; j < PH_PT; ++j) rowany[j] |= w[j];
+    for (int q = 0; q < CP_SPAN; ++q) {
+#pragma unroll
+        for (int jj = 0; jj < PH_PT; ++jj) wq[q][jj] = 0u;
+        if ((has >> q) & 1u) load_words(c0 + q, 0, wq[q]);
     }
-    if (!__ballot((rowany[0] | rowany[1] | rowany[2] | rowany[3]) != 0u)) return;        // no hit in this chunk
-    // rows the sweep preparation dropped (ego box): dropped rows before each of this lane's rows
-    int dropped[PH_PT] = {0, 0, 0, 0};
-    if (removed_bits) {
-        const int dbase = wc_drop[(size_t)f * nwc_max + chunk];
-        const uint32_t wv = lane < 8 ? removed_bits[(size_t)bits_off + 8 * chunk + lane] : 0u;
-        if (__ballot(wv != 0u) | (uint64_t)(dbase != 0)) {
-            int pc = __popc(wv), inc = pc;                       // lanes 0..7: inclusive prefix over the chunk's 8 words
+    // the coordinates of a wave-chunk's listed rows are requested one chunk ahead (under the ranks and stores of the chunk before)
+    float4 rc[PH_PT], rn[PH_PT];                                       // raw (or cloud) rows of the current / the next wave-chunk
+    uint32_t anyc[PH_PT], anyn[PH_PT];                                 // rows of the chunk that lie in any mask (all planes)
+    auto request_rows = [&](int chunk, const uint32_t (&w0)[PH_PT], float4 (&r)[PH_PT], uint32_t (&rowany)[PH_PT]) {
 #pragma unroll
-            for (int o = 1; o < 8; o <<= 1) { const int tt = __shfl_up(inc, o, 64); if (lane >= o) inc += tt; }
-            const int pre = __shfl(inc - pc, lane >> 3, 64);
-            const uint32_t myw = (uint32_t)__shfl((int)wv, lane >> 3, 64);
+        for (int jj = 0; jj < PH_PT; ++jj) { rowany[jj] = w0[jj]; r[jj] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int pl = 1; pl < planes; ++pl) {
+            uint32_t w[PH_PT];
+            load_words(chunk, pl, w);
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) dropped[j] = dbase + pre + __popc(myw & ((1u << (4 * (lane & 7) + j)) - 1u));
+            for (int jj = 0; jj < PH_PT; ++jj) rowany[jj] |= w[jj];
         }
-    }
-    // coordinates of this lane's rows that lie in any mask
-    float4 xyz[PH_PT];
+        if (!hit_xyz) return;
+        const size_t row0 = (size_t)p0 + (size_t)chunk * PH_WC + 4 * lane;
 #pragma unroll
-    for (int j = 0; j < PH_PT; ++j) xyz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (hit_xyz) {
-        if (xs.points) {
-#pragma unroll
-            for (int j = 0; j < PH_PT; ++j)
-                if (rowany[j]) xyz[j] = xs.points[(size_t)p0 + cb + 4 * lane + j];
-        } else {
-            const int32_t *srow = ft + FT_SROW;
-            int sw_lo = 0, sw_hi = 0;
-            if (ns > 1) { sw_lo = ph_sweep_of(srow, ns, cb); sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1); }
-            const bool uni = sw_lo >= sw_hi;
-            const float *xf_u = xs.sweep_xf + (size_t)(sa + sw_lo) * CM3D_SWEEP_XF_STRIDE;
-#pragma unroll
-            for (int j = 0; j < PH_PT; ++j) {
-                if (!rowany[j]) continue;
-                const int i = cb + 4 * lane + j;
-                const float *p = xs.raw + ((size_t)p0 + i) * xs.raw_stride;
-                const float x = p[0], y = p[1], z = p[2];
-                float bx, by, bz;
-                if (uni) ph_xform(xf_u, x, y, z, bx, by, bz);
-                else ph_xform(xs.sweep_xf + (size_t)(sa + ph_sweep_of(srow, ns, i)) * CM3D_SWEEP_XF_STRIDE, x, y, z, bx, by, bz);
-                xyz[j] = make_float4(bx, by, bz, p[3]);
+        for (int jj = 0; jj < PH_PT; ++jj) {
+            if (!rowany[jj]) continue;
+            if (xs.points) r[jj] = xs.points[row0 + jj];
+            else {
+                const float *p = xs.raw + (row0 + jj) * xs.raw_stride;
+                r[jj] = make_float4(p[0], p[1], p[2], p[3]);
             }
         }
-    }
-    for (int plane = 0; plane < planes; ++plane) {
-        uint32_t w[PH_PT];
-        if (plane == 0) {
+    };
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) w[j] = w0[j];
-        } else {
-            load_words(plane, w);
-        }
-        const uint32_t orw = cm3d_wave_or(w[0] | w[1] | w[2] | w[3]);
-        if (!orw) continue;
-        int run = 0;                         // lane b < 32: output offset of mask bit b for this chunk
-        if (lane < 32) {
-            const int k = plane * 32 + lane;
-            run = plane == 0 ? run_first : (k < nm ? base_row[k] : 0);
-        }
-        for (uint32_t r = orw; r; r &= r - 1) {
-            const int b = __builtin_ctz(r);
-            uint64_t mk[PH_PT];
-            int lower = 0;
+    for (int jj = 0; jj < PH_PT; ++jj) { rc[jj] = make_float4(0.f, 0.f, 0.f, 0.f); anyc[jj] = 0u; }
+    if (has & 1u) request_rows(c0, wq[0], rc, anyc);
+#pragma unroll 1
+    for (int j = 0; j < CP_SPAN; ++j) {
+        const int chunk = c0 + j;
+        if (chunk >= nwc) break;                                       // uniform
+        const bool next_has = j + 1 < CP_SPAN && ((has >> (j + 1)) & 1u);
+        if (next_has) request_rows(chunk + 1, wq[1], rn, anyn);
+        const int inf = __builtin_amdgcn_readlane(info, j);
+        const int cb = chunk * PH_WC;
+        const int nvalid = min(PH_WC, n - cb);
+        int dropc = inf & 0xFFFF;                                      // rows of this chunk the reference drops
+        uint32_t wv = 0u;                                              // lanes 0..7: the chunk's 8 words of removed-row bits
+        const bool want_bits = removed_bits && (fused ? (dropc != 0 && inf < 0) : true);
+        if (want_bits && lane < 8) wv = removed_bits[(size_t)bits_off + 8 * chunk + lane];
+        if (!fused) dropc = __builtin_amdgcn_readfirstlane(cm3d_wave_sum(__popc(wv)));
+        if (inf < 0) {
+            // dropped rows before each of this lane's rows
+            int dropped[PH_PT] = {dbase, dbase, dbase, dbase};
+            if (__ballot(wv != 0u)) {
+                int pc = __popc(wv), inc = pc;                       // lanes 0..7: inclusive prefix over the chunk's 8 words
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) { mk[j] = __ballot((w[j] >> b) & 1u); lower += cm3d_mbcnt(mk[j]); }
-            const int basepos = __builtin_amdgcn_readlane(run, b);
-            int own = 0;
+                for (int o = 1; o < 8; o <<= 1) { const int tt = __shfl_up(inc, o, 64); if (lane >= o) inc += tt; }
+                const int pre = __shfl(inc - pc, lane >> 3, 64);
+                const uint32_t myw = (uint32_t)__shfl((int)wv, lane >> 3, 64);
 #pragma unroll
-            for (int j = 0; j < PH_PT; ++j) {
-                if ((w[j] >> b) & 1u) {
-                    const int pos = basepos + lower + own;
-                    ++own;
-                    if (pos >= 0 && pos < idx_cap) {
-                        const int i = cb + 4 * lane + j;
-                        hit_idx[pos] = i - dropped[j];
-                        if (hit_row) hit_row[pos] = i;
-                        if (hit_xyz) hit_xyz[pos] = xyz[j];
-                    }
+                for (int jj = 0; jj < PH_PT; ++jj) dropped[jj] = dbase + pre + __popc(myw & ((1u << (4 * (lane & 7) + jj)) - 1u));
+            }
+            // coordinates of this lane's listed rows: the cloud's, or re-derived from the raw row
+            if (hit_xyz && !xs.points) {
+                int sw_lo = 0, sw_hi = 0;
+                if (ns > 1) { sw_lo = ph_sweep_of(srow, ns, cb); sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1); }
+                const bool uni = sw_lo >= sw_hi;
+                const float *xf_u = xs.sweep_xf + (size_t)(sa + sw_lo) * CM3D_SWEEP_XF_STRIDE;
+#pragma unroll
+                for (int jj = 0; jj < PH_PT; ++jj) {
+                    if (!anyc[jj]) continue;
+                    float bx, by, bz;
+                    if (uni) ph_xform(xf_u, rc[jj].x, rc[jj].y, rc[jj].z, bx, by, bz);
+                    else ph_xform(xs.sweep_xf + (size_t)(sa + ph_sweep_of(srow, ns, cb + 4 * lane + jj)) * CM3D_SWEEP_XF_STRIDE, rc[jj].x, rc[jj].y,
+                                  rc[jj].z, bx, by, bz);
+                    rc[jj] = make_float4(bx, by, bz, rc[jj].w);
                 }
             }
+            for (int plane = 0; plane < planes; ++plane) {
+                uint32_t w[PH_PT];
+                if (plane == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < PH_PT; ++jj) w[jj] = wq[0][jj];
+                } else {
+                    load_words(chunk, plane, w);
+                }
+                const uint32_t orw = cm3d_wave_or(w[0] | w[1] | w[2] | w[3]);
+                for (uint32_t r = orw; r; r &= r - 1) {
+                    const int b = __builtin_ctz(r);
+                    uint64_t mk[PH_PT];
+                    int lower = 0, total = 0;
+#pragma unroll
+                    for (int jj = 0; jj < PH_PT; ++jj) { mk[jj] = __ballot((w[jj] >> b) & 1u); lower += cm3d_mbcnt(mk[jj]); total += (int)__popcll(mk[jj]); }
+                    const int runpos = s_run[plane * 32 + b];       // (the same address in every lane: a broadcast)
+                    const int basepos = fbase + runpos;
+                    int own = 0;
+#pragma unroll
+                    for (int jj = 0; jj < PH_PT; ++jj) {
+                        if ((w[jj] >> b) & 1u) {
+                            const int pos = basepos + lower + own;
+                            ++own;
+                            if (pos >= 0 && pos < idx_cap) {
+                                const int i = cb + 4 * lane + jj;
+                                hit_idx[pos] = i - dropped[jj];
+                                if (hit_row) hit_row[pos] = i;
+                                if (hit_xyz) hit_xyz[pos] = rc[jj];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();                  // every lane has read s_run[..] before it moves on
+                    if (lane == 0) s_run[plane * 32 + b] = runpos + total;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        dbase += dropc;
+        // rotate: the next wave-chunk becomes the current one
+#pragma unroll
+        for (int q = 0; q + 1 < CP_SPAN; ++q) {
+#pragma unroll
+            for (int jj = 0; jj < PH_PT; ++jj) wq[q][jj] = wq[q + 1][jj];
+        }
+#pragma unroll
+        for (int jj = 0; jj < PH_PT; ++jj) { rc[jj] = rn[jj]; anyc[jj] = anyn[jj]; }
     }
 }
 
@@ -1410,7 +1433,8 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
 #define PH_LAUNCH(ONE, FUSED, STRIDE, KEEP)                                                                                      \
     hipLaunchKernelGGL((k_project_hits<ONE, FUSED, STRIDE, KEEP>), dim3(gx), dim3(PHK_THREADS), lds, st, src, stride, sw.sweep_xf,       \
                        sw.halfw, sw.points_out, sw.removed_bits, ws.ft, ws.ment, cams, n_cams, packed, W, H, Wp, min_dist, nm_cap, \
-                       nwc_max, n_points_total, hit_words, hit_count, ws.wc_cnt, n_frames, tpf, ws.queue)
+                       nwc_max, n_points_total, hit_words, hit_count, ws.wc_cnt, n_frames, tpf, ws.queue, ws.wc_info, ws.grp, ws.zstride,     \
+                       ws.frame_hits)
 #define PH_LAUNCH_S(ONE)                                                                                                         \
     do {                                                                                                                         \
         if (which == 0) PH_LAUNCH(ONE, false, 4, false);                                                                         \
@@ -1423,7 +1447,7 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
     } while (0)
     hipLaunchKernelGGL(k_frame_tables, dim3(n_frames), dim3(64), 0, st, sw, fused ? 1 : 0, pt_off, n_frames, cams, n_cams, mask_off, mask_cam,
                        (const int4 *)bbox, W, H, min_dist, nm_cap, max_pts_per_frame, (uint32_t)H * (uint32_t)Wp, ws.ft, ws.ment, ws.queue, tpf,
-                       status);
+                       ws.grp, ws.zstride, ws.frame_hits, status);
     CM3D_CHECK_LAUNCH();
     // optional timing events around the projection kernel itself (the table kernel above is not part of it)
     if (ev_start && hipEventRecord((hipEvent_t)ev_start, st) != hipSuccess) return CM3D_ERR_LAUNCH;
@@ -1487,16 +1511,21 @@ extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int3
     ph_ws_layout(n_frames, max_pts_per_frame, planes, workspace, &ws);
     const int nwc_max = (max_pts_per_frame + PH_WC - 1) / PH_WC;
     const int nm_cap = ph_nm_cap(planes);
-    hipLaunchKernelGGL(k_hit_offsets, dim3(n_frames), dim3(1024), 0, st, hit_count, n_masks, ws.ft, mask_off, n_frames, nm_cap, nwc_max,
-                       hit_off, tile_off, ws.wc_cnt, ws.wc_drop, removed_bits, idx_cap, status);
-    CM3D_CHECK_LAUNCH();
     const int64_t tile_cap64 = md_tile_cap(n_masks, idx_cap);
     const int tile_cap = (int)(tile_cap64 > 0x7FFFFFFF ? 0x7FFFFFFF : tile_cap64);
     PhXyzSrc xs;
     xs.raw = raw; xs.raw_stride = raw_stride; xs.sweep_xf = sweep_xf; xs.points = (const float4 *)points;
-    hipLaunchKernelGGL(k_compact_hits, dim3((nwc_max + PH_WAVES - 1) / PH_WAVES, n_frames + (tile_work ? 1 : 0)), dim3(PH_THREADS), 0, st,
-                       hit_words, n_points_total, ws.ft, nm_cap, nwc_max, ws.wc_cnt, ws.wc_drop, removed_bits, xs, hit_idx, hit_row,
-                       (float4 *)hit_xyz, idx_cap, n_frames, n_masks, hit_off, tile_off, tile_cap, (TileDesc *)tile_work);
+    static int span = 0;
+    if (!span) { const char *e = getenv("CM3D_CP_SPAN"); span = e ? atoi(e) : 4; if (span != 2 && span != 8) span = 4; }
+#define CP_LAUNCH(SPAN)                                                                                                          \
+    hipLaunchKernelGGL(k_compact_hits<SPAN>, dim3(((nwc_max + SPAN - 1) / SPAN + PH_WAVES - 1) / PH_WAVES, n_frames + 1),         \
+                       dim3(PH_THREADS), 0, st, hit_words, n_points_total, ws.ft, nm_cap, nwc_max, ws.wc_cnt, ws.wc_info, ws.grp,   \
+                       ws.zstride, ws.frame_hits, hit_count, removed_bits, xs, hit_idx, hit_row, (float4 *)hit_xyz, idx_cap,     \
+                       n_frames, n_masks, hit_off, tile_off, tile_cap, (TileDesc *)tile_work, status)
+    if (span == 8) CP_LAUNCH(8);
+    else if (span == 2) CP_LAUNCH(2);
+    else CP_LAUNCH(4);
+#undef CP_LAUNCH
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }

@@ -149,3 +149,128 @@ static __device__ __forceinline__ void md_build_worklist(int n_masks, const int3
         }
     }
 }
+
+
+// The same work list straight from the per-mask hit COUNTS (cm3d_compact_hits: the offsets do not exist yet when its launch
+// starts), together with what k_hit_offsets used to produce in a launch of its own: hit_off[m] = exclusive prefix of the
+// counts, tile_off[m] = exclusive prefix of the tile counts, their totals and the overflow flag.  `nparts` workgroups that
+// never talk to each other, each placing the masks of its own slots; every one of them reads ALL counts once (class totals,
+// and the sums of the slots before its own).  On an index-capacity overflow (status bit 1) no tile is listed at all
+// (tile_off = 0 everywhere): the host raises on that bit and nothing downstream may run off the end of a buffer.
+// s_i: MD_FROM_COUNTS_LDS(NT) ints of LDS, 8-byte aligned.  Contains workgroup barriers: call with all NT threads.
+#define MD_FROM_COUNTS_LDS(NT) (2 * MD_CLASSES + 2 * ((NT) / 64) + 8)
+template <int NT>
+static __device__ __forceinline__ void md_build_from_counts(int n_masks, const int32_t *__restrict__ hit_count, int idx_cap, int tile_cap,
+                                                            int32_t *__restrict__ hit_off, int32_t *__restrict__ tile_off,
+                                                            TileDesc *__restrict__ desc, int32_t *__restrict__ status, int *s_i,
+                                                            int part, int nparts)
+{
+    constexpr int NW = NT / 64;
+    int *s_hist = s_i, *s_cur = s_i + MD_CLASSES, *s_wc = s_i + 2 * MD_CLASSES, *s_wt = s_wc + NW, *s_tot = s_wt + NW;
+    unsigned long long *s_tot64 = reinterpret_cast<unsigned long long *>(s_tot + 4);      // (s_i is 8-byte aligned and the offset even)
+    const int lane = cm3d_lane(), wave = (int)threadIdx.x >> 6;
+    if (threadIdx.x < MD_CLASSES) { s_hist[threadIdx.x] = 0; s_cur[threadIdx.x] = 0; }
+    if (threadIdx.x < 8) s_tot[threadIdx.x] = 0;                     // 4 ints + 2 x 64 bits
+    __syncthreads();
+    const int nslots = (n_masks + NT - 1) / NT;
+    const int per_part = (nslots + nparts - 1) / nparts;
+    const int slot0 = min(nslots, part * per_part), slot1 = min(nslots, slot0 + per_part);      // this workgroup's slots
+    // pass 1: all counts once -- tiles per class (all masks / the masks before this workgroup's slots), hits and tiles before
+    // its slots, and the totals
+    int wrest = 0, wbefore = 0, wmine = 0;              // lane c: tiles of class c
+    long long cnt_before = 0, cnt_all = 0;
+    int nt_before = 0, nt_all = 0;
+    constexpr int PER = 4;
+    for (int g0 = 0; g0 < nslots; g0 += PER) {
+        int cv[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int m = (g0 + q) * NT + (int)threadIdx.x;
+            cv[q] = (g0 + q < nslots && m < n_masks) ? hit_count[m] : 0;                        // loads in flight together
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int g = g0 + q;
+            if (g >= nslots) continue;                   // uniform
+            const int nt = (cv[q] + CM3D_MEDOID_TILE - 1) / CM3D_MEDOID_TILE;
+            cnt_all += cv[q]; nt_all += nt;
+            if (g < slot0) { md_class_sums(nt, wbefore); cnt_before += cv[q]; nt_before += nt; }
+            else if (g < slot1) md_class_sums(nt, wmine);
+            else md_class_sums(nt, wrest);
+        }
+    }
+    if (lane < MD_CLASSES) {
+        const int all = wrest + wbefore + wmine;
+        if (all) atomicAdd(&s_hist[lane], all);
+        if (wbefore) atomicAdd(&s_cur[lane], wbefore);
+    }
+    {
+        // hit totals in 64 bits (a batch can hold more hits than its index buffer: that is the overflow this reports)
+        long long cb = cnt_before, ca = cnt_all;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { cb += __shfl_xor(cb, o, 64); ca += __shfl_xor(ca, o, 64); }
+        const int tb = cm3d_wave_sum(nt_before), ta = cm3d_wave_sum(nt_all);
+        if (lane == 0) {
+            atomicAdd(&s_tot64[0], (unsigned long long)cb); atomicAdd(&s_tot64[1], (unsigned long long)ca);
+            atomicAdd(&s_tot[2], tb); atomicAdd(&s_tot[3], ta);
+        }
+    }
+    __syncthreads();
+    const long long total64 = (long long)s_tot64[1];
+    const int base_cnt = (int)(s_tot64[0] > 0x7FFFFFFFull ? 0x7FFFFFFFull : s_tot64[0]);
+    const int total_cnt = (int)(total64 > 0x7FFFFFFFll ? 0x7FFFFFFFll : total64), base_nt = s_tot[2], total_nt = s_tot[3];
+    const bool overflow = total64 > (long long)idx_cap || total_nt > tile_cap || total_nt < 0;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = MD_CLASSES - 1; c >= 0; --c) { const int n = s_hist[c]; s_cur[c] += run; run += n; }     // longest lists first
+        if (part == 0) {
+            hit_off[n_masks] = total_cnt;
+            tile_off[n_masks] = overflow ? 0 : total_nt;
+            status[2] = total_cnt;
+            status[3] = total_nt;
+            if (overflow) atomicOr(&status[0], 2);
+        }
+    }
+    __syncthreads();
+    // pass 2 (own slots only): exact offsets by a block scan per slot; the wave reserves its share of every class with one
+    // atomic, positions inside it are ballot ranks
+    int vbase = 0;                                      // lane c: next free position of class c in this wave's share
+    if (lane < MD_CLASSES && wmine) vbase = atomicAdd(&s_cur[lane], wmine);
+    int carry_cnt = base_cnt, carry_nt = base_nt;
+    for (int g = slot0; g < slot1; ++g) {
+        const int m = g * NT + (int)threadIdx.x;
+        const int M = m < n_masks ? hit_count[m] : 0;
+        const int nt = (M + CM3D_MEDOID_TILE - 1) / CM3D_MEDOID_TILE;
+        const int ic = cm3d_wave_incl_scan(M), it = cm3d_wave_incl_scan(nt);
+        __syncthreads();                                 // the previous slot's readers are done
+        if (lane == 63) { s_wc[wave] = ic; s_wt[wave] = it; }
+        __syncthreads();
+        int wb_c = 0, wb_t = 0, tot_c = 0, tot_t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int a = s_wc[w], b = s_wt[w]; if (w < wave) { wb_c += a; wb_t += b; } tot_c += a; tot_t += b; }
+        const int off = carry_cnt + wb_c + ic - M, t0 = carry_nt + wb_t + it - nt;
+        carry_cnt += tot_c; carry_nt += tot_t;
+        if (m < n_masks) { hit_off[m] = off; tile_off[m] = overflow ? 0 : t0; }
+        const int ntl = (overflow || !desc) ? 0 : nt;   // tiles this lane lists
+        int pos = 0;
+#pragma unroll
+        for (int c = 0; c < MD_UNI; ++c) {
+            const uint64_t mk = __ballot(nt == c + 1);
+            if (!mk) continue;
+            if (nt == c + 1) pos = __builtin_amdgcn_readlane(vbase, c) + cm3d_mbcnt(mk) * (c + 1);
+            vbase += lane == c ? (int)__popcll(mk) * (c + 1) : 0;
+        }
+        if (__ballot(nt > MD_UNI)) {
+            const int cls = nt > MD_UNI ? md_class(nt) : -1;
+#pragma unroll
+            for (int c = MD_UNI; c < MD_CLASSES; ++c) {
+                if (!__ballot(cls == c)) continue;
+                const int v = cls == c ? nt : 0;
+                const int inc = cm3d_wave_incl_scan(v);
+                if (v) pos = __builtin_amdgcn_readlane(vbase, c) + inc - v;
+                vbase += lane == c ? __builtin_amdgcn_readlane(inc, 63) : 0;
+            }
+        }
+        for (int jt = 0; jt < ntl; ++jt) desc[pos + jt] = TileDesc{m, off, M, jt, t0 + jt};
+    }
+}

@@ -11,11 +11,17 @@ from cm3d_amd import lifting, synthetic as syn
 args = sys.argv[1:]
 for name, F in zip(args[0::2], args[1::2]):
     F = int(F)
-    cfg = syn.config(name)
-    frames = [syn.make_frame(cfg, i) for i in range(F)]
-    lanes = [syn.make_lane_table([600.0, 1600.0], 50000, seed=7, extent=260.0)]
-    hb = lifting.pack_frames(frames, lanes, [0] * F)
-    del frames
+    import pickle
+    cache = f"/tmp/cm3d_hb_{name}_{F}.pkl"          # the same batch for every variant of a sweep (generation takes longer than the passes)
+    if os.path.exists(cache):
+        hb = pickle.load(open(cache, "rb"))
+    else:
+        cfg = syn.config(name)
+        frames = [syn.make_frame(cfg, i) for i in range(F)]
+        lanes = [syn.make_lane_table([600.0, 1600.0], 50000, seed=7, extent=260.0)]
+        hb = lifting.pack_frames(frames, lanes, [0] * F)
+        del frames
+        pickle.dump(hb, open(cache, "wb"), protocol=4)
     eng = lifting.LiftEngine()
     eng.upload(hb)
     for _ in range(3):
