@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int32_t *srow = ft + FT_SROW;
     // Hit words (plane 0) of every wave-chunk of the span that holds a hit: all requested before the first is used.  The
-    // arrays below are only ever indexed at [0] / [1] and rotated, so they stay in registers without unrolling the loop.
+    // array is only ever indexed at [0] and rotated, so it stays in registers without unrolling the loop.
     uint32_t wq[CP_SPAN][PH_PT];
     auto load_words = [&](int chunk, int plane, uint32_t (&w)[PH_PT]) {
         const int cb = chunk * PH_WC, nvalid = min(PH_WC, n - cb);
@@ -1150,39 +1150,11 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *
         for (int jj = 0; jj < PH_PT; ++jj) wq[q][jj] = 0u;
         if ((has >> q) & 1u) load_words(c0 + q, 0, wq[q]);
     }
-    // the coordinates of a wave-chunk's listed rows are requested one chunk ahead (under the ranks and stores of the chunk before)
-    float4 rc[PH_PT], rn[PH_PT];                                       // raw (or cloud) rows of the current / the next wave-chunk
-    uint32_t anyc[PH_PT], anyn[PH_PT];                                 // rows of the chunk that lie in any mask (all planes)
-    auto request_rows = [&](int chunk, const uint32_t (&w0)[PH_PT], float4 (&r)[PH_PT], uint32_t (&rowany)[PH_PT]) {
-#pragma unroll
-        for (int jj = 0; jj < PH_PT; ++jj) { rowany[jj] = w0[jj]; r[jj] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        for (int pl = 1; pl < planes; ++pl) {
-            uint32_t w[PH_PT];
-            load_words(chunk, pl, w);
-#pragma unroll
-            for (int jj = 0; jj < PH_PT; ++jj) rowany[jj] |= w[jj];
-        }
-        if (!hit_xyz) return;
-        const size_t row0 = (size_t)p0 + (size_t)chunk * PH_WC + 4 * lane;
-#pragma unroll
-        for (int jj = 0; jj < PH_PT; ++jj) {
-            if (!rowany[jj]) continue;
-            if (xs.points) r[jj] = xs.points[row0 + jj];
-            else {
-                const float *p = xs.raw + (row0 + jj) * xs.raw_stride;
-                r[jj] = make_float4(p[0], p[1], p[2], p[3]);
-            }
-        }
-    };
-#pragma unroll
-    for (int jj = 0; jj < PH_PT; ++jj) { rc[jj] = make_float4(0.f, 0.f, 0.f, 0.f); anyc[jj] = 0u; }
-    if (has & 1u) request_rows(c0, wq[0], rc, anyc);
+    int2 *const tag_out = reinterpret_cast<int2 *>(hit_xyz);          // 16 bytes per position; the first 8 carry (row of the batch, sweep)
 #pragma unroll 1
     for (int j = 0; j < CP_SPAN; ++j) {
         const int chunk = c0 + j;
         if (chunk >= nwc) break;                                       // uniform
-        const bool next_has = j + 1 < CP_SPAN && ((has >> (j + 1)) & 1u);
-        if (next_has) request_rows(chunk + 1, wq[1], rn, anyn);
         const int inf = __builtin_amdgcn_readlane(info, j);
         const int cb = chunk * PH_WC;
         const int nvalid = min(PH_WC, n - cb);
@@ -1203,21 +1175,12 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *
 #pragma unroll
                 for (int jj = 0; jj < PH_PT; ++jj) dropped[jj] = dbase + pre + __popc(myw & ((1u << (4 * (lane & 7) + jj)) - 1u));
             }
-            // coordinates of this lane's listed rows: the cloud's, or re-derived from the raw row
-            if (hit_xyz && !xs.points) {
-                int sw_lo = 0, sw_hi = 0;
-                if (ns > 1) { sw_lo = ph_sweep_of(srow, ns, cb); sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1); }
-                const bool uni = sw_lo >= sw_hi;
-                const float *xf_u = xs.sweep_xf + (size_t)(sa + sw_lo) * CM3D_SWEEP_XF_STRIDE;
+            // sweep of each of this lane's rows (k_hit_xyz re-derives the coordinates of the listed rows from the raw rows)
+            int sweep[PH_PT] = {sa, sa, sa, sa};
+            if (ns > 1) {
+                const int sw_lo = ph_sweep_of(srow, ns, cb), sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1);
 #pragma unroll
-                for (int jj = 0; jj < PH_PT; ++jj) {
-                    if (!anyc[jj]) continue;
-                    float bx, by, bz;
-                    if (uni) ph_xform(xf_u, rc[jj].x, rc[jj].y, rc[jj].z, bx, by, bz);
-                    else ph_xform(xs.sweep_xf + (size_t)(sa + ph_sweep_of(srow, ns, cb + 4 * lane + jj)) * CM3D_SWEEP_XF_STRIDE, rc[jj].x, rc[jj].y,
-                                  rc[jj].z, bx, by, bz);
-                    rc[jj] = make_float4(bx, by, bz, rc[jj].w);
-                }
+                for (int jj = 0; jj < PH_PT; ++jj) sweep[jj] = sa + (sw_lo >= sw_hi ? sw_lo : ph_sweep_of(srow, ns, cb + 4 * lane + jj));
             }
             for (int plane = 0; plane < planes; ++plane) {
                 uint32_t w[PH_PT];
@@ -1246,7 +1209,7 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *
                                 const int i = cb + 4 * lane + jj;
                                 hit_idx[pos] = i - dropped[jj];
                                 if (hit_row) hit_row[pos] = i;
-                                if (hit_xyz) hit_xyz[pos] = rc[jj];
+                                if (hit_xyz) tag_out[2 * (size_t)pos] = make_int2(p0 + i, sweep[jj]);
                             }
                         }
                     }
@@ -1265,8 +1228,29 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *
 #pragma unroll
             for (int jj = 0; jj < PH_PT; ++jj) wq[q][jj] = wq[q + 1][jj];
         }
-#pragma unroll
-        for (int jj = 0; jj < PH_PT; ++jj) { rc[jj] = rn[jj]; anyc[jj] = anyn[jj]; }
+    }
+}
+
+// Coordinates of the listed points: one thread per output position.  k_compact_hits left (row of the batch, sweep) in the
+// first 8 bytes of the position's 16; here the row is fetched (from the cloud when there is one, else the raw row, which is
+// put through the projection kernel's very fma chains: same bits as the cloud would hold) and the position overwritten with
+// x, y, z, intensity.  Every thread is independent: tens of thousands of gathers in flight, where the compaction's waves
+// would each have waited for their own.
+__global__ __launch_bounds__(256) void k_hit_xyz(const PhXyzSrc xs, const int32_t *__restrict__ hit_off, int n_masks, int idx_cap,
+                                                 float4 *__restrict__ hit_xyz)
+{
+    const int total = min(hit_off[n_masks], idx_cap);
+    for (int pos = (int)(blockIdx.x * blockDim.x + threadIdx.x); pos < total; pos += (int)(gridDim.x * blockDim.x)) {
+        const int2 tag = reinterpret_cast<const int2 *>(hit_xyz)[2 * (size_t)pos];
+        float4 out;
+        if (xs.points) out = xs.points[tag.x];
+        else {
+            const float *p = xs.raw + (size_t)tag.x * xs.raw_stride;
+            float bx, by, bz;
+            ph_xform(xs.sweep_xf + (size_t)tag.y * CM3D_SWEEP_XF_STRIDE, p[0], p[1], p[2], bx, by, bz);
+            out = make_float4(bx, by, bz, p[3]);
+        }
+        hit_xyz[pos] = out;
     }
 }
 
@@ -1526,6 +1510,13 @@ extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int3
     else if (span == 2) CP_LAUNCH(2);
     else CP_LAUNCH(4);
 #undef CP_LAUNCH
+    CM3D_CHECK_LAUNCH();
+    if (hit_xyz) {
+        // (the number of listed points is only known on the device: a fixed grid strides over them)
+        int64_t blocks = ((int64_t)idx_cap + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_hit_xyz, dim3((unsigned)blocks), dim3(256), 0, st, xs, hit_off, n_masks, idx_cap, (float4 *)hit_xyz);
+    }
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
 }
