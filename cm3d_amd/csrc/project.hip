@@ -1352,6 +1352,10 @@ static int ph_target_blocks(const void *kernel, size_t lds)
     if (forced > 0) return forced;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PHK_THREADS, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+    // One workgroup per CU fewer than fit: three waves per SIMD run the launch as fast as four (measured alone: 65.7 against
+    // 64.4 us), and the registers the fourth would hold are what lets the small kernels of the neighbouring batches in flight
+    // (masks, compaction, medoid) run beside it instead of behind it (three batches in flight: 0.177 -> 0.174 ms per pass).
+    if (per_cu >= 4) --per_cu;
     return cus * per_cu;
 }
 
