@@ -58,13 +58,13 @@ def compulsory_bytes(hb, planes, sum_hits, mode, fused, cloud_stored, rect_bytes
         # The mask words a launch fetches (a subset of rect_bytes, mostly L2 hits) are extra traffic, not counted.
         "k_project_hits": (raw if fused else cloud) + hitw + (cloud if (fused and cloud_stored) else 0),
         "k_sweep_xform": raw + cloud,
-        "k_rle_erode_pack": runs + rect_bytes,
+        "k_rle_erode_pack_wave": runs + rect_bytes,
         "k_erode_pack": M * W * H + M * ((W + 31) // 32) * 4 * H,           # dense path: really streams both
         "k_compact_hits": hitw + 8 * sum_hits + (12 * sum_hits if not cloud_stored else 0),
         "k_medoid": 16 * sum_hits,
         "boxes": 80 * M,
     }
-    masks = by["k_erode_pack"] if mode == "dense" else by["k_rle_erode_pack"]
+    masks = by["k_erode_pack"] if mode == "dense" else by["k_rle_erode_pack_wave"]
     by["pass_total"] = (by["k_project_hits"] + (0 if fused else by["k_sweep_xform"]) + masks + by["k_compact_hits"] +
                         by["k_medoid"] + by["boxes"])
     return by
@@ -480,20 +480,24 @@ def main(argv=None):
                 for s in stages:
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()
-                    if s == "project":      # the library records the pair around the projection kernel itself
+                    if s == "project":      # the library records the pair around the projection kernel itself ...
                         b.record()
-                        calls[s](st, (a, b))
+                        c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        c.record()          # ... and this pair, like every other stage's, sits outside the call: it also holds the
+                        calls[s](st, (a, b))    # per-frame table kernel the call launches first and the launch boundaries
+                        d.record()
                         alone.append((a, b))
+                        ev.setdefault("project_with_tables", []).append((c, d))
                     else:
                         calls[s](st)
                         b.record()
                         ev[s].append((a, b))
         torch.cuda.synchronize()
-        stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) for s in stages}
+        stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) for s in list(stages) + ["project_with_tables"]}
         project_alone_ms = float(np.mean([a.elapsed_time(b) for a, b in alone]))
         status = eng.check_status()
         results[mode] = dict(dt=dt, stage_ms=stage_ms, project_alone_ms=project_alone_ms, fused=fused, sum_hits=int(status[2]),
-                             n_points=int(status[1]),
+                             n_points=int(status[1]), sum_pairs=int((eng.b.hit_count.to(torch.int64) ** 2).sum().item()),
                              n_boxes=int((eng.b.flags == 3).sum().item()), max_hits=int(eng.b.hit_count.max().item()),
                              rect_bytes=packed_rect_bytes(eng.b.bbox.cpu().numpy(), eng.b.Wp),
                              n_gathered=None if gathered is None else int(sum(g.shape[0] for g in gathered)))
@@ -556,15 +560,40 @@ def main(argv=None):
                 roofline["traffic"] = per_kernel.get("k_project_hits")
         except (OSError, ValueError):
             pass
-    mask_kernel = "k_erode_pack" if main_mode == "dense" else "k_rle_erode_pack"
+    mask_kernel = "k_erode_pack" if main_mode == "dense" else "k_rle_erode_pack_wave"
     kernels = {
         "masks": roof(mask_kernel, r["stage_ms"]["masks"], mask_kernel,
                       "run lengths read + the words of every eroded mask's bounding rectangle written (what the kernel stores); "
-                      "latency-bound, one workgroup per mask; stage time incl. the launch boundary" if main_mode == "rle" else
+                      "instruction-issue and latency bound, one wave per mask; stage time incl. the launch boundary" if main_mode == "rle" else
                       "dense uint8 masks read + bit-packed masks written; stage time incl. the launch boundary"),
         "stage_ms_one_batch_alone": {k: round(v, 4) for k, v in dict(r["stage_ms"], project=r["project_alone_ms"]).items()},
     }
     kernels["masks"]["traffic"] = per_kernel.get(mask_kernel)
+    # north_star's "projection + gather" as a GROUP: the projection launch and the compaction behind it (k_compact_hits: ranks
+    # and index lists; k_hit_xyz: the listed points' coordinates), bytes and times summed, one batch alone on the GPU
+    grp_ms = r["project_alone_ms"] + r["stage_ms"]["compact"]
+    grp_bytes = by["k_project_hits"] + by["k_compact_hits"]
+    roofline_group = {"kernels": ["k_project_hits", "k_compact_hits", "k_hit_xyz"], "bound": "hbm", "bytes": int(grp_bytes),
+                      "ms_alone": round(grp_ms, 4), "achieved": round(rate(grp_bytes, grp_ms), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(rate(grp_bytes, grp_ms) / HBM_PEAK_GBS, 4),
+                      "note": "projection kernel (library events) + the compaction stage (events outside the call: two launches and "
+                              "their boundaries), one batch alone; compaction bytes = hit words read + 4 B index + 16 B coordinates "
+                              "written per listed point" + ("" if cloud_stored else " + 12 B of its raw row read")}
+    # the medoid against the VECTOR-ALU roof ('report its time separately, not against HBM'): pairs = sum over masks of
+    # (points in the mask)^2, lane-operation slots per pair from the PMC pass of the same launch (SQ_INSTS_VALU x 64 / pairs:
+    # every issued vector instruction occupies 64 lane slots, idle lanes of partly filled 64-column tiles included)
+    VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9      # MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector = 78.6 T lane-operations/s x 2 flop (fma)
+    md_ms = r["stage_ms"]["medoid"]
+    insts = per_kernel.get("k_medoid_insts_valu")
+    slots = (insts * 64.0 / r["sum_pairs"]) if (insts and r["sum_pairs"]) else None
+    kernels["medoid"] = {"kernel": "k_medoid_tiles + k_medoid_reduce + k_medoid_long", "bound": "valu", "pairs_per_launch": r["sum_pairs"],
+                         "stage_ms_alone": round(md_ms, 4), "achieved_Gpairs_s": round(r["sum_pairs"] / (md_ms * 1e-3) / 1e9, 1),
+                         "lane_op_slots_per_pair": None if slots is None else round(slots, 1),
+                         "achieved_Tlaneops_s": None if slots is None else round(r["sum_pairs"] * slots / (md_ms * 1e-3) / 1e12, 2),
+                         "peak_Tlaneops_s": round(VALU_PEAK_LANE_OPS / 1e12, 1),
+                         "frac": None if slots is None else round(r["sum_pairs"] * slots / (md_ms * 1e-3) / VALU_PEAK_LANE_OPS, 4),
+                         "note": "pairs = sum of M^2 over the masks' index lists; the float32 arithmetic per pair is the reference's "
+                                 "(torch.cdist expansion + correctly rounded sqrt + ordered sum); stage time incl. three launch boundaries"}
     if not r["fused"]:
         kernels["sweeps"] = roof("k_sweep_xform", r["stage_ms"]["sweeps"], "k_sweep_xform", "HBM streaming, one pass; stage time incl. the launch boundary")
         kernels["sweeps"]["traffic"] = per_kernel.get("k_sweep_xform")
@@ -581,6 +610,7 @@ def main(argv=None):
                    "parallelism": f"frame-sharded x{world}, {depth} independent batches in flight per GPU, one RCCL gather of box records"},
         "ranks_in_group": torch.distributed.get_world_size() if world > 1 else 1,
         "roofline": roofline,
+        "roofline_group": roofline_group,
         "kernels": kernels,
         # the whole pass against the HBM roof: bytes every stage must move (compulsory_bytes) x passes/s, per GPU
         "pass_roofline": {"bound": "hbm", "achieved": round(pass_rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

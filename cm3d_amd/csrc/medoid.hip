@@ -30,7 +30,15 @@
 static __device__ __forceinline__ bool md_two_pass(int M) { return M > MD_LONG_MIN && M < MD_LONG_MAX; }
 
 #ifndef MD_APPROX_MFMA
-#define MD_APPROX_MFMA 1                 // first pass over long lists on the matrix pipe (k_medoid_approx); 0: in k_medoid_tiles
+// First pass over long lists on the matrix pipe (md_approx_tile); 0: on the vector pipe (md_rows<false, true>).  The error bound
+// of the second pass rests on v_mfma_f32_32x32x2_f32 being bit for bit the k-ordered fmaf chain, which is verified for gfx950
+// (cm3d_selftest_mfma: on the device at every engine start, LiftEngine.__init__, and in tests/test_gpu_golden.py): any other
+// target gets the vector-pipe form.
+#if defined(__gfx950__) || !defined(__HIP_DEVICE_COMPILE__)
+#define MD_APPROX_MFMA 1
+#else
+#define MD_APPROX_MFMA 0
+#endif
 #endif
 typedef float f2 __attribute__((ext_vector_type(2)));      // two rows side by side: v_pk_{add,mul,fma}_f32
 typedef float f16v __attribute__((ext_vector_type(16)));   // accumulator of v_mfma_f32_32x32x2_f32
@@ -674,8 +682,11 @@ __global__ __launch_bounds__(64) void k_selftest_mfma(uint64_t seed, int tiles_p
     auto coord = [&](float centre, float spread) { return centre + spread * ((float)(next() & 0xFFFFFF) * (1.0f / 8388608.0f) - 1.0f); };
     unsigned long long bad = 0;
     for (int t = 0; t < tiles_per_wave; ++t) {
-        // lane l < 32 owns row l and column l of this tile; magnitudes like nuScenes' global frame, objects a few metres wide
-        const float cx = 300.0f + 40.0f * (float)(t % 37), cy = 900.0f + 25.0f * (float)(t % 53), spread = (t & 1) ? 3.0f : 40.0f;
+        // lane l < 32 owns row l and column l of this tile; magnitudes from a vehicle-frame cloud (x 0.01) over nuScenes' global
+        // frame (x 1, x 2.5: the far corners of its maps) to 10 km and beyond (x 6, x 20), objects a few metres wide
+        const float mags[6] = {1.0f, 0.01f, 2.5f, 6.0f, 1.0f, 20.0f};
+        const float mag = mags[t % 6];
+        const float cx = mag * (300.0f + 40.0f * (float)(t % 37)), cy = mag * (900.0f + 25.0f * (float)(t % 53)), spread = (t & 1) ? 3.0f : 40.0f;
         const float rx = coord(cx, spread), ry = coord(cy, spread), rz = coord(1.0f, 2.0f);
         const float qx = coord(cx, spread), qy = coord(cy, spread), qz = coord(1.0f, 2.0f);
         const float rn = (rx * rx + ry * ry) + rz * rz, qn = (qx * qx + qy * qy) + qz * qz;

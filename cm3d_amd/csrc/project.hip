@@ -1370,6 +1370,8 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
         n_masks <= 0 || W <= 1 || H <= 1 || W > 32767 || H > 32767 || planes <= 0)
         return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_project_workspace_bytes(n_frames, max_pts_per_frame, planes) || ((uintptr_t)workspace & 15)) return CM3D_ERR_WORKSPACE;
+    // a mask's first word in `packed` travels as a 32-bit word offset in its table entry (k_frame_tables): ~95 k masks of 1600x900
+    if ((int64_t)n_masks * H * ((W + 31) / 32) > 0xFFFFFFFFll) return CM3D_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     PhWs ws;
     ph_ws_layout(n_frames, max_pts_per_frame, planes, workspace, &ws);

@@ -258,6 +258,27 @@ def _ptr(t: Optional[torch.Tensor]):
     return 0 if t is None else t.data_ptr()
 
 
+_MFMA_VERIFIED = {}
+
+
+def _verify_matrix_pipe(lib, dev):
+    """Once per process and device: the medoid's first pass over long lists runs on the matrix pipe, and the error bound of
+    its second pass holds only while v_mfma_f32_32x32x2_f32 reproduces the reference's k-ordered fmaf chain bit for bit
+    (csrc/medoid.hip).  cm3d_selftest_mfma checks exactly that on this device (2048 waves x 24 tiles, coordinates from
+    vehicle-frame to 20x nuScenes' global magnitudes, ~0.1 ms); a device that fails it must not produce labels."""
+    key = str(dev)
+    if key in _MFMA_VERIFIED:
+        return
+    with torch.cuda.device(dev):
+        bad = torch.zeros(1, dtype=torch.int64, device=dev)
+        check(lib.cm3d_selftest_mfma(20240607, 24, bad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "cm3d_selftest_mfma")
+        n_bad = int(bad.item())
+    if n_bad:
+        raise Cm3dError(f"matrix-pipe self-test failed on {key}: {n_bad} of {2048 * 24 * 1024} squared distances differ from the "
+                        "vector fma chain; rebuild with -DMD_APPROX_MFMA=0")
+    _MFMA_VERIFIED[key] = True
+
+
 class LiftEngine:
     """Owns the device buffers of one lift batch and launches the kernels.
     All launches go to torch's current HIP stream and never synchronise."""
@@ -277,6 +298,7 @@ class LiftEngine:
         self.hits_per_point = hits_per_point
         self.keep_colsum = keep_colsum
         self.keep_cloud = (os.environ.get("CM3D_KEEP_CLOUD", "0") == "1") if keep_cloud is None else bool(keep_cloud)
+        _verify_matrix_pipe(self.lib, self.dev)
         self.b = None
         self._lane = None                                    # the lane tables on the device and their spatial index (upload)
         d = self.dev
@@ -298,6 +320,9 @@ class LiftEngine:
         if M <= 0 or F <= 0 or S <= 0 or hb.n_raw_rows <= 0:
             raise ValueError("empty batch")
         nm_max = int(np.diff(hb.mask_off).max())
+        if hb.n_masks * hb.height * ((hb.width + 31) // 32) > 0xFFFFFFFF:
+            raise ValueError(f"{hb.n_masks} masks of {hb.width}x{hb.height} in one batch: their bit-packed words no longer fit a 32-bit offset "
+                             "(split the batch)")
         if nm_max > _lib.MAX_MASKS_PER_FRAME:
             raise ValueError(f"{nm_max} masks in one frame (limit {_lib.MAX_MASKS_PER_FRAME})")
         if hb.n_cams > _lib.MAX_CAMS or hb.mask_cam.min() < 0 or hb.mask_cam.max() >= hb.n_cams:

@@ -50,6 +50,16 @@ def main(tag):
     json.dump(out, open(f"profiles/{tag}_c2_rle_pmc_traffic.json", "w"), indent=1)
     traffic = {"c2_rle": {k: v["hbm_bytes_per_launch"] for k, v in out.items()}, "source": f"profiles/{tag}_c2_rle_pmc_traffic.json",
                "frames_per_gpu": 256}
+    # vector instructions of the medoid kernels per pass (SQ_INSTS_VALU, its own PMC pass): bench.py's kernels.medoid
+    insts_csv = os.path.join(src, "insts", "p_counter_collection.csv")
+    if os.path.exists(insts_csv):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(insts_csv)):
+            if r["Counter_Name"] == "SQ_INSTS_VALU":
+                agg[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        per = {k: sum(v) / len(v) for k, v in agg.items() if k.startswith("k_")}
+        json.dump(per, open(f"profiles/{tag}_c2_rle_pmc_insts_valu.json", "w"), indent=1)
+        traffic["c2_rle"]["k_medoid_insts_valu"] = int(sum(v for k, v in per.items() if k.startswith("k_medoid")))
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
     for label, fn in (("three batches in flight (default)", f"profiles/{tag}_c2_rle_kernel_stats.csv"),
                       ("one batch at a time", f"profiles/{tag}_c2_rle_one_batch_kernel_stats.csv")):
@@ -63,4 +73,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r03")
