@@ -467,10 +467,13 @@ def main(argv=None):
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        per_rank_dt = [dt]
         if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-            dt = float(tmax.item())
+            mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(every, mine)
+            per_rank_dt = [float(t.item()) for t in every]
+            dt = max(per_rank_dt)                        # the job's time is its slowest rank's
         # per-stage breakdown: a separate, untimed pass over ONE batch alone, with events around every stage
         alone = []
         with torch.cuda.stream(pipe.streams[0]):
@@ -496,7 +499,7 @@ def main(argv=None):
         stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) for s in list(stages) + ["project_with_tables"]}
         project_alone_ms = float(np.mean([a.elapsed_time(b) for a, b in alone]))
         status = eng.check_status()
-        results[mode] = dict(dt=dt, stage_ms=stage_ms, project_alone_ms=project_alone_ms, fused=fused, sum_hits=int(status[2]),
+        results[mode] = dict(dt=dt, per_rank_dt=per_rank_dt, stage_ms=stage_ms, project_alone_ms=project_alone_ms, fused=fused, sum_hits=int(status[2]),
                              n_points=int(status[1]), sum_pairs=int((eng.b.hit_count.to(torch.int64) ** 2).sum().item()),
                              n_boxes=int((eng.b.flags == 3).sum().item()), max_hits=int(eng.b.hit_count.max().item()),
                              rect_bytes=packed_rect_bytes(eng.b.bbox.cpu().numpy(), eng.b.Wp),
@@ -609,6 +612,7 @@ def main(argv=None):
                    "batches_in_flight": depth, "cloud_materialised": cloud_stored,
                    "parallelism": f"frame-sharded x{world}, {depth} independent batches in flight per GPU, one RCCL gather of box records"},
         "ranks_in_group": torch.distributed.get_world_size() if world > 1 else 1,
+        "per_rank_ms_per_step": [round(t / args.steps * 1e3, 4) for t in r["per_rank_dt"]],
         "roofline": roofline,
         "roofline_group": roofline_group,
         "kernels": kernels,

@@ -26,6 +26,18 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["ranks_in_group"] == 2 and d["gather_ok"] is True and d["backend"] == "gloo"
 
 
+def test_bench_launches_eight_ranks_for_the_drivers_scaling_run():
+    """The command line the driver uses at N = 8 (`python bench.py --gpus 8 ...`), rehearsed on the CPU: eight ranks come up over
+    gloo, rendezvous on 127.0.0.1, exchange their records once, rank 0 prints the line."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--rehearse-launch"], cwd=ROOT, env=_env(OMP_NUM_THREADS="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_in_group"] == 8 and d["gather_ok"] is True
+
+
 def test_bench_refuses_wrong_world_size():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--rehearse-launch"], cwd=ROOT,
                        env=_env(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
@@ -46,7 +58,7 @@ def test_byte_accounting_counts_only_bytes_that_move():
     assert by["k_project_hits"] == 70000 * (20 + 4)                       # raw rows in, hit words out, no cloud, no phantom masks
     assert bench.compulsory_bytes(HB, 1, 5000, "rle", True, True, 1000)["k_project_hits"] == 70000 * (20 + 4 + 16)
     assert bench.compulsory_bytes(HB, 1, 5000, "rle", False, True, 1000)["k_project_hits"] == 70000 * (16 + 4)
-    assert by["k_rle_erode_pack"] == 4000 + 1000
+    assert by["k_rle_erode_pack_wave"] == 4000 + 1000
     full_masks = 2 * 50 * 4 * 900
     assert by["pass_total"] < full_masks + by["k_project_hits"] + 200000     # nothing near a full read of the packed masks
     assert bench.visible_cores() >= 1

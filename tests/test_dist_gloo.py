@@ -61,3 +61,73 @@ def test_single_process_passthrough():
     t = torch.zeros(3, 10, dtype=torch.float64)
     out = cdist.gather_records(t)
     assert len(out) == 1 and out[0] is t
+
+
+def _c3_scene_sizes():
+    """850 scenes, 28 130 key frames (nuScenes trainval, BASELINE config C3): about 28..40 frames per scene, seeded."""
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(28, 39, 850)
+    while sizes.sum() != 28130:                      # spread the remainder over the scenes
+        i = int(rng.integers(0, 850))
+        sizes[i] += 1 if sizes.sum() < 28130 else -1
+    assert sizes.min() > 20 and sizes.sum() == 28130
+    return sizes.tolist()
+
+
+def _worker_c3(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    from cm3d_amd import dist as cdist
+    r, w, _ = cdist.init_from_env(backend="gloo")
+    sizes = _c3_scene_sizes()
+    first = np.concatenate([[0], np.cumsum(sizes)])
+    s0, s1 = cdist.shard_scenes(sizes, w)[r]
+    # the records a rank ships: one row of 10 doubles per kept box, (global frame number, rank) in the identity columns
+    # (lifting.kept_box_records); 0..3 boxes per frame, so some frames ship nothing at all
+    frames = np.arange(first[s0], first[s1])
+    per = frames % 4
+    rows = np.repeat(frames, per)
+    rec = torch.zeros(rows.size, 10, dtype=torch.float64)
+    rec[:, 5] = torch.from_numpy(rows.astype(np.float64))
+    rec[:, 6] = float(r)
+    rec[:, 9] = 3.0
+    out = cdist.gather_records(rec, dst=0)
+    if r == 0:
+        q.put([(o[:, 5].numpy().astype(np.int64), o[:, 6].numpy().astype(np.int64), float(o[:, 9].min()) if o.shape[0] else 3.0) for o in out])
+    else:
+        assert out is None
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gather_records_eight_ranks_c3_shape():
+    """BASELINE C3 at the real rank count, on the CPU: 28 130 frames of 850 scenes, scene-aligned blocks over 8 ranks
+    (dist.shard_scenes), every rank's kept-box records through the ONE exchange; rank 0 sees every frame's records once, in
+    frame order, from the rank that owns the frame's scene, and no padding row."""
+    from cm3d_amd import dist as cdist
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c3, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    assert len(got) == world
+    sizes = _c3_scene_sizes()
+    first = np.concatenate([[0], np.cumsum(sizes)])
+    bounds = cdist.shard_scenes(sizes, world)
+    frames = np.concatenate([g[0] for g in got])
+    exp = np.repeat(np.arange(28130), np.arange(28130) % 4)
+    assert np.array_equal(frames, exp)                                   # global frame order, nothing lost, nothing doubled
+    for r, (fr, rk, flag) in enumerate(got):
+        assert np.all(rk == r) and flag == 3.0                           # each block from its own rank; no zero padding row
+        a, b = first[bounds[r][0]], first[bounds[r][1]]
+        assert fr.size == 0 or (fr.min() >= a and fr.max() < b)          # scene-aligned: only frames of the rank's own scenes
+    per_rank = [int(first[b] - first[a]) for a, b in bounds]
+    assert max(per_rank) - min(per_rank) <= 2 * 40                       # balanced to within a scene at either end
