@@ -2,8 +2,12 @@
 src/waymo/ (2d_to_3d.py:394-1306), with the per-frame work on the GPU.
 
 Inputs: the reference's mask files `<INPUT_DIR>/<scene>/<f>_masks.pkl|_data.json` plus, per frame, the
-quantities the reference pulls out of the TFRecord with waymo_open_dataset / TensorFlow (third-party,
-not in this image): `<FRAMES_DIR>/<scene>/<f>_frame.npz` with
+quantities the reference pulls out of the TFRecord with waymo_open_dataset / TensorFlow (third-party).  Two routes to them,
+giving the same kernel inputs (tests/test_host_logic.py holds them against each other with a stand-in devkit):
+  * `--tfrecords DIR` (default: the reference's INPUT_PATH) where the devkit is installed: the entry point reads the
+    TFRecords itself, scene = file name, exactly like the reference (src/waymo/2d_to_3d.py:424-479) --
+    cm3d_amd.waymo.frame_records_from_tfrecord;
+  * otherwise `<FRAMES_DIR>/<scene>/<f>_frame.npz` (tools/extract_waymo_frames.py writes them with that same function) with
     points (N,3) float32   TOP-lidar first returns in the vehicle frame   (:472-479)
     extrinsics (5,16), intrinsics (5,9)   camera calibrations in camera-name order 1..5 (:513-518)
     pose (16,), timestamp_micros, context_name
@@ -25,29 +29,36 @@ from . import dist as cdist
 from . import lifting
 from . import waymo as wm
 
-INPUT_DIR = "../../mask_outputs/waymo-detic/"            # reference module constants (src/waymo/2d_to_3d.py)
+INPUT_PATH = "../../data/waymo-v1.4.2/waymo_format/training/"      # reference module constants (src/waymo/2d_to_3d.py:47,64-65)
+INPUT_DIR = "../../mask_outputs/waymo-detic/"
 FRAMES_DIR = "../../data/waymo_extracted/"
 OUTPUT_PATH = "../../outputs/waymo/pred_detic.bin"
 
 
-def load_scene(frames_dir, mask_dir, scene):
-    """-> (frames, lane_table) of one scene; frames without mask files are skipped like :450-455."""
+def _npz_records(frames_dir, scene):
     files = sorted(glob.glob(os.path.join(frames_dir, scene, "*_frame.npz")), key=lambda p: int(os.path.basename(p).split("_")[0]))
-    frames, lane_table = [], None
     for path in files:
-        fnum = int(os.path.basename(path).split("_")[0])
-        z = np.load(path, allow_pickle=False)
-        if fnum == 0 or lane_table is None and "lanes" in z:
-            if "lanes" in z:
-                off = z["lane_off"]
+        yield int(os.path.basename(path).split("_")[0]), np.load(path, allow_pickle=False)
+
+
+def load_scene(frames_dir, mask_dir, scene, tfrecord=None):
+    """-> (frames, lane_table) of one scene; frames without mask files are skipped like :450-455.
+    tfrecord: path of the scene's TFRecord -> read through the devkit (cm3d_amd.waymo.frame_records_from_tfrecord);
+    None -> the extracted `<frames_dir>/<scene>/<f>_frame.npz` files."""
+    def has_masks(fnum):
+        return os.path.exists(os.path.join(mask_dir, scene, f"{fnum}_masks.pkl")) and os.path.exists(os.path.join(mask_dir, scene, f"{fnum}_data.json"))
+    records = wm.frame_records_from_tfrecord(tfrecord, has_masks) if tfrecord else _npz_records(frames_dir, scene)
+    frames, lane_table = [], None
+    for fnum, z in records:
+        if lane_table is None and "lanes" in z:
+            off = z["lane_off"]
+            if len(off) > 1:
                 lane_table = np.vstack([wm.get_yaws_from_lane_coords(z["lanes"][off[i]:off[i + 1]]) for i in range(len(off) - 1)])
-        mp = os.path.join(mask_dir, scene, f"{fnum}_masks.pkl")
-        dp = os.path.join(mask_dir, scene, f"{fnum}_data.json")
-        if not (os.path.exists(mp) and os.path.exists(dp)):
+        if not has_masks(fnum):
             continue
-        with open(mp, "rb") as f:
+        with open(os.path.join(mask_dir, scene, f"{fnum}_masks.pkl"), "rb") as f:
             rles = pickle.load(f)
-        with open(dp) as f:
+        with open(os.path.join(mask_dir, scene, f"{fnum}_data.json")) as f:
             data = json.load(f)
         if not rles:
             continue
@@ -78,16 +89,16 @@ def lift_scene(eng, frames, lane_table, classes, masks="rle", scene_index=0):
     return recs
 
 
-def objects_from_records(rec, scenes, frames_dir, classes):
+def objects_from_records(rec, scenes, frames_dir, classes, meta=None):
     """Gathered records -> encoded metrics_pb2.Object payloads in the reference's order (scenes in order, frames in
     order, kept boxes in mask order; src/waymo/2d_to_3d.py:1034-1065,1262-1297).  The frame's context name and timestamp
     (:1050-1051) come from its extracted-frame file; the records only carry (scene index, frame number)."""
     rec = np.asarray(rec, np.float64).reshape(-1, 10)
     order = np.lexsort((np.arange(len(rec)), rec[:, lifting.REC_FRAME_B], rec[:, lifting.REC_FRAME_A]))     # stable inside a frame
-    meta, out = {}, []
+    meta, out = dict(meta or {}), []           # (scene index, frame number) -> (context name, timestamp): what this rank saw ...
     for r in rec[order]:
         key = (int(r[lifting.REC_FRAME_A]), int(r[lifting.REC_FRAME_B]))
-        if key not in meta:
+        if key not in meta:                    # ... and, for the frames of other ranks, the frame's extracted file
             z = np.load(os.path.join(frames_dir, scenes[key[0]], f"{key[1]}_frame.npz"), allow_pickle=False)
             meta[key] = (str(z["context_name"]), int(z["timestamp_micros"]))
         ctx, ts = meta[key]
@@ -101,6 +112,9 @@ def objects_from_records(rec, scenes, frames_dir, classes):
 def main(argv=None):
     ap = argparse.ArgumentParser(description="CM3D 2D->3D lifting (Waymo), MI355X path")
     ap.add_argument("--frames-dir", default=os.environ.get("CM3D_WAYMO_FRAMES", FRAMES_DIR))
+    ap.add_argument("--tfrecords", default=os.environ.get("CM3D_WAYMO_TFRECORDS", INPUT_PATH),
+                    help="directory of Waymo TFRecords (read through waymo_open_dataset when it is installed and the directory exists; "
+                         "otherwise the extracted <f>_frame.npz files of --frames-dir are used)")
     ap.add_argument("--mask-dir", default=os.environ.get("CM3D_INPUT_DIR", INPUT_DIR))
     ap.add_argument("--output", default=os.environ.get("CM3D_OUTPUT_PATH", OUTPUT_PATH))
     ap.add_argument("--scenes", default=os.environ.get("CM3D_SCENES", ""))
@@ -111,14 +125,18 @@ def main(argv=None):
     rank, world, local_rank = cdist.init_from_env()
     if os.environ.get("CM3D_SINGLE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box (with CM3D_DIST_BACKEND=gloo)
         local_rank = 0
-    scenes = [s for s in args.scenes.split(",") if s] or sorted(os.listdir(args.frames_dir))
+    use_tf = os.path.isdir(args.tfrecords) and wm.devkit_available()
+    # scene = TFRecord file name, like the reference (:424-436); with extracted frames: the directory name
+    scenes = [s for s in args.scenes.split(",") if s] or sorted(os.listdir(args.tfrecords if use_tf else args.frames_dir))
     pri = json.load(open(args.priors)) if os.path.exists(args.priors) else None
     classes = lifting.ClassTable.waymo(pri)
     eng = lifting.LiftEngine(f"cuda:{local_rank}", classes=classes)
     lo, hi = cdist.shard_range(len(scenes), rank, world)
-    mine = []
+    mine, meta = [], {}
     for si in range(lo, hi):
-        frames, lanes = load_scene(args.frames_dir, args.mask_dir, scenes[si])
+        frames, lanes = load_scene(args.frames_dir, args.mask_dir, scenes[si], os.path.join(args.tfrecords, scenes[si]) if use_tf else None)
+        for f in frames:
+            meta[(si, int(f.token.rsplit(":", 1)[1]))] = (f.context_name, f.timestamp_micros)
         if frames:
             if lanes is None:
                 raise FileNotFoundError(f"{scenes[si]}: no lane polylines (frame 0)")
@@ -131,7 +149,12 @@ def main(argv=None):
         torch.distributed.destroy_process_group()
     if rank != 0:
         return 0
-    mine = objects_from_records(torch.cat([g.cpu() for g in gathered], 0).numpy(), scenes, args.frames_dir, classes)
+    if use_tf and world > 1:
+        # the records carry (scene, frame) only; context name and timestamp of the other ranks' frames come from their TFRecords
+        for si in [i for i in range(len(scenes)) if not (lo <= i < hi)]:
+            for fnum, z in wm.frame_records_from_tfrecord(os.path.join(args.tfrecords, scenes[si]), lambda k: False):
+                meta[(si, fnum)] = (str(z["context_name"]), int(z["timestamp_micros"]))
+    mine = objects_from_records(torch.cat([g.cpu() for g in gathered], 0).numpy(), scenes, args.frames_dir, classes, meta)
     os.makedirs(os.path.dirname(os.path.abspath(args.output)), exist_ok=True)
     with open(args.output, "wb") as f:
         f.write(wm.encode_objects(mine))

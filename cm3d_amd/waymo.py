@@ -89,6 +89,52 @@ def frame_from_extracted(token, points_xyz, cams, rles, labels, scores, cam_nums
                            context_name=context_name)
 
 
+# ---------------------------------------------------------------- TFRecord route (third-party devkit, when installed)
+def devkit_available():
+    """waymo_open_dataset + TensorFlow importable?  (Neither is part of this repository's image; where they are installed the
+    Waymo entry point reads the TFRecords itself, like the reference.)"""
+    try:
+        import tensorflow.compat.v1  # noqa: F401
+        from waymo_open_dataset import dataset_pb2  # noqa: F401
+        from waymo_open_dataset.utils import frame_utils  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
+def frame_records_from_tfrecord(path, frame_filter=None):
+    """Yields (frame_num, record) for the frames of one Waymo TFRecord -- exactly the extraction steps of the reference's
+    src/waymo/2d_to_3d.py:444-446 (Frame proto), :472-479 (TOP-lidar first returns through the devkit's range-image
+    conversion), :513-518 (camera calibrations by name), :459-468 (lane polylines, frame 0 only) and nothing else.  A record
+    holds what `<f>_frame.npz` holds (tools/extract_waymo_frames.py writes these very dicts to disk):
+        points (N,3) f32, extrinsics (5,16), intrinsics (5,9), pose (16,), timestamp_micros, context_name [, lanes, lane_off]
+    frame_filter(frame_num) -> False: the frame is still yielded (calibrations, pose, timestamp) but with an empty cloud -- the
+    expensive range-image conversion of a frame nobody lifts (no mask files) is skipped."""
+    import tensorflow.compat.v1 as tf
+    from waymo_open_dataset import dataset_pb2
+    from waymo_open_dataset.utils import frame_utils
+    tf.enable_eager_execution()
+    for fnum, data in enumerate(tf.data.TFRecordDataset(path, compression_type="")):
+        frame = dataset_pb2.Frame()
+        frame.ParseFromString(bytearray(data.numpy()))
+        rec = {}
+        if fnum == 0:
+            polys = [np.array([[p.x, p.y, p.z] for p in f.lane.polyline]) for f in frame.map_features if f.HasField("lane")]
+            rec["lanes"] = np.vstack(polys) if polys else np.zeros((0, 3))
+            rec["lane_off"] = np.concatenate([[0], np.cumsum([len(p) for p in polys])]).astype(np.int64)
+        if frame_filter is None or frame_filter(fnum):
+            ri, cp, _, top_pose = frame_utils.parse_range_image_and_camera_projection(frame)
+            pts, _ = frame_utils.convert_range_image_to_point_cloud(frame, ri, cp, top_pose, 0, False)
+            rec["points"] = np.asarray(pts[0], np.float32)
+        else:
+            rec["points"] = np.zeros((0, 3), np.float32)
+        cals = sorted(frame.context.camera_calibrations, key=lambda c: c.name)
+        rec.update(extrinsics=np.array([list(c.extrinsic.transform) for c in cals]), intrinsics=np.array([list(c.intrinsic) for c in cals]),
+                   pose=np.array(frame.pose.transform), timestamp_micros=np.int64(frame.timestamp_micros),
+                   context_name=np.str_(frame.context.name))
+        yield fnum, rec
+
+
 # ---------------------------------------------------------------- metrics_pb2.Objects writer
 def _varint(n):
     n &= (1 << 64) - 1

@@ -401,3 +401,105 @@ def test_crafted_boundary_rows_fall_on_both_sides(oracle, mag):
             sel = slice(base + kind * N_EACH, base + (kind + 1) * N_EACH)
             inside = (in_rect if kind in (4, 5, 6, 7, 9) else in_img)[sel]
             assert 3 <= int(inside.sum()) <= N_EACH - 3, (mag, c, kind, int(inside.sum()))
+
+
+def _stub_waymo_devkit(monkeypatch):
+    """Stand-ins for `tensorflow.compat.v1` and `waymo_open_dataset` with the handful of members the extraction touches
+    (src/waymo/2d_to_3d.py:436-479 of the reference): a 'TFRecord' is a pickled list of per-frame dicts, `Frame.ParseFromString`
+    turns one back into an object tree shaped like dataset_pb2.Frame, and the range-image conversion hands back the cloud the
+    dict carries.  Third-party behaviour is not under test here -- the plumbing around it is."""
+    import pickle
+    import sys
+    import types
+    from types import SimpleNamespace as NS
+
+    class _Item:
+        def __init__(self, b): self.b = b
+        def numpy(self): return self.b
+
+    tf = types.ModuleType("tensorflow.compat.v1")
+    tf.enable_eager_execution = lambda: None
+    tf.data = NS(TFRecordDataset=lambda path, compression_type="": [_Item(pickle.dumps(d)) for d in pickle.load(open(path, "rb"))])
+
+    class Frame:
+        def ParseFromString(self, b):
+            d = pickle.loads(bytes(b))
+            self._points = d["points"]
+            self.timestamp_micros = d["timestamp_micros"]
+            self.pose = NS(transform=list(d["pose"]))
+            cal = [NS(name=c + 1, extrinsic=NS(transform=list(d["extrinsics"][c])), intrinsic=list(d["intrinsics"][c])) for c in range(len(d["extrinsics"]))]
+            self.context = NS(name=d["context_name"], camera_calibrations=cal[::-1])        # (the proto does not promise name order)
+            feats = []
+            for poly in d.get("lane_polylines", []):
+                feats.append(NS(HasField=lambda k: k == "lane", lane=NS(polyline=[NS(x=p[0], y=p[1], z=p[2]) for p in poly])))
+            feats.append(NS(HasField=lambda k: False, lane=None))                            # a map feature that is not a lane
+            self.map_features = feats
+
+    fu = types.ModuleType("waymo_open_dataset.utils.frame_utils")
+    fu.parse_range_image_and_camera_projection = lambda frame: ("ri", "cp", None, "pose")
+    fu.convert_range_image_to_point_cloud = lambda frame, ri, cp, pose, idx, keep: ([frame._points], None)
+    mods = {"tensorflow": types.ModuleType("tensorflow"), "tensorflow.compat": types.ModuleType("tensorflow.compat"), "tensorflow.compat.v1": tf,
+            "waymo_open_dataset": types.ModuleType("waymo_open_dataset"), "waymo_open_dataset.dataset_pb2": types.ModuleType("waymo_open_dataset.dataset_pb2"),
+            "waymo_open_dataset.utils": types.ModuleType("waymo_open_dataset.utils"), "waymo_open_dataset.utils.frame_utils": fu}
+    mods["tensorflow"].compat = mods["tensorflow.compat"]; mods["tensorflow.compat"].v1 = tf
+    mods["waymo_open_dataset.dataset_pb2"].Frame = Frame
+    mods["waymo_open_dataset"].dataset_pb2 = mods["waymo_open_dataset.dataset_pb2"]
+    mods["waymo_open_dataset"].utils = mods["waymo_open_dataset.utils"]; mods["waymo_open_dataset.utils"].frame_utils = fu
+    for k, v in mods.items():
+        monkeypatch.setitem(sys.modules, k, v)
+
+
+def test_waymo_tfrecord_route_equals_extracted_frame_route(tmp_path, monkeypatch):
+    """The Waymo entry point reads the TFRecords itself where the devkit is installed (like the reference, :436-479), and the
+    extracted `<f>_frame.npz` files otherwise; tools/extract_waymo_frames.py writes those files with the same function.  With a
+    stand-in devkit: both routes give the same frames, lane table and packed batch, frames without mask files are skipped
+    without converting their range images, and the scene is named after the TFRecord file as in the reference."""
+    import pickle
+    from cm3d_amd import geometry as geo, lifting, pipeline_waymo as pw, waymo as wm
+    _stub_waymo_devkit(monkeypatch)
+    assert wm.devkit_available()
+    cfg = syn.config("tiny", n_cams=5)
+    scene = "segment-123_with_camera_labels.tfrecord"
+    os.makedirs(tmp_path / "tf"); os.makedirs(tmp_path / "masks" / scene)
+    S = np.array([[0, -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float64)
+    dicts = []
+    for i in range(4):
+        fr, base = syn.make_waymo_frame(cfg, 20 + i), syn.make_frame(cfg, 20 + i)
+        P = np.asarray(fr.pose).reshape(4, 4)
+        ext, intr = [], []
+        for c in range(base.cams.shape[0]):
+            t_cs_neg, R_csT, _ = geo.cam_stage(base.cams[c], 1)
+            T = np.eye(4); T[:3, :3] = R_csT.T; T[:3, 3] = -t_cs_neg
+            K = geo.cam_K(base.cams[c]) / cfg.ratio
+            ext.append((T @ S).reshape(16)); intr.append([K[0, 0], K[1, 1], K[0, 2], K[1, 2], 0, 0, 0, 0, 0])
+        d = dict(points=fr.sweeps_raw[0][:, :3].copy(), extrinsics=np.array(ext), intrinsics=np.array(intr), pose=P.reshape(16),
+                 timestamp_micros=int(fr.timestamp_micros), context_name=fr.context_name)
+        if i == 0:
+            d["lane_polylines"] = [np.cumsum(np.concatenate([[[P[0, 3] - 100 + 30 * k, P[1, 3] - 100, 0.0]], np.tile([[0.0, 0.5, 0.0]], (300, 1))]), 0) for k in range(6)]
+        dicts.append(d)
+        if i != 2:                                   # frame 2 has no detections: the producer wrote no files for it
+            pickle.dump(fr.rles, open(tmp_path / "masks" / scene / f"{i}_masks.pkl", "wb"))
+            json.dump({"labels": fr.labels, "detection_scores": fr.scores, "cam_nums": fr.cam_nums}, open(tmp_path / "masks" / scene / f"{i}_data.json", "w"))
+    pickle.dump(dicts, open(tmp_path / "tf" / scene, "wb"))
+    # route 1: straight from the TFRecord
+    converted = []
+    from waymo_open_dataset.utils import frame_utils
+    orig = frame_utils.convert_range_image_to_point_cloud
+    monkeypatch.setattr(frame_utils, "convert_range_image_to_point_cloud", lambda fr_, *a: (converted.append(fr_.timestamp_micros), orig(fr_, *a))[1])
+    f1, lanes1 = pw.load_scene(None, str(tmp_path / "masks"), scene, tfrecord=str(tmp_path / "tf" / scene))
+    assert len(f1) == 3 and len(converted) == 3      # frame 2 was never converted
+    # route 2: extractor -> npz -> entry point
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import extract_waymo_frames
+    extract_waymo_frames.main(str(tmp_path / "tf" / scene), str(tmp_path / "frames"), scene=scene)
+    f2, lanes2 = pw.load_scene(str(tmp_path / "frames"), str(tmp_path / "masks"), scene)
+    assert [f.token for f in f1] == [f.token for f in f2] == [f"{scene}:{i}" for i in (0, 1, 3)]
+    assert np.array_equal(lanes1, lanes2) and lanes1.shape == (6 * 301, 3)
+    classes = lifting.ClassTable.waymo()
+    a, b = lifting.pack_frames(f1, [lanes1], [0] * 3, classes), lifting.pack_frames(f2, [lanes2], [0] * 3, classes)
+    for k in ("raw", "sweep_row_off", "sweep_xf", "frame_sweep_off", "cams", "mask_off", "mask_cam", "rle_counts", "rle_off", "class_id", "score",
+              "lane", "lane_off", "pose_rt", "pose_inv"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    assert [(f.context_name, f.timestamp_micros) for f in f1] == [(f.context_name, f.timestamp_micros) for f in f2]
+    assert a.cams.shape[1] == 5 and not a.ego_box
