@@ -469,3 +469,663 @@ extern "C" int cm3d_reader_load_masks(cm3d_reader *r, const char *const *paths, 
         return CM3D_RD_ERR_FORMAT;
     }
 }
+
+// =====================================================================================================================
+// nuScenes tables + frame manifests + result writer: the rest of the reference's host-side frame loop in native code.
+//   reference (src/nuscenes/2d_to_3d.py): NuScenes(VER_NAME, INPUT_PATH) :382 (the tables), the per-frame table walk :415-441 and
+//   :489-503 (sweep chain with its calibrated_sensor / ego_pose rows, the six cameras' records), json.load of <f>_data.json :423,
+//   and json.dump of the result dict :929-930.  cm3d_amd/nusc_io.py + lifting.nuscenes_results_json are the Python forms of
+//   the same steps; tests/test_reader.py holds the two against each other array for array and byte for byte.
+// All arithmetic on the records is IEEE double in the operation order of cm3d_amd/geometry.py (this file is compiled
+// with -ffp-contract=off), so the float32 records are bit-identical to the Python path's.
+#include <charconv>
+#include <cmath>
+#include <memory>
+#include <string_view>
+#include <unordered_map>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- a small JSON reader
+struct JP {
+    const char *p, *e;
+    bool ok = true;
+    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+    bool eat(char c) { ws(); if (p < e && *p == c) { ++p; return true; } return false; }
+    std::string str()                                           // a JSON string, escapes decoded (UTF-8 out)
+    {
+        std::string out;
+        ws();
+        if (p >= e || *p != '"') { ok = false; return out; }
+        ++p;
+        while (p < e && *p != '"') {
+            char c = *p++;
+            if (c != '\\') { out.push_back(c); continue; }
+            if (p >= e) { ok = false; return out; }
+            c = *p++;
+            switch (c) {
+            case 'n': out.push_back('\n'); break; case 't': out.push_back('\t'); break; case 'r': out.push_back('\r'); break;
+            case 'b': out.push_back('\b'); break; case 'f': out.push_back('\f'); break;
+            case 'u': {
+                if (e - p < 4) { ok = false; return out; }
+                unsigned v = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const char h = p[k];
+                    const int d = (h >= '0' && h <= '9') ? h - '0' : ((h | 32) >= 'a' && (h | 32) <= 'f') ? (h | 32) - 'a' + 10 : -1;
+                    if (d < 0) { ok = false; return out; }
+                    v = v * 16 + (unsigned)d;
+                }
+                p += 4;
+                if (v < 0x80) out.push_back((char)v);
+                else if (v < 0x800) { out.push_back((char)(0xC0 | (v >> 6))); out.push_back((char)(0x80 | (v & 0x3F))); }
+                else { out.push_back((char)(0xE0 | (v >> 12))); out.push_back((char)(0x80 | ((v >> 6) & 0x3F))); out.push_back((char)(0x80 | (v & 0x3F))); }
+                break;
+            }
+            default: out.push_back(c); break;                   // \" \\ \/
+            }
+        }
+        if (p >= e) { ok = false; return out; }
+        ++p;
+        return out;
+    }
+    double num()
+    {
+        ws();
+        // strtod needs a terminated buffer: the table files are read with a trailing NUL (read_text)
+        char *end = nullptr;
+        const double v = strtod(p, &end);                      // correctly rounded, like Python's float(): the same double
+        if (end == p || end > e) { ok = false; return 0.0; }
+        p = end;
+        return v;
+    }
+    bool boolean()
+    {
+        ws();
+        if (e - p >= 4 && !memcmp(p, "true", 4)) { p += 4; return true; }
+        if (e - p >= 5 && !memcmp(p, "false", 5)) { p += 5; return false; }
+        ok = false;
+        return false;
+    }
+    void skip()
+    {
+        ws();
+        if (p >= e) { ok = false; return; }
+        if (*p == '"') { (void)str(); return; }
+        if (*p == '{' || *p == '[') {
+            int depth = 0;
+            while (p < e) {
+                if (*p == '"') { (void)str(); if (!ok) return; continue; }
+                if (*p == '{' || *p == '[') ++depth;
+                else if ((*p == '}' || *p == ']') && --depth == 0) { ++p; return; }
+                ++p;
+            }
+            ok = false;
+            return;
+        }
+        while (p < e && *p != ',' && *p != '}' && *p != ']') ++p;   // number / true / false / null
+    }
+    int numbers(double *out, int cap)                         // a flat array of numbers; returns the count (-1: malformed / too many)
+    {
+        if (!eat('[')) { ok = false; return -1; }
+        int n = 0;
+        if (eat(']')) return 0;
+        for (;;) {
+            if (n >= cap) { ok = false; return -1; }
+            out[n++] = num();
+            if (!ok) return -1;
+            if (eat(',')) continue;
+            if (eat(']')) return n;
+            ok = false;
+            return -1;
+        }
+    }
+};
+
+bool read_text(const char *path, std::vector<uint8_t> &buf)
+{
+    if (!read_file(path, buf)) return false;
+    buf.push_back(0);                                          // strtod's sentinel
+    return true;
+}
+
+// walks `[ {..}, {..}, ... ]`: begin() per object, field(j, key) per key (must consume the value)
+template <typename Begin, typename Field>
+bool walk_table(const std::vector<uint8_t> &buf, Begin begin, Field field)
+{
+    JP j{(const char *)buf.data(), (const char *)buf.data() + buf.size() - 1};
+    if (!j.eat('[')) return false;
+    if (j.eat(']')) return true;
+    for (;;) {
+        if (!j.eat('{')) return false;
+        begin();
+        if (!j.eat('}')) {
+            for (;;) {
+                const std::string key = j.str();
+                if (!j.ok || !j.eat(':')) return false;
+                field(j, key);
+                if (!j.ok) return false;
+                if (j.eat(',')) continue;
+                if (j.eat('}')) break;
+                return false;
+            }
+        }
+        if (j.eat(',')) continue;
+        return j.eat(']');
+    }
+}
+
+struct PoseRow { std::string token; double t[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0}; };
+struct CsRow { std::string token, sensor_tok; double t[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0}, K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; bool has_k = false; int channel = -1; };
+struct SdRow { std::string token, sample_tok, pose_tok, cs_tok, next_tok, filename; bool key = false; int sample = -1, pose = -1, cs = -1, next = -1; };
+struct SampleRow { std::string token, next_tok, scene_tok; int next = -1; int data[7] = {-1, -1, -1, -1, -1, -1, -1}; };   // [0] LIDAR_TOP, [1..6] CAM_LIST
+struct SceneRow { std::string token, name, log_tok, first_tok; int first = -1, log = -1, nbr = 0; };
+struct NameRow { std::string token, value; };
+
+const char *const kChannels[7] = {"LIDAR_TOP", "CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_BACK_RIGHT", "CAM_BACK", "CAM_BACK_LEFT", "CAM_FRONT_LEFT"};
+
+// unit quaternion (w, x, y, z) -> row-major 3x3: the arithmetic of geometry.quat_to_rotmat, operation for operation
+void quat_to_rotmat(const double *qin, double *R)
+{
+    double w = qin[0], x = qin[1], y = qin[2], z = qin[3];
+    const double nrm = std::sqrt(w * w + x * x + y * y + z * z);
+    w = w / nrm; x = x / nrm; y = y / nrm; z = z / nrm;
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+}   // namespace
+
+struct cm3d_tables {
+    std::string dataroot, version;
+    std::vector<SceneRow> scenes;
+    std::vector<SampleRow> samples;
+    std::vector<SdRow> sds;
+    std::vector<PoseRow> poses;
+    std::vector<CsRow> css;
+    std::vector<NameRow> sensors, logs;
+    std::unordered_map<std::string, int> scene_by_name;
+};
+
+extern "C" cm3d_tables *cm3d_tables_open(cm3d_reader *r, const char *dataroot, const char *version, int32_t *err)
+{
+    auto fail = [&](int code) { if (err) *err = code; return (cm3d_tables *)nullptr; };
+    if (err) *err = CM3D_RD_OK;
+    if (!r || !dataroot || !version) return fail(CM3D_RD_ERR_ARG);
+    try {
+        std::unique_ptr<cm3d_tables> t(new cm3d_tables);
+        t->dataroot = dataroot; t->version = version;
+        const std::string base = t->dataroot + "/" + t->version + "/";
+        int rc[7] = {0, 0, 0, 0, 0, 0, 0};
+        // the seven tables are parsed side by side (sample_data is by far the longest), token references resolved afterwards
+        r->pool.run(7, [&](int which) {
+            try {
+                std::vector<uint8_t> buf;
+                static const char *const names[7] = {"scene", "sample", "sample_data", "ego_pose", "calibrated_sensor", "sensor", "log"};
+                if (!read_text((base + names[which] + ".json").c_str(), buf)) { rc[which] = CM3D_RD_ERR_IO; return; }
+                bool ok = false;
+                switch (which) {
+                case 0: ok = walk_table(buf, [&] { t->scenes.emplace_back(); }, [&](JP &j, const std::string &k) {
+                        SceneRow &s = t->scenes.back();
+                        if (k == "token") s.token = j.str(); else if (k == "name") s.name = j.str(); else if (k == "log_token") s.log_tok = j.str();
+                        else if (k == "first_sample_token") s.first_tok = j.str(); else if (k == "nbr_samples") s.nbr = (int)j.num(); else j.skip();
+                    }); break;
+                case 1: ok = walk_table(buf, [&] { t->samples.emplace_back(); }, [&](JP &j, const std::string &k) {
+                        SampleRow &s = t->samples.back();
+                        if (k == "token") s.token = j.str(); else if (k == "next") s.next_tok = j.str(); else if (k == "scene_token") s.scene_tok = j.str(); else j.skip();
+                    }); break;
+                case 2: ok = walk_table(buf, [&] { t->sds.emplace_back(); }, [&](JP &j, const std::string &k) {
+                        SdRow &s = t->sds.back();
+                        if (k == "token") s.token = j.str(); else if (k == "sample_token") s.sample_tok = j.str(); else if (k == "ego_pose_token") s.pose_tok = j.str();
+                        else if (k == "calibrated_sensor_token") s.cs_tok = j.str(); else if (k == "filename") s.filename = j.str();
+                        else if (k == "next") s.next_tok = j.str(); else if (k == "is_key_frame") s.key = j.boolean(); else j.skip();
+                    }); break;
+                case 3: ok = walk_table(buf, [&] { t->poses.emplace_back(); }, [&](JP &j, const std::string &k) {
+                        PoseRow &s = t->poses.back();
+                        if (k == "token") s.token = j.str();
+                        else if (k == "translation") { if (j.numbers(s.t, 3) != 3) j.ok = false; }
+                        else if (k == "rotation") { if (j.numbers(s.q, 4) != 4) j.ok = false; }
+                        else j.skip();
+                    }); break;
+                case 4: ok = walk_table(buf, [&] { t->css.emplace_back(); }, [&](JP &j, const std::string &k) {
+                        CsRow &s = t->css.back();
+                        if (k == "token") s.token = j.str(); else if (k == "sensor_token") s.sensor_tok = j.str();
+                        else if (k == "translation") { if (j.numbers(s.t, 3) != 3) j.ok = false; }
+                        else if (k == "rotation") { if (j.numbers(s.q, 4) != 4) j.ok = false; }
+                        else if (k == "camera_intrinsic") {                      // [] for a lidar, three rows of three for a camera
+                            if (!j.eat('[')) { j.ok = false; return; }
+                            if (j.eat(']')) return;
+                            for (int row = 0; row < 3; ++row) {
+                                if (j.numbers(s.K + 3 * row, 3) != 3) { j.ok = false; return; }
+                                if (row < 2 && !j.eat(',')) { j.ok = false; return; }
+                            }
+                            if (!j.eat(']')) { j.ok = false; return; }
+                            s.has_k = true;
+                        }
+                        else j.skip();
+                    }); break;
+                case 5: ok = walk_table(buf, [&] { t->sensors.emplace_back(); }, [&](JP &j, const std::string &k) {
+                        if (k == "token") t->sensors.back().token = j.str(); else if (k == "channel") t->sensors.back().value = j.str(); else j.skip();
+                    }); break;
+                default: ok = walk_table(buf, [&] { t->logs.emplace_back(); }, [&](JP &j, const std::string &k) {
+                        if (k == "token") t->logs.back().token = j.str(); else if (k == "location") t->logs.back().value = j.str(); else j.skip();
+                    }); break;
+                }
+                if (!ok) rc[which] = CM3D_RD_ERR_FORMAT;
+            } catch (...) {
+                rc[which] = CM3D_RD_ERR_FORMAT;
+            }
+        });
+        for (int k = 0; k < 7; ++k) if (rc[k] != CM3D_RD_OK) return fail(rc[k]);
+        // token -> row
+        std::unordered_map<std::string, int> sample_ix, sd_ix, pose_ix, cs_ix, sensor_ix, log_ix;
+        auto index = [](auto &rows, std::unordered_map<std::string, int> &ix) { ix.reserve(rows.size() * 2); for (size_t i = 0; i < rows.size(); ++i) ix.emplace(rows[i].token, (int)i); };
+        index(t->samples, sample_ix); index(t->sds, sd_ix); index(t->poses, pose_ix); index(t->css, cs_ix); index(t->sensors, sensor_ix); index(t->logs, log_ix);
+        auto find = [](const std::unordered_map<std::string, int> &ix, const std::string &tok) { auto it = ix.find(tok); return it == ix.end() ? -1 : it->second; };
+        for (auto &c : t->css) {
+            const int s = find(sensor_ix, c.sensor_tok);
+            if (s < 0) return fail(CM3D_RD_ERR_FORMAT);
+            for (int ch = 0; ch < 7; ++ch) if (t->sensors[s].value == kChannels[ch]) c.channel = ch;
+        }
+        for (auto &s : t->samples) s.next = s.next_tok.empty() ? -1 : find(sample_ix, s.next_tok);
+        for (size_t i = 0; i < t->sds.size(); ++i) {
+            SdRow &d = t->sds[i];
+            d.sample = find(sample_ix, d.sample_tok); d.pose = find(pose_ix, d.pose_tok); d.cs = find(cs_ix, d.cs_tok);
+            d.next = d.next_tok.empty() ? -1 : find(sd_ix, d.next_tok);
+            if (d.sample < 0 || d.pose < 0 || d.cs < 0) return fail(CM3D_RD_ERR_FORMAT);
+            // sample['data'][channel] like the devkit builds it: key frames only (a later row of the same channel wins, like a dict)
+            if (d.key && t->css[d.cs].channel >= 0) t->samples[d.sample].data[t->css[d.cs].channel] = (int)i;
+        }
+        for (size_t i = 0; i < t->scenes.size(); ++i) {
+            SceneRow &s = t->scenes[i];
+            s.first = find(sample_ix, s.first_tok); s.log = find(log_ix, s.log_tok);
+            if (s.first < 0 || s.log < 0) return fail(CM3D_RD_ERR_FORMAT);
+            t->scene_by_name.emplace(s.name, (int)i);
+        }
+        return t.release();
+    } catch (...) {
+        return fail(CM3D_RD_ERR_FORMAT);
+    }
+}
+
+extern "C" void cm3d_tables_close(cm3d_tables *t) { delete t; }
+
+extern "C" int32_t cm3d_tables_scene_samples(const cm3d_tables *t, const char *scene_name)
+{
+    if (!t || !scene_name) return CM3D_RD_ERR_ARG;
+    auto it = t->scene_by_name.find(scene_name);
+    if (it == t->scene_by_name.end()) return CM3D_RD_ERR_ARG;
+    int n = 0;
+    for (int s = t->scenes[it->second].first; s >= 0; s = t->samples[s].next) ++n;
+    return n;
+}
+
+extern "C" int32_t cm3d_tables_scene_location(const cm3d_tables *t, const char *scene_name, char *out, int32_t cap)
+{
+    if (!t || !scene_name || !out || cap <= 0) return CM3D_RD_ERR_ARG;
+    auto it = t->scene_by_name.find(scene_name);
+    if (it == t->scene_by_name.end()) return CM3D_RD_ERR_ARG;
+    const std::string &loc = t->logs[t->scenes[it->second].log].value;
+    if ((int32_t)loc.size() + 1 > cap) return CM3D_RD_ERR_CAPACITY;
+    memcpy(out, loc.c_str(), loc.size() + 1);
+    return (int32_t)loc.size();
+}
+
+// all scene names, NUL-separated, in table order; returns the bytes needed
+extern "C" int64_t cm3d_tables_scene_names(const cm3d_tables *t, char *out, int64_t cap)
+{
+    if (!t) return CM3D_RD_ERR_ARG;
+    int64_t need = 0;
+    for (const auto &s : t->scenes) need += (int64_t)s.name.size() + 1;
+    if (out && cap >= need) {
+        char *p = out;
+        for (const auto &s : t->scenes) { memcpy(p, s.name.c_str(), s.name.size() + 1); p += s.name.size() + 1; }
+    }
+    return need;
+}
+
+// sample tokens of the given scenes in job order (scenes in the given order, samples in scene order), NUL-separated, and
+// their rows in sample.json; returns the bytes the tokens need (negative: unknown scene)
+extern "C" int64_t cm3d_tables_job_tokens(const cm3d_tables *t, const char *const *scene_names, int32_t n_scenes, char *out, int64_t cap,
+                                          int32_t *rows_out, int64_t cap_rows)
+{
+    if (!t || !scene_names || n_scenes < 0) return CM3D_RD_ERR_ARG;
+    int64_t need = 0, k = 0;
+    char *p = out;
+    for (int i = 0; i < n_scenes; ++i) {
+        auto it = t->scene_by_name.find(scene_names[i] ? scene_names[i] : "");
+        if (it == t->scene_by_name.end()) return CM3D_RD_ERR_ARG;
+        for (int s = t->scenes[it->second].first; s >= 0; s = t->samples[s].next) {
+            const std::string &tok = t->samples[s].token;
+            need += (int64_t)tok.size() + 1;
+            if (out && need <= cap) { memcpy(p, tok.c_str(), tok.size() + 1); p += tok.size() + 1; }
+            if (rows_out && k < cap_rows) rows_out[k] = s;
+            ++k;
+        }
+    }
+    return need;
+}
+
+namespace {
+
+// <f>_data.json: {"labels": [str], "detection_scores": [float], "cam_nums": [int]} (gen_2d_masks_detic.py:497-504)
+struct FrameData { std::vector<std::string> labels; std::vector<double> scores; std::vector<int> cams; };
+bool parse_data_json(const std::vector<uint8_t> &buf, FrameData &d)
+{
+    JP j{(const char *)buf.data(), (const char *)buf.data() + buf.size() - 1};
+    if (!j.eat('{')) return false;
+    if (j.eat('}')) return true;
+    for (;;) {
+        const std::string key = j.str();
+        if (!j.ok || !j.eat(':')) return false;
+        if (key == "labels" || key == "detection_scores" || key == "cam_nums") {
+            if (!j.eat('[')) return false;
+            if (!j.eat(']')) {
+                for (;;) {
+                    if (key == "labels") d.labels.push_back(j.str());
+                    else if (key == "detection_scores") d.scores.push_back(j.num());
+                    else d.cams.push_back((int)j.num());
+                    if (!j.ok) return false;
+                    if (j.eat(',')) continue;
+                    if (j.eat(']')) break;
+                    return false;
+                }
+            }
+        } else j.skip();
+        if (!j.ok) return false;
+        if (j.eat(',')) continue;
+        return j.eat('}');
+    }
+}
+
+bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+
+}   // namespace
+
+struct cm3d_manifest {
+    int n_frames = 0;
+    std::vector<int32_t> sample_index;               // row of every frame in sample.json (its token is the caller's to look up)
+    std::vector<int32_t> frame_sweep_off, frame_mask_off;
+    std::vector<float> sweep_xf, cams;
+    std::vector<double> ego_xyz, score;
+    std::vector<int32_t> mask_cam, class_id;
+    std::string sweep_paths, mask_paths;             // NUL-separated
+    std::vector<int32_t> sweep_path_off, mask_path_off;
+    int bad_frame = -1;
+    std::string bad_label;
+};
+
+// The table walk of a batch of scenes (reference :415-441, :489-503 per frame; nusc_io.scene_manifest).  class_names = the
+// detection names in class-index order; labels are renamed like get_detection_name (:122-132) before the lookup.
+extern "C" cm3d_manifest *cm3d_tables_manifest(const cm3d_tables *t, cm3d_reader *r, const char *const *scene_names, int32_t n_scenes,
+                                               const char *mask_dir, int32_t n_sweeps, double ratio, const char *const *class_names,
+                                               int32_t n_classes, int32_t missing_ok, int32_t *err)
+{
+    auto fail = [&](int code) { if (err) *err = code; return (cm3d_manifest *)nullptr; };
+    if (err) *err = CM3D_RD_OK;
+    if (!t || !r || !scene_names || n_scenes <= 0 || !mask_dir || n_sweeps <= 0 || !class_names || n_classes <= 0) return fail(CM3D_RD_ERR_ARG);
+    try {
+        std::unique_ptr<cm3d_manifest> m(new cm3d_manifest);
+        // frames of the batch: (scene name, frame number inside the scene, sample row)
+        struct Fr { const std::string *scene; int num, sample; };
+        std::vector<Fr> frames;
+        for (int k = 0; k < n_scenes; ++k) {
+            auto it = t->scene_by_name.find(scene_names[k] ? scene_names[k] : "");
+            if (it == t->scene_by_name.end()) return fail(CM3D_RD_ERR_ARG);
+            int num = 0;
+            for (int s = t->scenes[it->second].first; s >= 0; s = t->samples[s].next) frames.push_back({&t->scenes[it->second].name, num++, s});
+        }
+        const int F = (int)frames.size();
+        m->n_frames = F;
+        struct PerFrame { std::vector<float> xf, cams; std::vector<std::string> sweeps; std::string mask; FrameData d; std::vector<int32_t> cls; double ego[3]; int rc = CM3D_RD_OK; std::string bad; };
+        std::vector<PerFrame> pf((size_t)F);
+        const float ratio32 = (float)ratio;
+        const std::string mdir(mask_dir);
+        r->pool.run(F, [&](int i) {
+            PerFrame &o = pf[i];
+            try {
+                const SampleRow &smp = t->samples[frames[i].sample];
+                // mask file + data file (a frame without detections has neither, gen_2d_masks_detic.py:490-491)
+                const std::string stem = mdir + "/" + *frames[i].scene + "/" + std::to_string(frames[i].num);
+                const std::string mp = stem + "_masks.pkl", dp = stem + "_data.json";
+                if (file_exists(mp) && file_exists(dp)) {
+                    o.mask = mp;
+                    std::vector<uint8_t> buf;
+                    if (!read_text(dp.c_str(), buf)) { o.rc = CM3D_RD_ERR_IO; return; }
+                    if (!parse_data_json(buf, o.d)) { o.rc = CM3D_RD_ERR_FORMAT; return; }
+                    if (o.d.labels.size() != o.d.scores.size() || o.d.labels.size() != o.d.cams.size()) { o.rc = CM3D_RD_ERR_FORMAT; return; }
+                    for (const std::string &lab : o.d.labels) {
+                        const char *name = lab == "trafficcone" ? "traffic_cone" : lab == "constructionvehicle" ? "construction_vehicle" : lab == "human" ? "pedestrian" : lab.c_str();
+                        int ci = -1;
+                        for (int c = 0; c < n_classes; ++c) if (!strcmp(class_names[c], name)) { ci = c; break; }
+                        if (ci < 0) { o.rc = CM3D_RD_ERR_FORMAT; o.bad = lab; return; }
+                        o.cls.push_back(ci);
+                    }
+                } else if (!missing_ok) { o.rc = CM3D_RD_ERR_IO; o.bad = mp; return; }
+                // sweeps: the key frame's LIDAR_TOP sample_data and its `next` chain (:433-463)
+                int sd = smp.data[0];
+                if (sd < 0) { o.rc = CM3D_RD_ERR_FORMAT; return; }
+                const PoseRow &key_pose = t->poses[t->sds[sd].pose];
+                o.ego[0] = key_pose.t[0]; o.ego[1] = key_pose.t[1]; o.ego[2] = key_pose.t[2];
+                for (int k = 0; k < n_sweeps && sd >= 0; ++k) {
+                    const SdRow &d = t->sds[sd];
+                    const CsRow &cs = t->css[d.cs];
+                    const PoseRow &pose = t->poses[d.pose];
+                    o.sweeps.push_back(t->dataroot + "/" + d.filename);
+                    double R[9];
+                    float xf[24];
+                    quat_to_rotmat(cs.q, R);
+                    for (int q = 0; q < 9; ++q) xf[q] = (float)R[q];
+                    for (int q = 0; q < 3; ++q) xf[9 + q] = (float)cs.t[q];
+                    quat_to_rotmat(pose.q, R);
+                    for (int q = 0; q < 9; ++q) xf[12 + q] = (float)R[q];
+                    for (int q = 0; q < 3; ++q) xf[21 + q] = (float)pose.t[q];
+                    o.xf.insert(o.xf.end(), xf, xf + 24);
+                    sd = d.next;
+                }
+                // the six cameras' records (:489-503 + :569-587): p += f32(-t_ego); p = f32(R_ego^T) p; p += f32(-t_cs); p = f32(R_cs^T) p; K' = f32(K) * f32(ratio)
+                o.cams.assign(6 * 64, 0.0f);
+                for (int c = 0; c < 6; ++c) {
+                    const int csd = smp.data[1 + c];
+                    if (csd < 0) { o.rc = CM3D_RD_ERR_FORMAT; return; }
+                    const SdRow &d = t->sds[csd];
+                    const CsRow &cs = t->css[d.cs];
+                    const PoseRow &pose = t->poses[d.pose];
+                    if (!cs.has_k) { o.rc = CM3D_RD_ERR_FORMAT; return; }
+                    float *rec = o.cams.data() + 64 * c;
+                    double R[9];
+                    quat_to_rotmat(pose.q, R);
+                    for (int q = 0; q < 3; ++q) rec[q] = (float)(-pose.t[q]);
+                    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) rec[3 + 3 * a + b] = (float)R[3 * b + a];          // transposed
+                    quat_to_rotmat(cs.q, R);
+                    for (int q = 0; q < 3; ++q) rec[15 + q] = (float)(-cs.t[q]);
+                    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) rec[18 + 3 * a + b] = (float)R[3 * b + a];
+                    for (int q = 0; q < 9; ++q) rec[45 + q] = (float)cs.K[q] * ratio32;        // float32 product (geometry.scaled_intrinsic_f32)
+                    rec[45 + 8] = 1.0f;
+                    rec[54] = 2.0f;
+                    rec[55] = 5.0f;                                                             // both stages translate first
+                }
+            } catch (...) {
+                o.rc = CM3D_RD_ERR_FORMAT;
+            }
+        });
+        m->frame_sweep_off.push_back(0);
+        m->frame_mask_off.push_back(0);
+        m->sweep_path_off.push_back(0);
+        m->mask_path_off.push_back(0);
+        for (int i = 0; i < F; ++i) {
+            PerFrame &o = pf[i];
+            if (o.rc != CM3D_RD_OK) {
+                m->bad_frame = i; m->bad_label = o.bad;
+                if (err) *err = o.rc;
+                return m.release();                        // the caller reads bad_frame / bad_label, then closes it
+            }
+            m->sample_index.push_back(frames[i].sample);
+            m->sweep_xf.insert(m->sweep_xf.end(), o.xf.begin(), o.xf.end());
+            m->cams.insert(m->cams.end(), o.cams.begin(), o.cams.end());
+            m->ego_xyz.insert(m->ego_xyz.end(), o.ego, o.ego + 3);
+            for (const std::string &p : o.sweeps) { m->sweep_paths += p; m->sweep_paths.push_back('\0'); m->sweep_path_off.push_back((int32_t)m->sweep_paths.size()); }
+            m->frame_sweep_off.push_back(m->frame_sweep_off.back() + (int32_t)o.sweeps.size());
+            m->mask_paths += o.mask; m->mask_paths.push_back('\0'); m->mask_path_off.push_back((int32_t)m->mask_paths.size());
+            m->mask_cam.insert(m->mask_cam.end(), o.d.cams.begin(), o.d.cams.end());
+            m->class_id.insert(m->class_id.end(), o.cls.begin(), o.cls.end());
+            m->score.insert(m->score.end(), o.d.scores.begin(), o.d.scores.end());
+            m->frame_mask_off.push_back(m->frame_mask_off.back() + (int32_t)o.cls.size());
+        }
+        return m.release();
+    } catch (...) {
+        return fail(CM3D_RD_ERR_FORMAT);
+    }
+}
+
+extern "C" void cm3d_manifest_close(cm3d_manifest *m) { delete m; }
+
+// sizes: [0] frames, [1] sweeps, [2] masks (per the data files), [3] bytes of the sweep-path blob, [4] of the mask-path blob,
+// [5] first frame that could not be read (-1: none)
+extern "C" void cm3d_manifest_sizes(const cm3d_manifest *m, int64_t *out)
+{
+    if (!m || !out) return;
+    out[0] = m->n_frames; out[1] = (int64_t)m->sweep_xf.size() / 24; out[2] = (int64_t)m->class_id.size();
+    out[3] = (int64_t)m->sweep_paths.size(); out[4] = (int64_t)m->mask_paths.size(); out[5] = m->bad_frame;
+}
+
+extern "C" const char *cm3d_manifest_bad_label(const cm3d_manifest *m) { return m ? m->bad_label.c_str() : ""; }
+
+// copies the manifest's arrays into caller buffers sized by cm3d_manifest_sizes (any pointer may be NULL to skip it)
+extern "C" int cm3d_manifest_copy(const cm3d_manifest *m, int32_t *sample_index, int32_t *frame_sweep_off, float *sweep_xf, float *cams,
+                                  double *ego_xyz, int32_t *frame_mask_off, int32_t *mask_cam, int32_t *class_id, double *score,
+                                  char *sweep_paths, int32_t *sweep_path_off, char *mask_paths, int32_t *mask_path_off)
+{
+    if (!m || m->bad_frame >= 0) return CM3D_RD_ERR_ARG;
+    auto cp = [](auto *dst, const auto &src) { if (dst && !src.empty()) memcpy(dst, src.data(), src.size() * sizeof(src[0])); };
+    cp(sample_index, m->sample_index); cp(frame_sweep_off, m->frame_sweep_off); cp(sweep_xf, m->sweep_xf); cp(cams, m->cams);
+    cp(ego_xyz, m->ego_xyz); cp(frame_mask_off, m->frame_mask_off); cp(mask_cam, m->mask_cam); cp(class_id, m->class_id); cp(score, m->score);
+    cp(sweep_paths, m->sweep_paths); cp(sweep_path_off, m->sweep_path_off); cp(mask_paths, m->mask_paths); cp(mask_path_off, m->mask_path_off);
+    return CM3D_RD_OK;
+}
+
+// the sweeps / mask files of a manifest through the batch loaders above (paths straight from the manifest: no path list
+// crosses the language boundary)
+extern "C" int cm3d_manifest_load_sweeps(cm3d_reader *r, const cm3d_manifest *m, int32_t stride, float *raw_out, int64_t cap_rows,
+                                         int32_t *sweep_row_off, int32_t *bad_index)
+{
+    if (!r || !m || m->bad_frame >= 0) return CM3D_RD_ERR_ARG;
+    try {
+        const int n = (int)m->sweep_path_off.size() - 1;
+        std::vector<const char *> paths((size_t)n);
+        for (int i = 0; i < n; ++i) paths[i] = m->sweep_paths.data() + m->sweep_path_off[i];
+        return cm3d_reader_load_sweeps(r, paths.data(), n, stride, raw_out, cap_rows, sweep_row_off, bad_index);
+    } catch (...) {
+        return CM3D_RD_ERR_IO;
+    }
+}
+
+extern "C" int cm3d_manifest_load_masks(cm3d_reader *r, const cm3d_manifest *m, uint32_t *counts_out, int64_t cap_counts, int32_t *rle_off,
+                                        int32_t *frame_mask_off, int32_t *mask_wh, int32_t cap_masks, int64_t *needed, int32_t *bad_index)
+{
+    if (!r || !m || m->bad_frame >= 0) return CM3D_RD_ERR_ARG;
+    try {
+        const int n = (int)m->mask_path_off.size() - 1;
+        std::vector<const char *> paths((size_t)n);
+        for (int i = 0; i < n; ++i) paths[i] = m->mask_paths.data() + m->mask_path_off[i];
+        return cm3d_reader_load_masks(r, paths.data(), n, counts_out, cap_counts, rle_off, frame_mask_off, mask_wh, cap_masks, needed, bad_index);
+    } catch (...) {
+        return CM3D_RD_ERR_FORMAT;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- result writer
+namespace {
+
+// repr(float) of Python 3 (float_repr_style 'short'): the shortest digit string that round-trips, fixed notation for
+// 1e-4 <= |x| < 1e16 (with ".0" when there is no fraction), else d.ddde[+-]XX with at least two exponent digits.
+// json.dumps spells the non-finite values Infinity / -Infinity / NaN.
+void py_float_repr(double x, std::string &out)
+{
+    if (std::isnan(x)) { out += "NaN"; return; }
+    if (std::isinf(x)) { out += x < 0 ? "-Infinity" : "Infinity"; return; }
+    if (x == 0.0) { out += std::signbit(x) ? "-0.0" : "0.0"; return; }
+    char buf[40];
+    const auto res = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::scientific);      // shortest round-trip digits
+    std::string_view sv(buf, (size_t)(res.ptr - buf));
+    const bool neg = sv[0] == '-';
+    if (neg) sv.remove_prefix(1);
+    const size_t epos = sv.find('e');
+    std::string digits;
+    for (char c : sv.substr(0, epos)) if (c != '.') digits.push_back(c);
+    int exp10 = 0;
+    std::from_chars(sv.data() + epos + 1 + (sv[epos + 1] == '+' ? 1 : 0), sv.data() + sv.size(), exp10);
+    const int decpt = exp10 + 1;                                // position of the decimal point relative to the digit string
+    if (neg) out.push_back('-');
+    if (decpt > -4 && decpt <= 16) {
+        if (decpt <= 0) { out += "0."; out.append((size_t)(-decpt), '0'); out += digits; }
+        else if ((size_t)decpt >= digits.size()) { out += digits; out.append((size_t)decpt - digits.size(), '0'); out += ".0"; }
+        else { out.append(digits, 0, (size_t)decpt); out.push_back('.'); out.append(digits, (size_t)decpt, std::string::npos); }
+    } else {
+        out.push_back(digits[0]);
+        if (digits.size() > 1) { out.push_back('.'); out.append(digits, 1, std::string::npos); }
+        out.push_back('e');
+        const int ex = decpt - 1;
+        out.push_back(ex < 0 ? '-' : '+');
+        const int a = ex < 0 ? -ex : ex;
+        if (a < 10) out.push_back('0');
+        out += std::to_string(a);
+    }
+}
+
+}   // namespace
+
+// The text json.dump writes for the reference's result dict (:808-817, :929-930), straight from the gathered box records:
+//   records  double[n][10]: 0-2 translation, 3 qw, 4 qz, 5 index of the sample in `tokens`, 7 score, 8 class
+//   tokens   n_tokens JSON-quoted sample tokens ("..." incl. the quotes), NUL-separated, in output order
+//   cls_head / cls_tail  per class: the text between the translation and the rotation (', "size": [...], "rotation": [')
+//            and the text behind the score (velocity, name, attribute, closing brace) -- rendered once by the caller
+//   prefix   everything up to and including '"results": {'
+// Returns the number of bytes written to `out` (needs cap), or the needed size as a negative number when cap is too small.
+extern "C" int64_t cm3d_write_results_json(const double *records, int64_t n, const char *tokens, int32_t n_tokens, const char *const *cls_mid,
+                                           const char *const *cls_score, const char *const *cls_tail, int32_t n_classes, const char *prefix,
+                                           char *out, int64_t cap)
+{
+    if ((!records && n) || !tokens || n_tokens < 0 || !cls_mid || !cls_score || !cls_tail || !prefix) return 0;
+    try {
+        std::vector<const char *> tok((size_t)n_tokens);
+        const char *p = tokens;
+        for (int i = 0; i < n_tokens; ++i) { tok[i] = p; p += strlen(p) + 1; }
+        // stable bucket by sample
+        std::vector<int64_t> first((size_t)n_tokens + 1, 0), order((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t ti = (int64_t)records[10 * i + 5];
+            if (ti < 0 || ti >= n_tokens || (int)records[10 * i + 8] < 0 || (int)records[10 * i + 8] >= n_classes) return 0;
+            ++first[ti + 1];
+        }
+        for (int i = 0; i < n_tokens; ++i) first[i + 1] += first[i];
+        std::vector<int64_t> cur(first.begin(), first.end() - 1);
+        for (int64_t i = 0; i < n; ++i) order[cur[(int64_t)records[10 * i + 5]]++] = i;
+        std::string s;
+        s.reserve((size_t)(n * 330 + n_tokens * 48 + 256));
+        s += prefix;
+        for (int ti = 0; ti < n_tokens; ++ti) {
+            if (ti) s += ", ";
+            s += tok[ti]; s += ": [";
+            for (int64_t q = first[ti]; q < first[ti + 1]; ++q) {
+                const double *r = records + 10 * order[q];
+                const int ci = (int)r[8];
+                if (q > first[ti]) s += ", ";
+                s += "{\"sample_token\": "; s += tok[ti]; s += ", \"translation\": [";
+                py_float_repr(r[0], s); s += ", "; py_float_repr(r[1], s); s += ", "; py_float_repr(r[2], s);
+                s += cls_mid[ci];
+                py_float_repr(r[3], s); s += ", 0.0, 0.0, "; py_float_repr(r[4], s);
+                s += cls_score[ci];
+                py_float_repr(r[7], s);
+                s += cls_tail[ci];
+            }
+            s += "]";
+        }
+        s += "}}";
+        if ((int64_t)s.size() > cap || !out) return -(int64_t)s.size();
+        memcpy(out, s.data(), s.size());
+        return (int64_t)s.size();
+    } catch (...) {
+        return 0;
+    }
+}

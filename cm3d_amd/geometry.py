@@ -17,10 +17,12 @@ SWEEP_XF_STRIDE = 24     # floats per sweep transform record (CM3D_SWEEP_XF_STRI
 def quat_to_rotmat(q_wxyz):
     """Unit-quaternion (w,x,y,z) -> 3x3 float64 rotation matrix
     (pyquaternion `Quaternion(q).rotation_matrix`; the quaternion is normalised first)."""
-    q = np.asarray(q_wxyz, np.float64)
-    # |q| = sqrt(q.q) as np.linalg.norm computes it; the elements as Python floats (the same IEEE double arithmetic without
-    # numpy's scalar overhead: this runs twenty times per frame in the entry points' table walk)
-    w, x, y, z = (q / math.sqrt(q.dot(q))).tolist()
+    # |q| = sqrt(w^2 + x^2 + y^2 + z^2) with the squares added left to right, all in IEEE double on Python floats: a DEFINED
+    # order (a BLAS dot product's is not), so that the native table walk (csrc/reader.cpp, cm3d_tables_*) produces the same
+    # bits; this runs twenty times per frame in the entry points' Python table walk
+    w, x, y, z = (float(v) for v in q_wxyz)
+    nrm = math.sqrt(w * w + x * x + y * y + z * z)
+    w, x, y, z = w / nrm, x / nrm, y / nrm, z / nrm
     return np.array([
         [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],

@@ -755,6 +755,22 @@ def nuscenes_results_json(rec, tokens, classes: Optional[ClassTable] = None, met
     return f'{{"meta": {json.dumps(meta if meta is not None else {})}, "results": {{{body}}}}}', sum(len(b) for b in per)
 
 
+def nuscenes_results_json_native(rec, tokens, classes: Optional[ClassTable] = None, meta=None) -> bytes:
+    """nuscenes_results_json through the native writer (libcm3d_reader.so, cm3d_write_results_json): the same bytes
+    (tests/test_reader.py), without a Python statement per box -- 60 000 boxes take milliseconds instead of a third of a second."""
+    import json
+    from . import reader as rdmod
+    classes = classes or ClassTable.nuscenes()
+    mid, score, tail = [], [], []
+    for ci, name in enumerate(classes.names):
+        size = json.dumps([float(v) for v in classes.prior_wlh[ci]])
+        mid.append(f'], "size": {size}, "rotation": [')
+        score.append(f'], "velocity": [0, 0], "detection_name": {json.dumps(name)}, "detection_score": ')
+        tail.append(f', "attribute_name": {json.dumps(ATTRIBUTE_NAMES[name])}}}')
+    prefix = f'{{"meta": {json.dumps(meta if meta is not None else {})}, "results": {{'
+    return rdmod.write_results_json(rec, [json.dumps(t) for t in tokens], mid, score, tail, prefix)
+
+
 def box_records(hb: HostBatch, res: dict, classes: Optional[ClassTable] = None):
     """Device results -> the reference's per-sample box dict lists (:808-817, after NMS :913-924).
     Every sample keeps its key; a sample without boxes maps to [] (:845 runs before the `continue` at :896)."""

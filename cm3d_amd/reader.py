@@ -37,6 +37,23 @@ def lib():
         h.cm3d_reader_load_sweeps.restype, h.cm3d_reader_load_sweeps.argtypes = C.c_int, [p, p, i32, i32, p, i64, p, p]
         h.cm3d_reader_load_masks.restype, h.cm3d_reader_load_masks.argtypes = C.c_int, [p, p, i32, p, i64, p, p, p, i32, p, p]
         h.cm3d_rle_string_to_counts.restype, h.cm3d_rle_string_to_counts.argtypes = i64, [C.c_char_p, i64, p, i64]
+        # tables / manifests / writer
+        h.cm3d_tables_open.restype, h.cm3d_tables_open.argtypes = p, [p, C.c_char_p, C.c_char_p, p]
+        h.cm3d_tables_close.restype, h.cm3d_tables_close.argtypes = None, [p]
+        h.cm3d_tables_scene_samples.restype, h.cm3d_tables_scene_samples.argtypes = i32, [p, C.c_char_p]
+        h.cm3d_tables_scene_location.restype, h.cm3d_tables_scene_location.argtypes = i32, [p, C.c_char_p, p, i32]
+        h.cm3d_tables_scene_names.restype, h.cm3d_tables_scene_names.argtypes = i64, [p, p, i64]
+        h.cm3d_tables_job_tokens.restype, h.cm3d_tables_job_tokens.argtypes = i64, [p, p, i32, p, i64, p, i64]
+        h.cm3d_tables_manifest.restype = p
+        h.cm3d_tables_manifest.argtypes = [p, p, p, i32, C.c_char_p, i32, C.c_double, p, i32, i32, p]
+        h.cm3d_manifest_close.restype, h.cm3d_manifest_close.argtypes = None, [p]
+        h.cm3d_manifest_sizes.restype, h.cm3d_manifest_sizes.argtypes = None, [p, p]
+        h.cm3d_manifest_bad_label.restype, h.cm3d_manifest_bad_label.argtypes = C.c_char_p, [p]
+        h.cm3d_manifest_copy.restype, h.cm3d_manifest_copy.argtypes = C.c_int, [p] + [p] * 13
+        h.cm3d_manifest_load_sweeps.restype, h.cm3d_manifest_load_sweeps.argtypes = C.c_int, [p, p, i32, p, i64, p, p]
+        h.cm3d_manifest_load_masks.restype, h.cm3d_manifest_load_masks.argtypes = C.c_int, [p, p, p, i64, p, p, p, i32, p, p]
+        h.cm3d_write_results_json.restype = i64
+        h.cm3d_write_results_json.argtypes = [p, i64, C.c_char_p, i32, p, p, p, i32, C.c_char_p, p, i64]
         _lib = h
     return _lib
 
@@ -166,3 +183,176 @@ def string_to_counts(s: bytes) -> np.ndarray:
     if L.cm3d_rle_string_to_counts(s, len(s), out.ctypes.data, n) != n:
         raise ValueError("malformed RLE string")
     return out[:n]
+
+
+class Tables:
+    """The nuScenes tables in native memory (cm3d_tables_open): what NuScenes(VER_NAME, INPUT_PATH) holds for the frame loop of the
+    reference (src/nuscenes/2d_to_3d.py:382, :415-503), parsed once by the reader's thread pool."""
+
+    def __init__(self, rd: Reader, dataroot, version):
+        err = C.c_int32(0)
+        self.rd, self.dataroot, self.version = rd, dataroot, version
+        self.h = lib().cm3d_tables_open(rd.h, os.fsencode(dataroot), os.fsencode(version), C.byref(err))
+        if not self.h:
+            raise ReaderError(err.value, f"cm3d_tables_open({dataroot!r}, {version!r})")
+
+    def close(self):
+        if self.h:
+            lib().cm3d_tables_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def scene_names(self):
+        L = lib()
+        n = L.cm3d_tables_scene_names(self.h, None, 0)
+        buf = C.create_string_buffer(int(n))
+        L.cm3d_tables_scene_names(self.h, buf, n)
+        return [x.decode() for x in buf.raw[:n].split(b"\0")[:-1]]
+
+    def scene_samples(self, name):
+        n = lib().cm3d_tables_scene_samples(self.h, name.encode())
+        if n < 0:
+            raise KeyError(name)
+        return int(n)
+
+    def location(self, name):
+        buf = C.create_string_buffer(256)
+        if lib().cm3d_tables_scene_location(self.h, name.encode(), buf, 256) < 0:
+            raise KeyError(name)
+        return buf.value.decode()
+
+    def job_tokens(self, names):
+        """-> (sample tokens of the scenes in job order, their rows in sample.json as an int32 array)."""
+        L = lib()
+        arr = _paths(names)
+        need = L.cm3d_tables_job_tokens(self.h, arr, len(names), None, 0, None, 0)
+        if need < 0:
+            raise KeyError(names)
+        n = sum(self.scene_samples(s) for s in names)
+        buf = C.create_string_buffer(int(need))
+        rows = np.zeros(max(n, 1), np.int32)
+        L.cm3d_tables_job_tokens(self.h, arr, len(names), buf, need, rows.ctypes.data, n)
+        return [x.decode() for x in buf.raw[:need].split(b"\0")[:-1]], rows[:n]
+
+    def manifest(self, names, mask_dir, n_sweeps, ratio, class_names, missing_ok=False):
+        return Manifest(self, names, mask_dir, n_sweeps, ratio, class_names, missing_ok)
+
+
+class Manifest:
+    """The table walk of a batch of scenes done natively (cm3d_tables_manifest; reference :415-441, :489-503, :423): the
+    per-frame arrays of a lift batch -- sweep transforms, camera records, ego positions, labels as class ids, scores, camera
+    numbers -- plus the sweep and mask files, which `load` reads through the same handle without a path list ever crossing into
+    Python."""
+
+    def __init__(self, tables, names, mask_dir, n_sweeps, ratio, class_names, missing_ok):
+        L = lib()
+        err = C.c_int32(0)
+        self.tables = tables
+        self.h = L.cm3d_tables_manifest(tables.h, tables.rd.h, _paths(names), len(names), os.fsencode(mask_dir), int(n_sweeps), float(ratio),
+                                        _paths(class_names), len(class_names), 1 if missing_ok else 0, C.byref(err))
+        if not self.h:
+            raise ReaderError(err.value, "cm3d_tables_manifest")
+        sz = np.zeros(6, np.int64)
+        L.cm3d_manifest_sizes(self.h, sz.ctypes.data)
+        if sz[5] >= 0:
+            label = L.cm3d_manifest_bad_label(self.h).decode()
+            code = err.value
+            self.close()
+            raise ReaderError(code, f"cm3d_tables_manifest: {label!r}", int(sz[5]))
+        F, S, M = int(sz[0]), int(sz[1]), int(sz[2])
+        self.n_frames, self.n_sweeps, self.n_masks = F, S, M
+        self.sample_index = np.zeros(F, np.int32)
+        self.frame_sweep_off = np.zeros(F + 1, np.int32)
+        self.sweep_xf = np.zeros((S, 24), np.float32)
+        self.cams = np.zeros((F, 6, 64), np.float32)
+        self.ego_xyz = np.zeros((F, 3), np.float64)
+        self.frame_mask_off = np.zeros(F + 1, np.int32)
+        self.mask_cam = np.zeros(M, np.int32)
+        self.class_id = np.zeros(M, np.int32)
+        self.score = np.zeros(M, np.float64)
+        ptr = lambda a: a.ctypes.data if a.size else None
+        rc = L.cm3d_manifest_copy(self.h, ptr(self.sample_index), ptr(self.frame_sweep_off), ptr(self.sweep_xf), ptr(self.cams), ptr(self.ego_xyz),
+                                  ptr(self.frame_mask_off), ptr(self.mask_cam), ptr(self.class_id), ptr(self.score), None, None, None, None)
+        if rc != OK:
+            raise ReaderError(rc, "cm3d_manifest_copy")
+
+    def close(self):
+        if self.h:
+            lib().cm3d_manifest_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_sweeps(self, stride=5):
+        """-> (raw (rows, stride) float32 in a page-locked staging buffer, sweep_row_off int32)"""
+        L, rd = lib(), self.tables.rd
+        off = np.zeros(self.n_sweeps + 1, np.int32)
+        bad = C.c_int32(-1)
+        rc = L.cm3d_manifest_load_sweeps(rd.h, self.h, stride, None, 0, off.ctypes.data, C.byref(bad))
+        if rc not in (OK, ERR_CAPACITY):
+            raise ReaderError(rc, "cm3d_manifest_load_sweeps", bad.value)
+        rows = int(off[-1])
+        raw, owner = _staging(rows * stride, np.float32, rd.pinned)
+        if rows:
+            rc = L.cm3d_manifest_load_sweeps(rd.h, self.h, stride, raw.ctypes.data, rows, off.ctypes.data, C.byref(bad))
+            if rc != OK:
+                raise ReaderError(rc, "cm3d_manifest_load_sweeps", bad.value)
+        out = raw[:rows * stride].reshape(rows, stride)
+        if owner is not None:
+            rd._keep = [owner] + rd._keep[:1]
+            out = _Owned(out, owner)
+        return out, off
+
+    def load_masks(self, guess_counts=1 << 20):
+        """-> (rle_counts uint32, rle_off int32 (M+1), frame_mask_off int32 (F+1), mask_wh int32 (M,2))"""
+        L, rd = lib(), self.tables.rd
+        fmo = np.zeros(self.n_frames + 1, np.int32)
+        need = np.zeros(2, np.int64)
+        bad = C.c_int32(-1)
+        cap_c, cap_m = int(guess_counts), max(self.n_masks, 1)
+        for _ in range(2):
+            counts, owner = _staging(cap_c, np.uint32, rd.pinned)
+            rle_off = np.zeros(cap_m + 1, np.int32)
+            wh = np.zeros((cap_m, 2), np.int32)
+            rc = L.cm3d_manifest_load_masks(rd.h, self.h, counts.ctypes.data, cap_c, rle_off.ctypes.data, fmo.ctypes.data, wh.ctypes.data, cap_m,
+                                            need.ctypes.data, C.byref(bad))
+            if rc == OK:
+                nc, nm = int(need[0]), int(need[1])
+                c = counts[:nc]
+                if owner is not None:
+                    rd._keep = [owner] + rd._keep[:1]
+                    c = _Owned(c, owner)
+                return c, rle_off[:nm + 1].copy(), fmo, wh[:nm].copy()
+            if rc != ERR_CAPACITY:
+                raise ReaderError(rc, "cm3d_manifest_load_masks", bad.value)
+            cap_c, cap_m = int(need[0]) + 16, int(need[1]) + 1
+        raise ReaderError(rc, "cm3d_manifest_load_masks")
+
+
+def write_results_json(rec, tokens_json, cls_mid, cls_score, cls_tail, prefix):
+    """The text of the reference's result file (json.dump of the dict of box lists, :929-930) from the gathered box records,
+    written natively (cm3d_write_results_json); see lifting.nuscenes_results_json for the Python form it must equal."""
+    L = lib()
+    rec = np.ascontiguousarray(rec, np.float64).reshape(-1, 10)
+    blob = b"".join(t.encode() + b"\0" for t in tokens_json)
+    a, b, c = _paths(cls_mid), _paths(cls_score), _paths(cls_tail)
+    cap = int(rec.shape[0]) * 360 + len(blob) * 2 + len(prefix) + 256
+    for _ in range(2):
+        out = C.create_string_buffer(cap)
+        n = L.cm3d_write_results_json(rec.ctypes.data if rec.size else None, rec.shape[0], blob, len(tokens_json), a, b, c, len(cls_mid),
+                                      prefix.encode(), out, cap)
+        if n > 0:
+            return out.raw[:n]
+        if n == 0:
+            raise ReaderError(ERR_ARG, "cm3d_write_results_json")
+        cap = int(-n) + 16
+    raise ReaderError(ERR_CAPACITY, "cm3d_write_results_json")

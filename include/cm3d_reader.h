@@ -56,6 +56,60 @@ int cm3d_reader_load_masks(cm3d_reader *r, const char *const *paths, int32_t n_f
  * negative CM3D_RD_ERR_*; counts_out may be NULL to only count. */
 int64_t cm3d_rle_string_to_counts(const uint8_t *s, int64_t len, uint32_t *counts_out, int64_t cap);
 
+/* ---- the rest of the reference's host-side frame loop: tables, per-frame table walk, <f>_data.json, result writer --------
+ * Replaces (src/nuscenes/2d_to_3d.py of the reference):
+ *   :382       NuScenes(VER_NAME, INPUT_PATH): the scene / sample / sample_data / ego_pose / calibrated_sensor / sensor / log
+ *              tables, parsed once (on the reader's pool) into a flat index
+ *   :415-441, :489-503  the per-frame walk: key-frame LIDAR_TOP sample_data and its `next` chain with every sweep's
+ *              calibrated_sensor + ego_pose (-> float32[24] sweep transform: R_cs, t_cs, R_ego, t_ego as the reference hands
+ *              them to rotate / translate), the six cameras' ego_pose + calibrated_sensor (-> float32[64] camera records,
+ *              include/cm3d_hip.h CM3D_CAM_STRIDE), the LIDAR_TOP ego translation (push_centroid's origin, :793-795)
+ *   :422-423   the frame's file names and json.load of <f>_data.json (labels -> class index after the renames of :122-132,
+ *              detection_scores, cam_nums)
+ *   :929-930   json.dump of {"meta": ..., "results": {token: [box, ...]}}
+ * Quaternion -> matrix and the float64 -> float32 casts follow cm3d_amd/geometry.py operation for operation, so the records
+ * are bit-identical to the Python path's (tests/test_reader.py). */
+typedef struct cm3d_tables cm3d_tables;
+typedef struct cm3d_manifest cm3d_manifest;
+
+cm3d_tables *cm3d_tables_open(cm3d_reader *r, const char *dataroot, const char *version, int32_t *err);
+void cm3d_tables_close(cm3d_tables *t);
+int32_t cm3d_tables_scene_samples(const cm3d_tables *t, const char *scene_name);                 /* < 0: unknown scene */
+int32_t cm3d_tables_scene_location(const cm3d_tables *t, const char *scene_name, char *out, int32_t cap);
+int64_t cm3d_tables_scene_names(const cm3d_tables *t, char *out, int64_t cap);                   /* NUL-separated; returns bytes needed */
+int64_t cm3d_tables_job_tokens(const cm3d_tables *t, const char *const *scene_names, int32_t n_scenes, char *out, int64_t cap,
+                               int32_t *rows_out, int64_t cap_rows);
+
+/* The walk over the frames of `scene_names` (a batch).  class_names: detection names in class-index order.  On an unreadable
+ * frame (missing files without missing_ok, malformed json, a label outside class_names) the manifest is still returned, with
+ * *err set and cm3d_manifest_sizes()[5] = the frame: the caller falls back to its own reader for that batch. */
+cm3d_manifest *cm3d_tables_manifest(const cm3d_tables *t, cm3d_reader *r, const char *const *scene_names, int32_t n_scenes,
+                                    const char *mask_dir, int32_t n_sweeps, double ratio, const char *const *class_names,
+                                    int32_t n_classes, int32_t missing_ok, int32_t *err);
+void cm3d_manifest_close(cm3d_manifest *m);
+/* out[6]: frames, sweeps, masks, bytes of the sweep-path blob, bytes of the mask-path blob, first unreadable frame (-1: none) */
+void cm3d_manifest_sizes(const cm3d_manifest *m, int64_t *out);
+const char *cm3d_manifest_bad_label(const cm3d_manifest *m);
+/* arrays sized by cm3d_manifest_sizes; any pointer may be NULL:
+ *  sample_index int32[F] (row in sample.json), frame_sweep_off int32[F+1], sweep_xf float[S][24], cams float[F][6][64],
+ *  ego_xyz double[F][3], frame_mask_off int32[F+1], mask_cam int32[M], class_id int32[M], score double[M],
+ *  sweep_paths / mask_paths: NUL-separated with their offset arrays int32[S+1] / int32[F+1] */
+int cm3d_manifest_copy(const cm3d_manifest *m, int32_t *sample_index, int32_t *frame_sweep_off, float *sweep_xf, float *cams,
+                       double *ego_xyz, int32_t *frame_mask_off, int32_t *mask_cam, int32_t *class_id, double *score,
+                       char *sweep_paths, int32_t *sweep_path_off, char *mask_paths, int32_t *mask_path_off);
+/* cm3d_reader_load_sweeps / cm3d_reader_load_masks on the manifest's own file lists */
+int cm3d_manifest_load_sweeps(cm3d_reader *r, const cm3d_manifest *m, int32_t stride, float *raw_out, int64_t cap_rows,
+                              int32_t *sweep_row_off, int32_t *bad_index);
+int cm3d_manifest_load_masks(cm3d_reader *r, const cm3d_manifest *m, uint32_t *counts_out, int64_t cap_counts, int32_t *rle_off,
+                             int32_t *frame_mask_off, int32_t *mask_wh, int32_t cap_masks, int64_t *needed, int32_t *bad_index);
+
+/* Result writer (:929-930): records double[n][10] (0-2 translation, 3 qw, 4 qz, 5 index into tokens, 7 score, 8 class), tokens =
+ * n_tokens JSON-quoted sample tokens, NUL-separated, in output order; per class the constant text pieces around the numbers
+ * (rendered once by the caller); floats are written as Python's repr() writes them.  Returns bytes written, or -(bytes needed). */
+int64_t cm3d_write_results_json(const double *records, int64_t n, const char *tokens, int32_t n_tokens, const char *const *cls_mid,
+                                const char *const *cls_score, const char *const *cls_tail, int32_t n_classes, const char *prefix,
+                                char *out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

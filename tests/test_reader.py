@@ -1,6 +1,7 @@
 """CPU: the native host-side loader (libcm3d_reader.so, include/cm3d_reader.h) against the Python reader that mirrors the
 reference's per-frame `pickle.load` / `np.fromfile` -- same host batches, error codes instead of crashes on bad input."""
 import ctypes
+import json
 import os
 import pickle
 import re
@@ -18,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_reader_library_exports_every_declared_symbol(tmp_path):
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "cm3d_reader.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(cm3d_[a-z0-9_]+)\s*\(", src)))
-    assert len(names) == 6
+    assert len(names) == 20 and "cm3d_tables_manifest" in names and "cm3d_write_results_json" in names
     h = ctypes.CDLL(reader.LIB_PATH)
     for n in names:
         assert hasattr(h, n), n
@@ -177,3 +178,92 @@ def test_malformed_mask_files_are_errors_not_crashes(tmp_path):
         with pytest.raises(ValueError):
             reader.string_to_counts(b"o" * groups + b"0")
     assert list(reader.string_to_counts(b"o" * 5 + b"0")) == [0x1FFFFFF]
+
+
+def test_native_tables_and_manifest_equal_the_python_table_walk(tmp_path):
+    """cm3d_tables_open + cm3d_tables_manifest (the table walk, <f>_data.json and the record arithmetic in native code) against
+    nusc_io.NuscTables + scene_manifest + lifting.pack_manifest (Python): every array of the packed batch bit for bit, tokens,
+    scene sizes, map locations; a frame without mask files under missing_ok; a label outside the class table reported, not
+    swallowed."""
+    from cm3d_amd import lifting
+    cfg = syn.config("tiny", n_sweeps=3)
+    dataroot, mask_dir, names = nusc_io.write_synthetic_dataset(str(tmp_path), cfg, n_scenes=3, frames_per_scene=4, lane_points=300)
+    os.remove(os.path.join(mask_dir, names[1], "2_masks.pkl"))          # a frame without detections has no files
+    os.remove(os.path.join(mask_dir, names[1], "2_data.json"))
+    rd = reader.Reader(4, pinned=False)
+    nt = reader.Tables(rd, dataroot, "v1.0-synth")
+    pt = nusc_io.NuscTables("v1.0-synth", dataroot, annotations=False)
+    assert nt.scene_names() == [s["name"] for s in pt.t["scene"].values()]
+    for n in names:
+        assert nt.scene_samples(n) == 4 and nt.location(n) == pt.location(pt.scene_by_name(n))
+    toks, rows = nt.job_tokens(names[::-1])
+    assert toks == [s["token"] for n in names[::-1] for s in pt.samples_of_scene(pt.scene_by_name(n))]
+    sample_rows = list(pt.t["sample"].keys())
+    assert [sample_rows[r] for r in rows] == toks
+    classes = lifting.ClassTable.nuscenes()
+    man = nt.manifest(names, mask_dir, 3, cfg.ratio, classes.names, missing_ok=True)
+    # the Python path on the same scenes
+    pman, lanes, fl = [], [], []
+    for k, n in enumerate(names):
+        ms = nusc_io.scene_manifest(pt, pt.scene_by_name(n), mask_dir, n_sweeps=3, ratio=cfg.ratio, missing_ok=True)
+        pman.extend(ms); lanes.append(nusc_io.load_lane_points(dataroot, pt.location(pt.scene_by_name(n)))); fl.extend([k] * len(ms))
+    assert man.n_frames == len(pman) == 12
+    assert [sample_rows[r] for r in man.sample_index] == [m.token for m in pman]
+    assert np.array_equal(man.cams.view(np.uint32), np.stack([m.cams for m in pman]).view(np.uint32))
+    assert np.array_equal(man.sweep_xf.view(np.uint32), np.concatenate([m.sweep_xf for m in pman]).astype(np.float32).view(np.uint32))
+    assert np.array_equal(man.ego_xyz, np.stack([m.ego_xyz for m in pman]))
+    assert np.array_equal(man.frame_sweep_off, np.concatenate([[0], np.cumsum([len(m.sweep_paths) for m in pman])]))
+    assert np.array_equal(man.frame_mask_off, np.concatenate([[0], np.cumsum([len(m.labels) for m in pman])]))
+    assert man.frame_mask_off[7] == man.frame_mask_off[6]                 # the frame without files: no masks
+    assert np.array_equal(man.mask_cam, np.concatenate([m.cam_nums for m in pman]))
+    assert np.array_equal(man.score, np.concatenate([np.asarray(m.scores, np.float64) for m in pman]))
+    assert np.array_equal(man.class_id, [classes.index(lifting.get_detection_name(l)) for m in pman for l in m.labels])
+    # the bulk data through the manifest's own file lists = through path lists
+    raw, row_off = man.load_sweeps(5)
+    raw2, row_off2 = rd.load_sweeps([p for m in pman for p in m.sweep_paths], 5)
+    assert np.array_equal(row_off, row_off2) and np.array_equal(raw, raw2)
+    c1, o1, f1, wh1 = man.load_masks()
+    c2, o2, f2, wh2 = rd.load_masks([m.mask_path for m in pman])
+    assert np.array_equal(c1, c2) and np.array_equal(o1, o2) and np.array_equal(f1, f2) and np.array_equal(wh1, wh2)
+    assert np.array_equal(f1, man.frame_mask_off)
+    # missing files without missing_ok, and an unknown label: errors that name the frame
+    with pytest.raises(reader.ReaderError) as e:
+        nt.manifest(names, mask_dir, 3, cfg.ratio, classes.names, missing_ok=False)
+    assert e.value.code == reader.ERR_IO and e.value.index == 6
+    d = json.load(open(os.path.join(mask_dir, names[0], "1_data.json")))
+    d["labels"][0] = "unicorn"
+    json.dump(d, open(os.path.join(mask_dir, names[0], "1_data.json"), "w"))
+    with pytest.raises(reader.ReaderError) as e:
+        nt.manifest(names, mask_dir, 3, cfg.ratio, classes.names, missing_ok=True)
+    assert e.value.code == reader.ERR_FORMAT and e.value.index == 1 and "unicorn" in str(e.value)
+
+
+def test_native_result_writer_equals_json_dump(tmp_path):
+    """cm3d_write_results_json against lifting.nuscenes_results_json (itself held to json.dumps of the reference's dicts in
+    tests/test_host_logic.py): byte for byte, on records whose floats cover every branch of Python's repr -- integers, tiny and
+    huge magnitudes (exponent notation from 1e16 and below 1e-4), negative zero, subnormals, non-finite values, 17-digit
+    mantissas -- and samples without boxes."""
+    from cm3d_amd import lifting
+    rng = np.random.default_rng(5)
+    classes = lifting.ClassTable.nuscenes()
+    tokens = [f"tok-{i:04d}" for i in range(40)] + ['quote"and\\\\slash', "ünï"]
+    special = [0.0, -0.0, 1.0, -1.0, 100.0, 1e15, 1e16, 1.5e16, 123456789012345680.0, 1e22, 1e-4, 9.999e-5, 1e-5, 1.2345e-7, 5e-324, 2.2250738585072014e-308,
+               1.7976931348623157e308, 0.1, 1 / 3, 2 / 3, 1e23, 1234.5, 600.1234567890123, 1600.987654321, float("inf"), float("-inf"), float("nan"),
+               4.35, 0.30000000000000004, 123456.78901234567, 9007199254740993.0, 0.001, 0.0001, 12345678.0, 1e-10, 3.14e+100]
+    n = 700
+    rec = np.zeros((n, 10))
+    rec[:, 0:3] = rng.normal(scale=[800, 800, 2], size=(n, 3)) + [600, 1600, 0]
+    rec[:, 3:5] = rng.normal(size=(n, 2))
+    rec[:, 5] = rng.integers(0, len(tokens), n)
+    rec[rec[:, 5] == 7, 5] = 8                                           # sample 7 stays without boxes
+    rec[:, 7] = np.round(rng.uniform(0.3, 1, n), 2)
+    rec[:, 8] = rng.integers(0, len(classes.names), n)
+    vals = rng.choice(special, size=(n, 6))
+    use = rng.random((n, 6)) < 0.3
+    for k, col in enumerate((0, 1, 2, 3, 4, 7)):
+        rec[use[:, k], col] = vals[use[:, k], k]
+    meta = {"use_camera": True, "use_lidar": False, "use_radar": False, "use_map": True, "use_external": False}
+    want, n_boxes = lifting.nuscenes_results_json(rec, tokens, classes, meta)
+    got = lifting.nuscenes_results_json_native(rec, tokens, classes, meta)
+    assert n_boxes == n and got == want.encode()
+    assert lifting.nuscenes_results_json_native(np.zeros((0, 10)), tokens[:3], classes, meta) == lifting.nuscenes_results_json(np.zeros((0, 10)), tokens[:3], classes, meta)[0].encode()
