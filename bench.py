@@ -84,27 +84,8 @@ def survey_8d_bytes(hb, sum_hits, mode):
 
 def visible_cores():
     """Cores this process may use: the scheduler affinity, cut by the cgroup CPU quota when there is one."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    quota = None
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    quota = float(txt[0]) / float(txt[1])
-            else:
-                q = float(txt[0])
-                if q > 0:
-                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    if quota:
-        n = max(1, min(n, int(quota + 0.5)))
-    return n
+    from cm3d_amd.reader import usable_cores
+    return usable_cores()
 
 
 def cpu_baseline(frames, lanes, frame_lane, hb, n_sample):
@@ -304,7 +285,7 @@ def end_to_end_bench(args):
 
         run("warm", names[:2], 0, 0)                                      # first-use costs (library loads, allocator) stay out
         nproc = max(2, min(cores // 2, 16))
-        dt_t, res_t, timer_t = run("threads", names, 0, 0)
+        dt_t, res_t, timer_t = run("threads", names, int(os.environ.get("CM3D_E2E_READER_THREADS", "0")), 0)
         dt_p, res_p, timer_p = run("procs", names, max(1, cores // nproc), nproc)
         sub = names[:max(2, 128 // per_scene)]
         dt_py, res_py, _ = run("python", sub, -1, 0)

@@ -331,10 +331,10 @@ class LiftEngine:
         Wp = (W + 31) // 32
         b = type("DeviceBatch", (), {})()
         b.hb, b.F, b.M, b.S, b.W, b.H, b.Wp = hb, F, M, S, W, H, Wp
-        b.raw = t(hb.raw); b.sweep_row_off = t(hb.sweep_row_off); b.sweep_xf = t(hb.sweep_xf)
+        b.sweep_row_off = t(hb.sweep_row_off); b.sweep_xf = t(hb.sweep_xf)
         b.frame_sweep_off = t(hb.frame_sweep_off)
         b.cams = t(hb.cams); b.mask_off = t(hb.mask_off); b.mask_cam = t(hb.mask_cam); b.mask_frame = t(hb.mask_frame)
-        b.rle_counts = t(hb.rle_counts.view(np.int32)); b.rle_off = t(hb.rle_off)
+        b.rle_off = t(hb.rle_off)
         b.class_id = t(hb.class_id); b.score = t(hb.score)
         b.pose_rt = t(hb.pose_rt) if hb.pose_rt is not None else None
         b.pose_inv = t(hb.pose_inv) if hb.pose_inv is not None else None
@@ -381,13 +381,19 @@ class LiftEngine:
         # The spatial index of the lane tables depends on the tables alone (the reference discretises a scene's lanes once,
         # 2d_to_3d.py:406, and looks every frame of the scene up in them): it is built once per distinct set of tables and kept
         # across passes and uploads -- consecutive batches of a scene, and every pass over a resident batch, reuse it.
-        key = (hb.lane.shape, hb.lane_off.tobytes(), zlib.crc32(np.ascontiguousarray(hb.lane).view(np.uint8)))
+        # (a caller that knows which tables these are says so -- pipeline_nuscenes: the map locations --; else their checksum)
+        key = getattr(hb, "lane_key", None) or (hb.lane.shape, hb.lane_off.tobytes(), zlib.crc32(np.ascontiguousarray(hb.lane).view(np.uint8)))
         if self._lane is not None and self._lane["key"] == key:
             b.lane, b.lane_off, b.grid = self._lane["lane"], self._lane["lane_off"], self._lane["grid"]
         else:
             b.grid = torch.empty(b.grid_bytes, dtype=torch.uint8, device=d)
             self._lane = {"key": key, "lane": b.lane, "lane_off": b.lane_off, "grid": b.grid, "built": False}
         b.dense = dense_masks
+        # The bulk data LAST: sweeps and run lengths come from page-locked staging buffers (cm3d_amd.reader) and copy
+        # asynchronously; the small arrays above are pageable, their copies block the host until everything queued before them on
+        # the stream is done -- behind the 180 MB of a C2 batch's sweeps that was the whole transfer time (4 ms), per batch.
+        b.rle_counts = t(hb.rle_counts.view(np.int32))
+        b.raw = t(hb.raw)
         self.b = b
         return b
 
@@ -524,11 +530,20 @@ class LiftEngine:
 
     STAGES = ("sweeps", "masks", "project", "compact", "medoid", "lanes", "boxes")
 
-    def run(self, masks="dense", project_events=None):
+    def run(self, masks="dense", project_events=None, stage_events=None):
         """One pass of the hot path over the resident batch (asynchronous).  project_events: optional pair of
-        torch.cuda.Event recorded around the projection launch on the launch stream (bench.py's roofline timing)."""
+        torch.cuda.Event recorded around the projection launch on the launch stream (bench.py's roofline timing).
+        stage_events: optional list; gets five timing events appended -- before the point/mask stages, behind the compaction,
+        the medoid, the lane search and the boxes -- the entry points' timer buckets (reference :368-378) come from them."""
         st = torch.cuda.current_stream(self.dev).cuda_stream
+
+        def mark():
+            if stage_events is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                stage_events.append(e)
         self.stage_begin(st)
+        mark()
         if not self.can_fuse_sweeps():
             self.stage_sweeps(st)
         self.stage_masks(st, masks)
@@ -537,10 +552,14 @@ class LiftEngine:
         else:
             self.stage_sweep_project(st, project_events)
         self.stage_compact(st)
+        mark()
         self.stage_medoid(st)
+        mark()
         self.wait_lane_grid()
         self.stage_lanes(st)
+        mark()
         self.stage_boxes(st)
+        mark()
         self._lane["passes_since_build"] = self._lane.get("passes_since_build", 0) + 1
 
     def capture_graph(self, masks="rle"):
@@ -638,7 +657,7 @@ class LiftPipeline:
     def depth(self):
         return len(self.engines)
 
-    def submit(self, hb: HostBatch, masks="rle"):
+    def submit(self, hb: HostBatch, masks="rle", stage_events=None):
         """Uploads `hb` into the next slot and issues one pass over it on that slot's stream (asynchronous).
         Returns the slot; `collect(slot)` must be called before the slot comes round again."""
         slot = self._next
@@ -649,7 +668,7 @@ class LiftPipeline:
             self.uploaded[slot].record(self.streams[slot])
             if masks == "dense":
                 eng.decode_masks_dense()
-            eng.run(masks=masks)
+            eng.run(masks=masks, stage_events=stage_events)
         self.masks[slot] = masks
         return slot
 

@@ -183,6 +183,12 @@ def _ahead(it, depth=1):
         yield x
 
 
+def _tokens_as_rows(hb, sample_rows):
+    """A fallback batch of the native route: its frames named by their row in sample.json, like the native batches'."""
+    hb.tokens = [sample_rows[t] for t in hb.tokens]
+    return hb
+
+
 def sample_tokens(tables, scene_names):
     """The job's sample tokens in output order (scenes in the given order, samples in scene order): every rank derives the
     same list from the tables alone, so a shipped record only needs its index into it."""
@@ -258,6 +264,139 @@ def lift_scenes(tables, scene_names, mask_dir, classes, device, n_sweeps=3, rati
     return torch.zeros(0, 10, dtype=torch.float64, device=device)
 
 
+REFERENCE_BUCKETS = ("io", "points in mask", "medoid", "drivable", "closest lane", "nms")       # the reference's timer (:368-378)
+
+
+def _native_batch_head(nt, names, mask_dir, n_sweeps, ratio, classes, missing_ok, lane_cache, sub=None):
+    """First host stage of a batch on the native route: table walk, <f>_data.json, mask pickles + RLE strings (reader.Tables /
+    reader.Manifest) and the scenes' lane tables.  Returns what _native_batch_tail needs, or None when the batch needs the Python
+    reader (frames without masks to be dropped, mixed mask sizes, a pickle the native parser does not know)."""
+    from .reader import ERR_FORMAT, ReaderError
+    t = [time.perf_counter()]
+    try:
+        man = nt.manifest(names, mask_dir, n_sweeps, ratio, classes.names, missing_ok)
+        t.append(time.perf_counter())
+        counts, rle_off, fmo, wh = man.load_masks()
+        t.append(time.perf_counter())
+    except ReaderError as exc:
+        if exc.code != ERR_FORMAT:
+            raise
+        return None
+    n_per = np.diff(fmo)
+    if man.n_masks == 0 or (n_per == 0).any() or not np.array_equal(fmo, man.frame_mask_off):
+        return None
+    W, H = int(wh[0, 0]), int(wh[0, 1])
+    if (wh[:, 0] != W).any() or (wh[:, 1] != H).any():
+        return None
+    lanes, frame_lane, locs = [], [], []
+    for k, name in enumerate(names):
+        loc = nt.location(name)
+        if loc not in lane_cache:
+            lane_cache[loc] = np.asarray(nusc_io.load_lane_points(nt.dataroot, loc), np.float64).astype(np.float32).reshape(-1, 3)   # torch.Tensor(...) at :278
+        lanes.append(lane_cache[loc])
+        locs.append(loc)
+        frame_lane.extend([k] * nt.scene_samples(name))
+    t.append(time.perf_counter())
+    if sub is not None:
+        for key, a in (("host table walk + data.json", 0), ("host mask files", 1), ("host lane tables", 2)):
+            sub[key] = sub.get(key, 0.0) + t[a + 1] - t[a]
+    return man, counts, rle_off, fmo, n_per, (W, H), lanes, frame_lane, locs
+
+
+def _native_batch_tail(nt, head, sub=None, rd=None):
+    """Second host stage: the batch's sweeps read straight into a page-locked buffer, and the HostBatch put together -- without
+    a Python statement per frame.  Returns (HostBatch, rows of its frames in sample.json)."""
+    man, counts, rle_off, fmo, n_per, (W, H), lanes, frame_lane, locs = head
+    t0 = time.perf_counter()
+    raw, row_off = man.load_sweeps(5, rd)
+    t1 = time.perf_counter()
+    F = man.n_frames
+    hb = lifting.HostBatch(
+        raw=raw, raw_stride=5, sweep_row_off=row_off, sweep_xf=man.sweep_xf, frame_sweep_off=man.frame_sweep_off,
+        max_rows_per_sweep=max(1, int(np.diff(row_off).max())), cams=man.cams, n_cams=6, mask_off=fmo.astype(np.int32), mask_cam=man.mask_cam,
+        mask_frame=np.repeat(np.arange(F, dtype=np.int32), n_per), rle_counts=counts, rle_off=rle_off, class_id=man.class_id, score=man.score,
+        lane=np.concatenate(lanes, 0), lane_off=np.concatenate([[0], np.cumsum([t_.shape[0] for t_ in lanes])]).astype(np.int32),
+        frame_lane=np.asarray(frame_lane, np.int32), ego_xyz=man.ego_xyz, width=W, height=H, tokens=[None] * F, labels=None, ego_box=True)
+    hb.lane_key = (nt.dataroot, tuple(locs))              # which lane tables these are: LiftEngine keeps their spatial index across batches
+    if sub is not None:
+        sub["host sweep files"] = sub.get("host sweep files", 0.0) + t1 - t0
+        sub["host assemble"] = sub.get("host assemble", 0.0) + time.perf_counter() - t1
+    return hb, man.sample_index
+
+
+def _native_batch(nt, names, mask_dir, n_sweeps, ratio, classes, missing_ok, lane_cache, sub=None):
+    head = _native_batch_head(nt, names, mask_dir, n_sweeps, ratio, classes, missing_ok, lane_cache, sub)
+    return None if head is None else _native_batch_tail(nt, head, sub)
+
+
+def lift_scenes_native(nt, scene_names, mask_dir, classes, device, row_to_out, n_sweeps=3, ratio=0.64, masks="rle", timer=None,
+                       scenes_per_batch=4, missing_ok=False, python_batch=None):
+    """lift_scenes with the whole host side in libcm3d_reader.so (reader.Tables): per batch one native table walk, one native read
+    of all its files, one upload, one pass.  Three host threads in a row -- the reads of batch k+1 run under the upload and the
+    launches of batch k -- and two batches in flight on the GPU.  row_to_out: row in sample.json -> index of the sample in the
+    job's output order.  python_batch(names) -> (tokens, [HostBatch]) is the fallback for a batch the native path declines.
+    Per-stage GPU times go into `timer` under the reference's bucket names."""
+    timer = timer if timer is not None else {}
+    records, pending, stage_ev = [], [], []
+    pipe = lifting.LiftPipeline(device, depth=2, classes=classes)
+    lane_cache = {}
+    from . import reader as rdmod
+    rd_sweeps = rdmod.Reader(nt.rd.threads)                    # the sweep stage runs on a thread of its own: its own pool and buffers
+    # (both pools together oversubscribe the cores by two: the table / mask stage is short and mostly waits on the sweep stage)
+
+    def drain(keep):
+        while len(pending) > keep:
+            t1 = time.time()
+            slot, ids, evs = pending.pop(0)
+            records.append(pipe.collect_records(slot, ids))
+            timer["gpu lifting"] = timer.get("gpu lifting", 0.0) + time.time() - t1
+            if len(evs) == 5:                                   # (complete: the slot's stream has been synchronised)
+                for key, a, b in (("points in mask", 0, 1), ("medoid", 1, 2), ("closest lane", 2, 3), ("nms", 3, 4)):
+                    timer[key] = timer.get(key, 0.0) + evs[a].elapsed_time(evs[b]) * 1e-3
+
+    # three host threads in a row: (1) table walk, data files, mask files and lane tables of batch k+2, (2) the sweep files of
+    # batch k+1 into a page-locked buffer, (3) this one: upload and launches of batch k.  The native calls release the
+    # interpreter lock, so the three really overlap.
+    def heads():
+        for b0 in range(0, len(scene_names), scenes_per_batch):
+            names = list(scene_names[b0:b0 + scenes_per_batch])
+            t0 = time.time()
+            head = _native_batch_head(nt, names, mask_dir, n_sweeps, ratio, classes, missing_ok, lane_cache, timer)
+            yield names, head, time.time() - t0
+
+    def prepared():
+        for names, head, io_s in _ahead(heads(), depth=1):
+            t0 = time.time()
+            got = None if head is None else _native_batch_tail(nt, head, timer, rd_sweeps)
+            yield names, got, max(io_s, time.time() - t0)       # the two stages overlap: the longer one is the wall time
+
+    for names, got, io_s in _ahead(prepared(), depth=1):
+        timer["io"] = timer.get("io", 0.0) + io_s
+        if got is None:                                         # the Python reader takes this batch
+            t0 = time.time()
+            tokens, batches = python_batch(names)
+            timer["io"] += time.time() - t0
+            todo = [(hb, None) for hb in batches]
+        else:
+            todo = [got]
+        for hb, rows in todo:
+            t1 = time.time()
+            drain(pipe.depth - 1)
+            if rows is None:
+                ids = np.array([[row_to_out[t], 0] for t in hb.tokens], np.float64)
+            else:
+                ids = np.stack([row_to_out[rows].astype(np.float64), np.zeros(len(rows))], 1)
+            evs = []
+            t2 = time.time()
+            pending.append((pipe.submit(hb, masks, stage_events=evs), ids, evs))
+            timer["host upload + launches"] = timer.get("host upload + launches", 0.0) + time.time() - t2
+            timer["gpu lifting"] = timer.get("gpu lifting", 0.0) + time.time() - t1
+    drain(0)
+    if records:
+        return torch.cat(records, 0)
+    return torch.zeros(0, 10, dtype=torch.float64, device=device)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="CM3D 2D->3D lifting (nuScenes), MI355X path")
     ap.add_argument("--version", default=os.environ.get("CM3D_VER_NAME", VER_NAME))
@@ -284,23 +423,56 @@ def main(argv=None):
     if os.environ.get("CM3D_SINGLE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box (with CM3D_DIST_BACKEND=gloo)
         local_rank = 0
     device = f"cuda:{local_rank}"
-    timer = {"tables": 0.0, "io": 0.0, "gpu lifting": 0.0, "gather": 0.0, "write": 0.0, "total": 0.0}
-    tables = nusc_io.NuscTables(args.version, args.dataroot, annotations=False)
-    timer["tables"] = time.time() - total_start
-    names = [s for s in args.scenes.split(",") if s] or [n for n in MINI_VAL]
-    known = {s["name"] for s in tables.scenes()}
-    if not args.scenes and not all(n in known for n in names):
-        names = sorted(known)
+    timer = {k: 0.0 for k in REFERENCE_BUCKETS}
+    timer.update({"tables": 0.0, "gpu lifting": 0.0, "gather": 0.0, "write": 0.0, "total": 0.0})
     priors = _load_priors(args.priors)
     classes = lifting.ClassTable.nuscenes(priors)
+    native = args.reader_threads >= 0 and args.workers <= 0
+    py_tables = []
 
-    # scene-aligned sharding: each rank loads only its scenes' lane tables
-    sizes = [tables.scene_by_name(n)["nbr_samples"] for n in names]
-    lo, hi = cdist.shard_scenes(sizes, world)[rank]
-    tokens = sample_tokens(tables, names)                  # the whole job's samples, identical on every rank
-    mine = lift_scenes(tables, names[lo:hi], args.mask_dir, classes, device, args.n_sweeps, args.ratio, args.masks, timer,
-                       missing_ok=args.missing_ok, workers=args.workers, priors=priors, scenes_per_batch=max(1, args.scenes_per_batch),
-                       token_index={t: i for i, t in enumerate(tokens)}, reader_threads=args.reader_threads)
+    def tables_py():                       # the Python tables, when something needs them (fallback batches, the Python reader)
+        if not py_tables:
+            py_tables.append(nusc_io.NuscTables(args.version, args.dataroot, annotations=False))
+        return py_tables[0]
+    if native:
+        # the whole host side in libcm3d_reader.so: tables parsed once (natively, on the reader's threads), per batch one native
+        # table walk + one native read of all its files; the Python tables are only loaded if a batch falls back
+        from . import reader as rdmod
+        rd = rdmod.Reader(args.reader_threads)
+        nt = rdmod.Tables(rd, args.dataroot, args.version)
+        timer["tables"] = time.time() - total_start
+        known = nt.scene_names()
+        names = [s for s in args.scenes.split(",") if s] or [n for n in MINI_VAL]
+        if not args.scenes and not all(n in known for n in names):
+            names = sorted(known)
+        sizes = [nt.scene_samples(n) for n in names]
+        lo, hi = cdist.shard_scenes(sizes, world)[rank]
+        tokens, rows = nt.job_tokens(names)                    # the whole job's samples, identical on every rank
+        row_to_out = np.full(int(rows.max()) + 1 if len(rows) else 1, -1, np.int64)
+        row_to_out[rows] = np.arange(len(rows))
+
+        def python_batch(batch_names):
+            tabs = tables_py()
+            toks, batches, _ = prepare_scene_batch((args.version, args.dataroot, args.mask_dir, batch_names, args.n_sweeps, args.ratio,
+                                                    args.missing_ok, priors))
+            sample_rows = {t: i for i, t in enumerate(tabs.t["sample"].keys())}
+            return toks, [_tokens_as_rows(hb, sample_rows) for hb in batches]
+        mine = lift_scenes_native(nt, names[lo:hi], args.mask_dir, classes, device, row_to_out, args.n_sweeps, args.ratio, args.masks, timer,
+                                  scenes_per_batch=max(1, args.scenes_per_batch), missing_ok=args.missing_ok, python_batch=python_batch)
+    else:
+        tables = tables_py()
+        timer["tables"] = time.time() - total_start
+        names = [s for s in args.scenes.split(",") if s] or [n for n in MINI_VAL]
+        known = {s["name"] for s in tables.scenes()}
+        if not args.scenes and not all(n in known for n in names):
+            names = sorted(known)
+        # scene-aligned sharding: each rank loads only its scenes' lane tables
+        sizes = [tables.scene_by_name(n)["nbr_samples"] for n in names]
+        lo, hi = cdist.shard_scenes(sizes, world)[rank]
+        tokens = sample_tokens(tables, names)                  # the whole job's samples, identical on every rank
+        mine = lift_scenes(tables, names[lo:hi], args.mask_dir, classes, device, args.n_sweeps, args.ratio, args.masks, timer,
+                           missing_ok=args.missing_ok, workers=args.workers, priors=priors, scenes_per_batch=max(1, args.scenes_per_batch),
+                           token_index={t: i for i, t in enumerate(tokens)}, reader_threads=args.reader_threads)
 
     # the single exchange of the job: fixed-size box records -> rank 0 (one RCCL all_gather of payload; also the path of a
     # one-rank run).  Ranks hold contiguous scene blocks, so rank order is sample order.
@@ -316,10 +488,14 @@ def main(argv=None):
 
     # the writer (:929-930): the records straight to the text json.dump would produce for the reference's dict of box lists
     t0 = time.time()
-    text, _ = lifting.nuscenes_results_json(rec, tokens, classes, dict(META))
     os.makedirs(args.output_dir, exist_ok=True)
-    with open(os.path.join(args.output_dir, args.output_name), "w") as f:
-        f.write(text)
+    if native:
+        with open(os.path.join(args.output_dir, args.output_name), "wb") as f:
+            f.write(lifting.nuscenes_results_json_native(rec, tokens, classes, dict(META)))
+    else:
+        text, _ = lifting.nuscenes_results_json(rec, tokens, classes, dict(META))
+        with open(os.path.join(args.output_dir, args.output_name), "w") as f:
+            f.write(text)
     timer["write"] = time.time() - t0
     print(f"wrote {len(tokens)} samples.")
     timer["total"] = time.time() - total_start

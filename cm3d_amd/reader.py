@@ -58,6 +58,32 @@ def lib():
     return _lib
 
 
+def usable_cores():
+    """Cores this process may use: the scheduler affinity, cut by the cgroup CPU quota when there is one (a container that sees
+    256 cores and is granted 16 must not start 64 reader threads: measured 8 k against 15 k frames/s end to end)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def _paths(paths):
     arr = (C.c_char_p * len(paths))()
     arr[:] = [None if p is None else os.fsencode(p) for p in paths]
@@ -78,6 +104,8 @@ class Reader:
     """A pool of reader threads plus growable staging buffers.  One instance per consumer thread."""
 
     def __init__(self, threads=0, pinned=None):
+        if int(threads) <= 0:
+            threads = min(64, usable_cores())          # 0 = one thread per core this process may use
         self.h = lib().cm3d_reader_open(int(threads))
         if not self.h:
             raise ReaderError(ERR_ARG, "cm3d_reader_open")
@@ -292,9 +320,11 @@ class Manifest:
         except Exception:
             pass
 
-    def load_sweeps(self, stride=5):
-        """-> (raw (rows, stride) float32 in a page-locked staging buffer, sweep_row_off int32)"""
-        L, rd = lib(), self.tables.rd
+    def load_sweeps(self, stride=5, rd=None):
+        """-> (raw (rows, stride) float32 in a page-locked staging buffer, sweep_row_off int32).  rd: the Reader whose threads and
+        staging buffers to use (a Reader serves one calling thread at a time: a caller that reads the sweeps on another thread
+        than the one that walks the tables brings a second one)."""
+        L, rd = lib(), (rd or self.tables.rd)
         off = np.zeros(self.n_sweeps + 1, np.int32)
         bad = C.c_int32(-1)
         rc = L.cm3d_manifest_load_sweeps(rd.h, self.h, stride, None, 0, off.ctypes.data, C.byref(bad))
