@@ -1086,7 +1086,7 @@ extern "C" int64_t cm3d_write_results_json(const double *records, int64_t n, con
                                            const char *const *cls_score, const char *const *cls_tail, int32_t n_classes, const char *prefix,
                                            char *out, int64_t cap)
 {
-    if ((!records && n) || !tokens || n_tokens < 0 || !cls_mid || !cls_score || !cls_tail || !prefix) return 0;
+    if ((!records && n) || !tokens || n_tokens < 0 || !cls_mid || !cls_score || !cls_tail) return 0;
     try {
         std::vector<const char *> tok((size_t)n_tokens);
         const char *p = tokens;
@@ -1103,7 +1103,7 @@ extern "C" int64_t cm3d_write_results_json(const double *records, int64_t n, con
         for (int64_t i = 0; i < n; ++i) order[cur[(int64_t)records[10 * i + 5]]++] = i;
         std::string s;
         s.reserve((size_t)(n * 330 + n_tokens * 48 + 256));
-        s += prefix;
+        if (prefix) s += prefix;
         for (int ti = 0; ti < n_tokens; ++ti) {
             if (ti) s += ", ";
             s += tok[ti]; s += ": [";
@@ -1121,7 +1121,7 @@ extern "C" int64_t cm3d_write_results_json(const double *records, int64_t n, con
             }
             s += "]";
         }
-        s += "}}";
+        if (prefix) s += "}}";                                  // (prefix == NULL: only the "token: [...]" entries, for a caller that streams)
         if ((int64_t)s.size() > cap || !out) return -(int64_t)s.size();
         memcpy(out, s.data(), s.size());
         return (int64_t)s.size();

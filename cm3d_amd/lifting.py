@@ -774,9 +774,12 @@ def nuscenes_results_json(rec, tokens, classes: Optional[ClassTable] = None, met
     return f'{{"meta": {json.dumps(meta if meta is not None else {})}, "results": {{{body}}}}}', sum(len(b) for b in per)
 
 
-def nuscenes_results_json_native(rec, tokens, classes: Optional[ClassTable] = None, meta=None) -> bytes:
+def nuscenes_results_json_native(rec, tokens, classes: Optional[ClassTable] = None, meta=None, part=None) -> bytes:
     """nuscenes_results_json through the native writer (libcm3d_reader.so, cm3d_write_results_json): the same bytes
-    (tests/test_reader.py), without a Python statement per box -- 60 000 boxes take milliseconds instead of a third of a second."""
+    (tests/test_reader.py), without a Python statement per box -- 60 000 boxes take milliseconds instead of a third of a second.
+    part = (first, count): only the entries of tokens[first:first+count] (records whose column 5 lies in that range), without the
+    file's head and tail -- the entry point formats every batch's share while the later batches are still on the GPU and joins
+    the parts with ", " between nuscenes_results_json_head(meta) and b"}}"."""
     import json
     from . import reader as rdmod
     classes = classes or ClassTable.nuscenes()
@@ -786,8 +789,17 @@ def nuscenes_results_json_native(rec, tokens, classes: Optional[ClassTable] = No
         mid.append(f'], "size": {size}, "rotation": [')
         score.append(f'], "velocity": [0, 0], "detection_name": {json.dumps(name)}, "detection_score": ')
         tail.append(f', "attribute_name": {json.dumps(ATTRIBUTE_NAMES[name])}}}')
-    prefix = f'{{"meta": {json.dumps(meta if meta is not None else {})}, "results": {{'
-    return rdmod.write_results_json(rec, [json.dumps(t) for t in tokens], mid, score, tail, prefix)
+    if part is not None:
+        first, count = part
+        rec = np.array(rec, np.float64).reshape(-1, _lib.BOX_STRIDE)
+        rec[:, REC_FRAME_A] -= first
+        return rdmod.write_results_json(rec, [json.dumps(t) for t in tokens[first:first + count]], mid, score, tail, None)
+    return rdmod.write_results_json(rec, [json.dumps(t) for t in tokens], mid, score, tail, nuscenes_results_json_head(meta).decode())
+
+
+def nuscenes_results_json_head(meta=None) -> bytes:
+    import json
+    return f'{{"meta": {json.dumps(meta if meta is not None else {})}, "results": {{'.encode()
 
 
 def box_records(hb: HostBatch, res: dict, classes: Optional[ClassTable] = None):

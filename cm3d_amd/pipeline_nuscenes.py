@@ -330,12 +330,14 @@ def _native_batch(nt, names, mask_dir, n_sweeps, ratio, classes, missing_ok, lan
 
 
 def lift_scenes_native(nt, scene_names, mask_dir, classes, device, row_to_out, n_sweeps=3, ratio=0.64, masks="rle", timer=None,
-                       scenes_per_batch=4, missing_ok=False, python_batch=None):
+                       scenes_per_batch=4, missing_ok=False, python_batch=None, on_records=None):
     """lift_scenes with the whole host side in libcm3d_reader.so (reader.Tables): per batch one native table walk, one native read
     of all its files, one upload, one pass.  Three host threads in a row -- the reads of batch k+1 run under the upload and the
     launches of batch k -- and two batches in flight on the GPU.  row_to_out: row in sample.json -> index of the sample in the
     job's output order.  python_batch(names) -> (tokens, [HostBatch]) is the fallback for a batch the native path declines.
-    Per-stage GPU times go into `timer` under the reference's bucket names."""
+    Per-stage GPU times go into `timer` under the reference's bucket names.  on_records(records of one batch as numpy, first
+    output index, number of samples): called per finished batch whose samples are a contiguous run of the output order, with
+    (None, 0, 0) otherwise -- the caller can then write the batch's share of the result file while later batches still run."""
     timer = timer if timer is not None else {}
     records, pending, stage_ev = [], [], []
     pipe = lifting.LiftPipeline(device, depth=2, classes=classes)
@@ -350,6 +352,12 @@ def lift_scenes_native(nt, scene_names, mask_dir, classes, device, row_to_out, n
             slot, ids, evs = pending.pop(0)
             records.append(pipe.collect_records(slot, ids))
             timer["gpu lifting"] = timer.get("gpu lifting", 0.0) + time.time() - t1
+            if on_records is not None:
+                first = int(ids[0, 0]) if len(ids) else 0
+                if len(ids) and np.array_equal(ids[:, 0], np.arange(first, first + len(ids))):
+                    on_records(records[-1].cpu().numpy(), first, len(ids))
+                else:
+                    on_records(None, 0, 0)
             if len(evs) == 5:                                   # (complete: the slot's stream has been synchronised)
                 for key, a, b in (("points in mask", 0, 1), ("medoid", 1, 2), ("closest lane", 2, 3), ("nms", 3, 4)):
                     timer[key] = timer.get(key, 0.0) + evs[a].elapsed_time(evs[b]) * 1e-3
@@ -457,8 +465,21 @@ def main(argv=None):
                                                     args.missing_ok, priors))
             sample_rows = {t: i for i, t in enumerate(tabs.t["sample"].keys())}
             return toks, [_tokens_as_rows(hb, sample_rows) for hb in batches]
+        # one rank: every finished batch's share of the result file is formatted right away, under the GPU work of the next ones
+        parts, next_first, streamed = [], [0], [world == 1]
+
+        def on_records(rec_np, first, count):
+            t0 = time.time()
+            if rec_np is None or first != next_first[0]:
+                streamed[0] = False
+            elif streamed[0]:
+                parts.append(lifting.nuscenes_results_json_native(rec_np, tokens, classes, None, part=(first, count)))
+                next_first[0] = first + count
+            timer["write"] += time.time() - t0
         mine = lift_scenes_native(nt, names[lo:hi], args.mask_dir, classes, device, row_to_out, args.n_sweeps, args.ratio, args.masks, timer,
-                                  scenes_per_batch=max(1, args.scenes_per_batch), missing_ok=args.missing_ok, python_batch=python_batch)
+                                  scenes_per_batch=max(1, args.scenes_per_batch), missing_ok=args.missing_ok, python_batch=python_batch,
+                                  on_records=on_records if world == 1 else None)
+        streamed[0] = streamed[0] and next_first[0] == len(tokens)
     else:
         tables = tables_py()
         timer["tables"] = time.time() - total_start
@@ -491,12 +512,15 @@ def main(argv=None):
     os.makedirs(args.output_dir, exist_ok=True)
     if native:
         with open(os.path.join(args.output_dir, args.output_name), "wb") as f:
-            f.write(lifting.nuscenes_results_json_native(rec, tokens, classes, dict(META)))
+            if streamed[0]:
+                f.write(lifting.nuscenes_results_json_head(dict(META)) + b", ".join(parts) + b"}}")
+            else:
+                f.write(lifting.nuscenes_results_json_native(rec, tokens, classes, dict(META)))
     else:
         text, _ = lifting.nuscenes_results_json(rec, tokens, classes, dict(META))
         with open(os.path.join(args.output_dir, args.output_name), "w") as f:
             f.write(text)
-    timer["write"] = time.time() - t0
+    timer["write"] += time.time() - t0
     print(f"wrote {len(tokens)} samples.")
     timer["total"] = time.time() - total_start
     for op, v in timer.items():

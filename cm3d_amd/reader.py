@@ -375,14 +375,16 @@ def write_results_json(rec, tokens_json, cls_mid, cls_score, cls_tail, prefix):
     rec = np.ascontiguousarray(rec, np.float64).reshape(-1, 10)
     blob = b"".join(t.encode() + b"\0" for t in tokens_json)
     a, b, c = _paths(cls_mid), _paths(cls_score), _paths(cls_tail)
-    cap = int(rec.shape[0]) * 360 + len(blob) * 2 + len(prefix) + 256
+    cap = int(rec.shape[0]) * 360 + len(blob) * 2 + len(prefix or "") + 256
     for _ in range(2):
         out = C.create_string_buffer(cap)
         n = L.cm3d_write_results_json(rec.ctypes.data if rec.size else None, rec.shape[0], blob, len(tokens_json), a, b, c, len(cls_mid),
-                                      prefix.encode(), out, cap)
+                                      None if prefix is None else prefix.encode(), out, cap)
         if n > 0:
             return out.raw[:n]
         if n == 0:
+            if prefix is None and not tokens_json:
+                return b""
             raise ReaderError(ERR_ARG, "cm3d_write_results_json")
         cap = int(-n) + 16
     raise ReaderError(ERR_CAPACITY, "cm3d_write_results_json")

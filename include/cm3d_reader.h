@@ -105,7 +105,9 @@ int cm3d_manifest_load_masks(cm3d_reader *r, const cm3d_manifest *m, uint32_t *c
 
 /* Result writer (:929-930): records double[n][10] (0-2 translation, 3 qw, 4 qz, 5 index into tokens, 7 score, 8 class), tokens =
  * n_tokens JSON-quoted sample tokens, NUL-separated, in output order; per class the constant text pieces around the numbers
- * (rendered once by the caller); floats are written as Python's repr() writes them.  Returns bytes written, or -(bytes needed). */
+ * (rendered once by the caller); floats are written as Python's repr() writes them.  prefix = everything up to and including
+ * '"results": {'; NULL: only the comma-separated `"token": [...]` entries are written (a caller that streams the file batch by
+ * batch joins them itself).  Returns bytes written, or -(bytes needed). */
 int64_t cm3d_write_results_json(const double *records, int64_t n, const char *tokens, int32_t n_tokens, const char *const *cls_mid,
                                 const char *const *cls_score, const char *const *cls_tail, int32_t n_classes, const char *prefix,
                                 char *out, int64_t cap);

@@ -267,3 +267,28 @@ def test_native_result_writer_equals_json_dump(tmp_path):
     got = lifting.nuscenes_results_json_native(rec, tokens, classes, meta)
     assert n_boxes == n and got == want.encode()
     assert lifting.nuscenes_results_json_native(np.zeros((0, 10)), tokens[:3], classes, meta) == lifting.nuscenes_results_json(np.zeros((0, 10)), tokens[:3], classes, meta)[0].encode()
+
+
+def test_native_result_writer_in_parts_equals_the_whole(tmp_path):
+    """The entry point formats every batch's share of the result file while later batches are still on the GPU: the parts, joined,
+    are the file the one-call writer produces."""
+    from cm3d_amd import lifting
+    rng = np.random.default_rng(6)
+    classes = lifting.ClassTable.nuscenes()
+    tokens = [f"tok-{i:04d}" for i in range(50)]
+    rec = np.zeros((400, 10))
+    rec[:, 0:3] = rng.normal(scale=50, size=(400, 3))
+    rec[:, 3:5] = rng.normal(size=(400, 2))
+    rec[:, 5] = np.sort(rng.integers(0, 50, 400))
+    rec[rec[:, 5] == 20, 5] = 21
+    rec[:, 7] = np.round(rng.uniform(0.3, 1, 400), 2)
+    rec[:, 8] = rng.integers(0, len(classes.names), 400)
+    meta = {"use_camera": True}
+    whole = lifting.nuscenes_results_json_native(rec, tokens, classes, meta)
+    parts = []
+    for first, count in ((0, 17), (17, 8), (25, 0), (25, 25)):
+        sel = (rec[:, 5] >= first) & (rec[:, 5] < first + count)
+        p = lifting.nuscenes_results_json_native(rec[sel], tokens, classes, meta, part=(first, count))
+        if count:
+            parts.append(p)
+    assert lifting.nuscenes_results_json_head(meta) + b", ".join(parts) + b"}}" == whole
