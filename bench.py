@@ -331,6 +331,8 @@ def main(argv=None):
     ap.add_argument("--in-flight", type=int, default=3,
                     help="independent batches kept in flight per GPU (LiftPipeline depth; 1 = one batch at a time)")
     ap.add_argument("--keep-cloud", action="store_true", help="also materialise the transformed cloud (16 B/row more HBM traffic)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("CM3D_BENCH_GRAPH", "0")),
+                    help="1: the passes that carry no timing events are HIP-graph replays (one launch per pass instead of ~14)")
     ap.add_argument("--fusion", type=int, default=0, metavar="SAMPLES",
                     help="time the SAM3D fusion matching (SURVEY 8 f4) on this many samples instead of the lifting path")
     ap.add_argument("--rehearse-launch", action="store_true", help="launch, rendezvous and the record exchange only (no GPU needed)")
@@ -430,6 +432,13 @@ def main(argv=None):
             pe[0].record()
             pe[1].record()
             ev["project"].append(pe)
+        graphs = None
+        if args.graph:
+            graphs = []
+            for slot in range(depth):
+                with torch.cuda.stream(pipe.streams[slot]):
+                    graphs.append(pipe.engines[slot].capture_graph(masks=mode))
+            torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -437,7 +446,11 @@ def main(argv=None):
             pe = None
             if step % ev_every == 0:    # HIP events around the roofline kernel only, recorded by the library on its launch stream
                 pe = ev["project"][step // ev_every]
-            pipe.rerun(step % depth, masks=mode, project_events=pe)       # LiftEngine.run() on that batch's stream
+            if graphs is not None and pe is None:
+                with torch.cuda.stream(pipe.streams[step % depth]):
+                    graphs[step % depth].replay()
+            else:
+                pipe.rerun(step % depth, masks=mode, project_events=pe)       # LiftEngine.run() on that batch's stream
         gathered = None
         if mode == modes[0]:
             # the single end-of-job exchange: fixed-size box records -> rank 0 (RCCL gather)
