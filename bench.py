@@ -331,6 +331,9 @@ def main(argv=None):
     ap.add_argument("--in-flight", type=int, default=3,
                     help="independent batches kept in flight per GPU (LiftPipeline depth; 1 = one batch at a time)")
     ap.add_argument("--keep-cloud", action="store_true", help="also materialise the transformed cloud (16 B/row more HBM traffic)")
+    ap.add_argument("--reuse-batch", action="store_true",
+                    help="generate ONE synthetic batch and make every slot in flight a resident copy of it (the large shapes: generating "
+                         "three 256-frame batches of the 10-sweep configuration takes longer than the measurement)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CM3D_BENCH_GRAPH", "0")),
                     help="1: the passes that carry no timing events are HIP-graph replays (one launch per pass instead of ~14)")
     ap.add_argument("--fusion", type=int, default=0, metavar="SAMPLES",
@@ -383,7 +386,14 @@ def main(argv=None):
         if cache and os.path.exists(cache):
             batches.append((None, pickle.load(open(cache, "rb"))))
             continue
-        fr = [syn.make_frame(cfg, (rank * depth + slot) * args.frames + i) for i in range(args.frames)]
+        if args.reuse_batch and batches:
+            batches.append(batches[0])
+            continue
+        fr = []
+        for i in range(args.frames):
+            fr.append(syn.make_frame(cfg, (rank * depth + slot) * args.frames + i))
+            if rank == 0 and cfg.n_points * cfg.n_sweeps >= 300000 and (i + 1) % 32 == 0:
+                print(f"generating: batch {slot}, frame {i + 1} / {args.frames}", file=sys.stderr, flush=True)     # a long run must not look hung
         batches.append((fr, lifting.pack_frames(fr, lanes, frame_lane)))
         if cache:
             os.makedirs(cache_dir, exist_ok=True)
@@ -603,7 +613,7 @@ def main(argv=None):
                                f"{cfg.n_masks} masks {cfg.width}x{cfg.height}), masks resident as {main_mode}",
                    "frames_per_gpu": args.frames, "points_per_frame": cfg.n_points * cfg.n_sweeps, "masks_per_frame": cfg.n_masks,
                    "mask_size": [cfg.width, cfg.height], "lane_points": args.lane_points, "mask_input": main_mode,
-                   "batches_in_flight": depth, "cloud_materialised": cloud_stored,
+                   "batches_in_flight": depth, "distinct_batches": 1 if args.reuse_batch else depth, "cloud_materialised": cloud_stored,
                    "parallelism": f"frame-sharded x{world}, {depth} independent batches in flight per GPU, one RCCL gather of box records"},
         "ranks_in_group": torch.distributed.get_world_size() if world > 1 else 1,
         "per_rank_ms_per_step": [round(t / args.steps * 1e3, 4) for t in r["per_rank_dt"]],

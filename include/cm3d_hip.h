@@ -173,7 +173,11 @@ int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t 
  *                                very fma chains of the sweep preparation (bit-identical)
  *  tile_work OUT, optional (may be NULL): cm3d_tile_work_bytes(n_masks, idx_cap) bytes; the work list of
  *            cm3d_medoid (one record per medoid tile, longest lists first), built beside the compaction
- *  workspace: the buffer cm3d_project_hits / cm3d_sweep_project_hits filled */
+ *  workspace: the buffer cm3d_project_hits / cm3d_sweep_project_hits filled (per wave-chunk: hit counts per mask, whether it
+ *            holds a hit at all, dropped rows; their sums over groups of 16 wave-chunks; in-mask points per frame)
+ * Two launches, no scan kernel: the compaction computes its own output offsets from those counts, never reads the hit words of a
+ * wave-chunk without a hit, builds hit_off / tile_off / tile_work in the same launch, and leaves (row, sweep) tags in hit_xyz;
+ * a one-thread-per-point launch then fetches and transforms the listed rows (all gathers in flight at once). */
 int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int32_t n_frames, int32_t max_pts_per_frame,
                       int32_t n_points_total, const int32_t *mask_off, int32_t n_masks, const int32_t *hit_count,
                       const uint32_t *removed_bits, const float *raw, int32_t raw_stride, const float *sweep_xf,
