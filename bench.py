@@ -500,8 +500,11 @@ def main(argv=None):
                         b.record()
                         ev[s].append((a, b))
         torch.cuda.synchronize()
-        stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) for s in list(stages) + ["project_with_tables"]}
-        project_alone_ms = float(np.mean([a.elapsed_time(b) for a, b in alone]))
+        # (project: the events of the timed region -> mean, it is an average launch duration; the alone-pass stages: medians of a
+        # handful of passes, one preempted pass must not stand for the stage)
+        stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) if s == "project" else float(np.median([a.elapsed_time(b) for a, b in ev[s]]))
+                    for s in list(stages) + ["project_with_tables"]}
+        project_alone_ms = float(np.median([a.elapsed_time(b) for a, b in alone]))
         status = eng.check_status()
         results[mode] = dict(dt=dt, per_rank_dt=per_rank_dt, stage_ms=stage_ms, project_alone_ms=project_alone_ms, fused=fused, sum_hits=int(status[2]),
                              n_points=int(status[1]), sum_pairs=int((eng.b.hit_count.to(torch.int64) ** 2).sum().item()),
@@ -539,7 +542,10 @@ def main(argv=None):
                     + f" + hit words written (4 B/row/plane, {eng.b.planes} plane(s))"
                     + (" + transformed cloud written (16 B/row)" if (r["fused"] and cloud_stored) else "")
                     + "; the bit-packed mask words the launch gathers (bounding-box gated, mostly L2 hits) and the per-frame tables "
-                      "are extra traffic and NOT counted, so `frac` cannot be inflated by bytes the kernel skips")
+                      "are extra traffic and NOT counted, so `frac` cannot be inflated by bytes the kernel skips; avg_launch_ms = HIP events the "
+                      "library records on the launch stream right around the kernel, inside the timed region: with several batches in flight "
+                      "it holds the time the launch queues behind and shares the chip with the other batches' kernels (rocprof's execution time "
+                      "of the same launches: profiles/*_kernel_stats.csv); frac_alone = the same launch with nothing else on the GPU")
     roofline["rows_per_launch"] = rows
     roofline["bytes_per_row"] = per_row
     # the box's own streaming rate beside the nominal peak: device-to-device copy of 1 GiB, read + write bytes

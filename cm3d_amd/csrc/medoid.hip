@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
 // runs over them in ascending row order (v_readlane + v_add, the only serial part) -- the very additions, in the very
 // order, of the column-per-lane loop, at a fraction of its time when few of the 64 columns are wanted.  More than
 // MDL_MAXC candidates (lists full of duplicated points): wave 0 takes them 64 columns at a time, as k_medoid_tiles does.
-#define MDL_WAVES 8
+#define MDL_WAVES 4                      // (8 waves and 148 VGPRs meant ONE workgroup per CU; four waves let three masks share a CU: the serial sums are latency)
 #define MDL_MAXC 64
 
 // exact float32 distance of this lane's row to the candidate (qx, qy, qz, qn): md_pair2<false> + the correctly rounded root
@@ -441,7 +441,7 @@ static __device__ __forceinline__ float md_exact_colsum_rows(Fetch fetch, int of
     return s;
 }
 
-__global__ __launch_bounds__(64 * MDL_WAVES) void k_medoid_long(const float4 *__restrict__ points, const int32_t *__restrict__ pt_off,
+__global__ __launch_bounds__(64 * MDL_WAVES, 2) void k_medoid_long(const float4 *__restrict__ points, const int32_t *__restrict__ pt_off,
                                                                 const int32_t *__restrict__ mask_frame, int n_masks,
                                                                 const int32_t *__restrict__ hit_off, const int32_t *__restrict__ hit_row,
                                                                 int idx_cap, const float *__restrict__ approx,
@@ -647,7 +647,7 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
                        n_masks, hit_off, tile_off, hit_row, idx_cap, best, tile_cap, approx ? 1 : 0, medoid_pos, centroid);
     CM3D_CHECK_LAUNCH();
     if (approx) {
-        hipLaunchKernelGGL(k_medoid_long, dim3(n_masks < 512 ? n_masks : 512), dim3(64 * MDL_WAVES), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks, hit_off,
+        hipLaunchKernelGGL(k_medoid_long, dim3(n_masks < 1024 ? n_masks : 1024), dim3(64 * MDL_WAVES), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks, hit_off,
                            hit_row, idx_cap, approx, medoid_pos, centroid);
         CM3D_CHECK_LAUNCH();
     }

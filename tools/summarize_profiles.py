@@ -59,7 +59,10 @@ def main(tag):
                 agg[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         per = {k: sum(v) / len(v) for k, v in agg.items() if k.startswith("k_")}
         json.dump(per, open(f"profiles/{tag}_c2_rle_pmc_insts_valu.json", "w"), indent=1)
-        traffic["c2_rle"]["k_medoid_insts_valu"] = int(sum(v for k, v in per.items() if k.startswith("k_medoid")))
+        # per PASS: every medoid dispatch of the run (both instantiations of the tile kernel, the reduction, the long lists'
+        # second pass) summed, divided by the number of passes (= dispatches of the reduction kernel)
+        passes = max(1, len(agg.get("k_medoid_reduce", [])))
+        traffic["c2_rle"]["k_medoid_insts_valu"] = int(sum(sum(v) for k, v in agg.items() if k.startswith("k_medoid")) / passes)
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
     for label, fn in (("three batches in flight (default)", f"profiles/{tag}_c2_rle_kernel_stats.csv"),
                       ("one batch at a time", f"profiles/{tag}_c2_rle_one_batch_kernel_stats.csv")):
