@@ -80,7 +80,57 @@ static __device__ __forceinline__ f2 md_sqrt_core2_ref(f2 x)
 }
 static __device__ __forceinline__ bool md_sqrt_ok(float x) { return (x < 1.0e30f) & (x >= 1.0e-30f); }
 
+// md_sqrt_core2 that takes +0 as well (-> +0).  clamp_min_(0) leaves MANY zeros, not only the diagonal: the expansion's rounding
+// noise is an ulp of the squared norm (0.25 m^2 at 1.7 km from the map origin, 8 m^2 at 10 km), so every pair of points closer
+// than that has an even chance of a non-positive value.  Sending a whole 8-row step of 64 columns to sqrtf() for one such pair
+// cost three times the step (PMC: 21 vector instructions per row where the loop has 11).  With the reciprocal root capped,
+// x = 0 gives s = 0 * r = 0, e = 1/2, d = fma(-0, 0, 0) = +0 and the result fma(0, h, 0) = +0; for x >= 1e-30 the cap
+// (rsq <= 1e15 there) changes nothing, so the values are md_sqrt_core2's.  8 v_min_f32 per step: the packed pipe has no min.
+static __device__ __forceinline__ f2 md_sqrt_core2z(f2 x)
+{
+    const f2 r = {fminf(__builtin_amdgcn_rsqf(x.x), 1.0e18f), fminf(__builtin_amdgcn_rsqf(x.y), 1.0e18f)};
+    f2 s = x * r;
+    f2 h = r * 0.5f;
+    const f2 e = PK_FMA(-h, s, (f2)(0.5f));
+    h = PK_FMA(h, e, h);
+    s = PK_FMA(s, e, s);
+    const f2 d = PK_FMA(-s, s, x);
+    return PK_FMA(d, h, s);
+}
+// x - 1 in the integer order of non-negative floats: +0 becomes the LARGEST value, so an unsigned minimum is the smallest
+// non-zero one
+static __device__ __forceinline__ uint32_t md_nz_key(float x) { return __float_as_uint(x) - 1u; }
+static __device__ __forceinline__ bool md_sqrt_okz(float x) { return x == 0.0f || md_sqrt_ok(x); }
+
 struct TileBest { float s; int j; };
+
+#ifdef CM3D_DIAG
+// Diagnostic build only (make diag; tools/md_diag.py): s_memtime of every tile's wave at its start, after its first staged
+// chunk and at its end, its placement (XCC_ID << 32 | HW_ID) and its list length.
+#define MD_DIAG_WAVES 16384
+__device__ int g_md_diag;
+__device__ unsigned long long g_md_wave[5 * MD_DIAG_WAVES];
+static __device__ __forceinline__ unsigned long long md_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+extern "C" int cm3d_md_diag_set(int flags)
+{
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_md_diag), &flags, sizeof(int)) != hipSuccess) return CM3D_ERR_LAUNCH;
+    void *wv = nullptr;
+    if (hipGetSymbolAddress(&wv, HIP_SYMBOL(g_md_wave)) != hipSuccess || hipMemset(wv, 0, sizeof(g_md_wave)) != hipSuccess) return CM3D_ERR_LAUNCH;
+    return hipDeviceSynchronize() == hipSuccess ? CM3D_OK : CM3D_ERR_LAUNCH;
+}
+extern "C" int cm3d_md_diag_read_waves(unsigned long long *out_host, int n_waves)
+{
+    if (n_waves > MD_DIAG_WAVES) return CM3D_ERR_ARG;
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_md_wave), 5 * (size_t)n_waves * sizeof(unsigned long long)) == hipSuccess ? CM3D_OK : CM3D_ERR_LAUNCH;
+}
+#endif
 __global__ __launch_bounds__(1024) void k_medoid_desc(int n_masks, const int32_t *__restrict__ hit_off,
                                                       const int32_t *__restrict__ tile_off, int idx_cap, int tile_cap,
                                                       TileDesc *__restrict__ desc)
@@ -126,7 +176,16 @@ static __device__ __forceinline__ f2 md_pair2(const float4 A, const float4 B, fl
 // correctly rounded root -- the first pass over long lists (k_medoid_long settles them)
 static __device__ __forceinline__ float md_asqrt(float x) { return x < 1.0e-30f ? 0.0f : __builtin_amdgcn_sqrtf(x); }
 
-template <bool DIRECT, bool APPROX = false>
+// SAFE: the caller has established (md_col_safe, md_row_safe) that every value of the expansion is either <= 0 -- clamp_min_
+// makes it +0 -- or inside md_sqrt_ok's domain, so the per-step test of the extremes (two min / max trees, 12 instructions of
+// a step's ~100) is not needed.  The argument: the chain ends in fl(a + n_j) with n_j this lane's squared norm.  A positive
+// result with a >= -n_j / 2 is >= n_j / 2; with -n_j < a < -n_j / 2 the subtraction is exact (Sterbenz) and a multiple of
+// ulp(n_j / 2) >= 2^-25 n_j.  So n_j >= 1e-22 bounds every positive value from below by 2.9e-30; and n_i, n_j < 2e29 bound
+// it from above by 2 (n_i + n_j) (1 + 1e-6) < 1e30.
+static __device__ __forceinline__ bool md_col_safe(float qn) { return qn >= 1.0e-22f && qn < 2.0e29f; }
+static __device__ __forceinline__ bool md_row_safe(float n) { return n < 2.0e29f; }
+
+template <bool DIRECT, bool APPROX = false, bool SAFE = false>
 static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float qx, float qy, float qz, float qn, float s)
 {
 #ifndef MD_U
@@ -134,6 +193,9 @@ static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float
 #endif
     constexpr int U = MD_U;                   // pairs per step
     int ii = 0;
+#ifdef CM3D_DIAG
+    const int ab = __builtin_amdgcn_readfirstlane(g_md_diag);      // ablations (results wrong by construction): 2 no root, 4 no domain test, 8 no LDS reads, 16 one add per step
+#endif
     for (; ii + 2 * U <= cnt; ii += 2 * U) {
         f2 d[U];
         if (DIRECT) {
@@ -145,6 +207,12 @@ static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float
             float4 A[U], B[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { A[u] = s4[ii + 2 * u]; B[u] = s4[ii + 2 * u + 1]; }
+#ifdef CM3D_DIAG
+            if (ab & 8) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { A[u] = make_float4(qx + u, qy, qz, qn + ii); B[u] = make_float4(qy, qz + u, qx, qn + 3.0f); }
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < U; ++u) d[u] = (f2){A[u].x, A[u].y} * qx;                       // (-2 x_i) * x_j
 #pragma unroll
@@ -158,30 +226,66 @@ static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float
 #pragma unroll
             for (int u = 0; u < U; ++u) d[u] = __builtin_elementwise_max(d[u], (f2)(0.0f));     // clamp_min_(0): v_pk_max_f32
         }
-        // md_sqrt_core's domain, tested on the extremes (a 0 on the diagonal sends its step to sqrtf); packed min / max trees
+        if (SAFE && !DIRECT && !APPROX) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = md_sqrt_core2z(d[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { s = s + d[u].x; s = s + d[u].y; }
+            continue;
+        }
+        // md_sqrt_core's domain, tested on the extremes; packed min / max trees
         f2 lo2 = d[0], hi2 = d[0];
 #pragma unroll
         for (int u = 1; u < U; ++u) { lo2 = __builtin_elementwise_min(lo2, d[u]); hi2 = __builtin_elementwise_max(hi2, d[u]); }
         const float lo = fminf(lo2.x, lo2.y), hi = fmaxf(hi2.x, hi2.y);
+#ifdef CM3D_DIAG
+        if (!APPROX && (ab & 6)) {
+            if (!(ab & 2)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) d[u] = md_sqrt_core2(d[u]);
+            } else if (!(ab & 4)) {
+                s += (lo >= 1.0e-30f && hi < 1.0e30f) ? 0.0f : 1.0f;
+            }
+        } else
+#endif
         if (APPROX) {
 #pragma unroll
             for (int u = 0; u < U; ++u) d[u] = (f2){md_asqrt(d[u].x), md_asqrt(d[u].y)};
-        } else if (__ballot(!(lo >= 1.0e-30f && hi < 1.0e30f))) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) d[u] = (f2){sqrtf(d[u].x), sqrtf(d[u].y)};
-        } else {
+        } else if (!__ballot(!(lo >= 1.0e-30f && hi < 1.0e30f))) {
 #pragma unroll
             for (int u = 0; u < U; ++u) d[u] = md_sqrt_core2(d[u]);
+        } else {
+            // some lane holds a value outside the domain: almost always a zero (md_sqrt_core2z), which is no reason to leave
+            // the packed form -- only a NON-ZERO value below 1e-30, or one beyond 1e30, is
+            uint32_t nz = 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < U; ++u) nz = min(nz, min(md_nz_key(d[u].x), md_nz_key(d[u].y)));
+            if (!__ballot(!(nz >= __builtin_bit_cast(uint32_t, 1.0e-30f) - 1u && hi < 1.0e30f))) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) d[u] = md_sqrt_core2z(d[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) d[u] = (f2){sqrtf(d[u].x), sqrtf(d[u].y)};
+            }
         }
+#ifdef CM3D_DIAG
+        if (ab & 16) {
+            f2 a2 = d[0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) a2 = a2 + d[u];
+            s = s + (a2.x + a2.y);
+            continue;
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < U; ++u) { s = s + d[u].x; s = s + d[u].y; }
     }
     for (; ii < cnt; ii += 2) {               // remaining pairs; the last one may hold a single row
         const f2 d = md_pair2<DIRECT>(s4[ii], s4[ii + 1], qx, qy, qz, qn);
         const bool two = ii + 1 < cnt;
-        const bool bad = !md_sqrt_ok(d.x) || (two && !md_sqrt_ok(d.y));
+        const bool bad = !(SAFE && !DIRECT) && (!md_sqrt_okz(d.x) || (two && !md_sqrt_okz(d.y)));
         const f2 r = APPROX ? (f2){md_asqrt(d.x), md_asqrt(d.y)}
-                            : (__ballot(bad) ? (f2){sqrtf(d.x), sqrtf(d.y)} : md_sqrt_core2((f2){d.x, two ? d.y : 1.0f}));
+                            : (__ballot(bad) ? (f2){sqrtf(d.x), sqrtf(d.y)} : md_sqrt_core2z((f2){d.x, two ? d.y : 1.0f}));
         s = s + r.x;
         if (two) s = s + r.y;
     }
@@ -278,6 +382,11 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
 {
     __shared__ float4 s_row_all[MD_WAVES][MD_STAGE];
     const int wave = threadIdx.x >> 6, lane = cm3d_lane();
+#ifdef CM3D_DIAG
+    const int diag = g_md_diag & 1;
+    const unsigned long long t_start = diag ? md_now() : 0ull;
+    unsigned long long t_staged = 0ull;
+#endif
     float4 *s_row = s_row_all[wave];
     const int ntiles = min(tile_off[n_masks], tile_cap);
     if (ntiles <= 0) return;
@@ -304,6 +413,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
             qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
         }
         float s = 0.f;
+        const bool col_safe = !__ballot(act && !md_col_safe(qn));
         const bool direct = M <= 25;
         const bool approx = approx_opt != nullptr && md_two_pass(M);      // long list: approximate sums (k_medoid_approx), k_medoid_long later
         if (WITH_LONG && approx && MD_APPROX_MFMA) {
@@ -316,6 +426,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
         for (int i0 = 0; i0 < M; i0 += MD_STAGE) {
             __builtin_amdgcn_wave_barrier();                  // the previous rows' readers are done
             float4 g[MD_STAGE / 64];
+            bool rows_safe = true;
 #pragma unroll
             for (int c = 0; c < MD_STAGE / 64; ++c)
                 if (i0 + c * 64 + lane < M) g[c] = fetch(off + i0 + c * 64 + lane);
@@ -324,6 +435,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
                 if (i0 + c * 64 + lane < M) {
                     float4 r = g[c];
                     r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
+                    rows_safe &= md_row_safe(r.w);
                     // the expansion branch only ever needs -2x, -2y, -2z of a row (exact products)
                     if (!direct) { r.x = -2.0f * r.x; r.y = -2.0f * r.y; r.z = -2.0f * r.z; }
                     md_stage(s_row, c * 64 + lane, r);
@@ -333,8 +445,13 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int cnt = min(MD_STAGE, M - i0);
+#ifdef CM3D_DIAG
+            if (diag && i0 == 0) t_staged = md_now();
+#endif
+            const bool safe = col_safe && !__ballot(!rows_safe);
             s = direct ? md_rows<true>(s_row, cnt, qx, qy, qz, qn, s)
-                       : (approx ? md_rows<false, true>(s_row, cnt, qx, qy, qz, qn, s) : md_rows<false>(s_row, cnt, qx, qy, qz, qn, s));
+                       : (approx ? md_rows<false, true>(s_row, cnt, qx, qy, qz, qn, s)
+                                 : (safe ? md_rows<false, false, true>(s_row, cnt, qx, qy, qz, qn, s) : md_rows<false>(s_row, cnt, qx, qy, qz, qn, s)));
         }
         if (approx) {
             if (act) approx_opt[off + j] = s;
@@ -357,6 +474,13 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
             if (better(os, oj, bs, bj)) { bs = os; bj = oj; }
         }
         if (lane == 0) { tile_best[d.t].s = bs; tile_best[d.t].j = bj; }
+#ifdef CM3D_DIAG
+        if (diag && lane == 0 && t < MD_DIAG_WAVES) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            g_md_wave[5 * t] = t_start; g_md_wave[5 * t + 1] = t_staged; g_md_wave[5 * t + 2] = md_now();
+            g_md_wave[5 * t + 3] = ((unsigned long long)xcc << 32) | hw; g_md_wave[5 * t + 4] = (unsigned long long)M;
+        }
+#endif
     }
 }
 
@@ -415,7 +539,8 @@ static __device__ __forceinline__ float md_exact_dist(float4 p, float qx, float 
     acc = acc + n;
     acc = acc + qn;
     acc = fmaxf(acc, 0.0f);
-    return md_sqrt_ok(acc) ? md_sqrt_core2((f2){acc, acc}).x : sqrtf(acc);      // both forms are the correctly rounded root
+    if (__ballot(!md_sqrt_okz(acc))) return sqrtf(acc);                      // both forms are the correctly rounded root
+    return md_sqrt_core2z((f2){acc, acc}).x;
 }
 
 template <typename Fetch>
@@ -656,7 +781,8 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
 
 // ---------------------------------------------------------------------------
 // Diagnostic: every float32 bit pattern in [first_bits, last_bits] (positive, inside md_sqrt_ok's domain) through
-// md_sqrt_core2, md_sqrt_core2_ref and sqrtf(); counts the values on which they are not all bit-identical.
+// md_sqrt_core2, md_sqrt_core2z (next to a +0, which must come out as +0), md_sqrt_core2_ref and sqrtf(); counts the values
+// on which they are not all bit-identical.
 __global__ __launch_bounds__(256) void k_selftest_sqrt(uint32_t first_bits, uint32_t last_bits, unsigned long long *n_bad,
                                                         uint32_t *first_bad)
 {
@@ -668,8 +794,10 @@ __global__ __launch_bounds__(256) void k_selftest_sqrt(uint32_t first_bits, uint
         const float x = __uint_as_float(b);
         if (!md_sqrt_ok(x)) continue;
         const float want = sqrtf(x);
-        const float a = md_sqrt_core2((f2){x, x}).x, c = md_sqrt_core2_ref((f2){x, x}).y;
-        if (__float_as_uint(a) != __float_as_uint(want) || __float_as_uint(c) != __float_as_uint(want)) {
+        const float a = md_sqrt_core2((f2){x, x}).x, c = md_sqrt_core2_ref((f2){x, x}).y, z = md_sqrt_core2z((f2){0.0f, x}).y;
+        const uint32_t z0 = __float_as_uint(md_sqrt_core2z((f2){0.0f, x}).x);           // +0 next to x: +0
+        if (__float_as_uint(a) != __float_as_uint(want) || __float_as_uint(c) != __float_as_uint(want) ||
+            __float_as_uint(z) != __float_as_uint(want) || z0 != 0u) {
             ++bad;
             atomicMin(first_bad, b);
         }

@@ -334,6 +334,36 @@ def test_two_pass_medoid_on_near_ties(oracle):
         assert got == want, name
 
 
+def test_every_route_of_the_medoid_root_equals_the_oracle(oracle):
+    """k_medoid_tiles takes the root of a step of squared distances on one of four routes (csrc/medoid.hip md_rows): without any
+    test when the norms of the list prove every value to be 0 or inside [1e-30, 1e30) (SAFE), packed after a test of the
+    step's extremes, packed with zeros among the values, or sqrtf().  Lists built to land on each: ordinary global-frame
+    points with duplicates and near neighbours (zeros everywhere, SAFE); the same list with the map origin itself and
+    points within 1e-12 m of it among the columns (not SAFE: tested routes, zeros); coordinates of 1e-15 m (values around and
+    below 1e-30: sqrtf); coordinates of 1e15 m (norms beyond 2e29: not SAFE, values beyond 1e30: sqrtf).  Column sums bit for
+    bit the oracle's, on lists shorter and longer than one staging chunk."""
+    from cm3d_amd import ops
+    rng = np.random.default_rng(77)
+    centre = np.array([612.0, 1634.0, 1.5])
+    for M in (90, 700):
+        base = centre + rng.normal(0, [0.6, 0.4, 0.3], (M, 3))
+        base[rng.integers(0, M, M // 8)] = base[rng.integers(0, M, M // 8)]          # duplicated rows
+        near_origin = base.copy()
+        near_origin[5] = 0.0
+        near_origin[6:12] = rng.normal(0, 1e-13, (6, 3))
+        near_origin[70] = 0.0
+        cases = {"global": base, "origin among the columns": near_origin,
+                 "femtometres": rng.normal(0, 1e-15, (M, 3)), "femtometres and metres": np.concatenate([rng.normal(0, 1e-15, (M // 2, 3)), base[: M - M // 2] - centre]),
+                 "1e15 m": rng.normal(0, 1e15, (M, 3)), "1e15 m among ordinary points": np.concatenate([base[: M - 3], rng.normal(0, 1e15, (3, 3))])}
+        for name, pts in cases.items():
+            p = np.ascontiguousarray(pts.astype(np.float32))
+            j, cs = ops.get_medoid(p.T, want_colsum=True)
+            P4 = np.concatenate([p, np.zeros((M, 1), np.float32)], 1)
+            je, exp = oracle.medoid(P4, np.arange(M), want_colsum=True)
+            assert np.array_equal(cs.view(np.uint32), exp.view(np.uint32)), (name, M, int((cs.view(np.uint32) != exp.view(np.uint32)).sum()))
+            assert j == je, (name, M)
+
+
 _RLE_FORM_SCRIPT = """
 import sys
 import numpy as np
