@@ -443,7 +443,9 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
 // previous two rows in registers -- 3 LDS reads per output word instead of 9.  The launch is bound by instruction issue and by
 // its longest wave (measured: one wave for a whole 60 000-pixel mask runs 20 us by itself), hence the bands.
 // Same outputs bit for bit (tests/test_gpu_golden.py runs both forms against the oracle).
+#ifndef RW_WAVES
 #define RW_WAVES 4
+#endif
 #define RW_THREADS (64 * RW_WAVES)
 #define RW_PER 8
 #define RW_CHUNK (64 * RW_PER)

@@ -110,6 +110,7 @@ struct TileBest { float s; int j; };
 #define MD_DIAG_WAVES 16384
 __device__ int g_md_diag;
 __device__ unsigned long long g_md_wave[5 * MD_DIAG_WAVES];
+__device__ unsigned long long g_md_clock[4];          // s_memtime and the 100 MHz s_memrealtime at the first wave's start and the last wave's end
 static __device__ __forceinline__ unsigned long long md_now()
 {
     unsigned long long t;
@@ -121,9 +122,15 @@ static __device__ __forceinline__ unsigned long long md_now()
 extern "C" int cm3d_md_diag_set(int flags)
 {
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_md_diag), &flags, sizeof(int)) != hipSuccess) return CM3D_ERR_LAUNCH;
+    unsigned long long z[4] = {~0ull, ~0ull, 0ull, 0ull};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_md_clock), z, sizeof(z)) != hipSuccess) return CM3D_ERR_LAUNCH;
     void *wv = nullptr;
     if (hipGetSymbolAddress(&wv, HIP_SYMBOL(g_md_wave)) != hipSuccess || hipMemset(wv, 0, sizeof(g_md_wave)) != hipSuccess) return CM3D_ERR_LAUNCH;
     return hipDeviceSynchronize() == hipSuccess ? CM3D_OK : CM3D_ERR_LAUNCH;
+}
+extern "C" int cm3d_md_diag_read_clock(unsigned long long *out_host)
+{
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_md_clock), 4 * sizeof(unsigned long long)) == hipSuccess ? CM3D_OK : CM3D_ERR_LAUNCH;
 }
 extern "C" int cm3d_md_diag_read_waves(unsigned long long *out_host, int n_waves)
 {
@@ -386,6 +393,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
     const int diag = g_md_diag & 1;
     const unsigned long long t_start = diag ? md_now() : 0ull;
     unsigned long long t_staged = 0ull;
+    const unsigned long long w_start = diag ? wall_clock64() : 0ull;
 #endif
     float4 *s_row = s_row_all[wave];
     const int ntiles = min(tile_off[n_masks], tile_cap);
@@ -479,6 +487,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
             const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
             g_md_wave[5 * t] = t_start; g_md_wave[5 * t + 1] = t_staged; g_md_wave[5 * t + 2] = md_now();
             g_md_wave[5 * t + 3] = ((unsigned long long)xcc << 32) | hw; g_md_wave[5 * t + 4] = (unsigned long long)M;
+            if (t == 0) { g_md_clock[0] = t_start; g_md_clock[1] = w_start; g_md_clock[2] = md_now(); g_md_clock[3] = wall_clock64(); }       // same wave, same XCD as the start stamps
         }
 #endif
     }

@@ -711,35 +711,27 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
         int32_t *cnt_row = wc_cnt_f + pend_chunk * nm_cap;
         bool any = false, mine = false;
         if (ONE_PLANE) {
-            uint32_t *hw = hit_words + (size_t)p0 + pcb + 4 * lane;
-            if (pvalid >= PH_WC) {
-                *reinterpret_cast<u4u *>(hw) = (u4u){pend_bits[0], pend_bits[1], pend_bits[2], pend_bits[3]};
-            } else {
+            any = __ballot(pend_cnt != 0) != 0ull;
+            // the hit words of a wave-chunk WITHOUT a hit (two thirds of them on the headline shape) are never read -- the
+            // compaction looks at wc_info first -- and are not written: 16 bytes per lane of HBM traffic less
+            if (any) {
+                uint32_t *hw = hit_words + (size_t)p0 + pcb + 4 * lane;
+                if (pvalid >= PH_WC) {
+                    *reinterpret_cast<u4u *>(hw) = (u4u){pend_bits[0], pend_bits[1], pend_bits[2], pend_bits[3]};
+                } else {
 #pragma unroll
-                for (int j = 0; j < PH_PT; ++j)
-                    if (4 * lane + j < pvalid) hw[j] = pend_bits[j];
+                    for (int j = 0; j < PH_PT; ++j)
+                        if (4 * lane + j < pvalid) hw[j] = pend_bits[j];
+                }
             }
             if (lane < 32) {
                 cnt_row[lane] = pend_cnt;
                 if (pend_cnt) atomicAdd(&grp_f[(pend_chunk / PH_GRP) * nm_cap + lane], pend_cnt);
             }
-            any = __ballot(pend_cnt != 0) != 0ull;
         } else {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int pl = 0; pl < planes; ++pl) {
-                const uint4 w4 = *reinterpret_cast<const uint4 *>(&s_bits[pl * PH_WC + 4 * lane]);
-                uint32_t *hw = hit_words + (size_t)pl * n_points_total + p0 + pcb + 4 * lane;
-                if (pvalid >= PH_WC) {
-                    *reinterpret_cast<u4u *>(hw) = (u4u){w4.x, w4.y, w4.z, w4.w};
-                } else {
-                    const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-                    for (int j = 0; j < PH_PT; ++j)
-                        if (4 * lane + j < pvalid) hw[j] = wv[j];
-                }
-            }
             for (int k = lane; k < nm; k += 64) {
                 const int cv = s_cnt[k];
                 cnt_row[k] = cv;
@@ -751,6 +743,18 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
                 }
             }
             any = __ballot(mine) != 0ull;
+            for (int pl = 0; any && pl < planes; ++pl) {              // (a wave-chunk without a hit: see above)
+                const uint4 w4 = *reinterpret_cast<const uint4 *>(&s_bits[pl * PH_WC + 4 * lane]);
+                uint32_t *hw = hit_words + (size_t)pl * n_points_total + p0 + pcb + 4 * lane;
+                if (pvalid >= PH_WC) {
+                    *reinterpret_cast<u4u *>(hw) = (u4u){w4.x, w4.y, w4.z, w4.w};
+                } else {
+                    const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int j = 0; j < PH_PT; ++j)
+                        if (4 * lane + j < pvalid) hw[j] = wv[j];
+                }
+            }
             __builtin_amdgcn_wave_barrier();
         }
         // what the compaction wants to know about the chunk before it touches anything else of it

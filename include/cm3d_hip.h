@@ -126,7 +126,9 @@ int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int3
  *        [55] flags: bit 2s = stage s has t_pre, bit 2s+1 = stage s has t_post.
  *        All float32 exactly as the reference hands them to translate/rotate/matmul/view_points.
  *  hit_words uint32[planes][n_points_total] OUT, planes = (max masks per frame + 31)/32;
- *        bit (k&31) of hit_words[k>>5][p] = point p lies in mask mask_off[f]+k
+ *        bit (k&31) of hit_words[k>>5][p] = point p lies in mask mask_off[f]+k.  An intermediate for cm3d_compact_hits:
+ *        written per block of 256 consecutive rows of a frame, and only for blocks that hold at least one in-mask point
+ *        (the per-block flags travel in the workspace); the words of the other blocks keep what the buffer held before
  *  hit_count int32[n_masks] IN/OUT accumulated with atomics; zeroed by cm3d_batch_begin
  *  workspace: cm3d_project_workspace_bytes(F, max_pts_per_frame, planes), 16-byte aligned; it receives the per-frame
  *        tables and the per-(256-row chunk, mask) hit counts and must be handed unchanged to cm3d_compact_hits

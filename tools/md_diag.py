@@ -46,6 +46,10 @@ for _ in range(3):
     eng.stage_medoid(st)
     b.record()
     torch.cuda.synchronize()
+ck = (C.c_ulonglong * 4)()
+L.cm3d_md_diag_read_clock.argtypes = [C.c_void_p]
+L.cm3d_md_diag_read_clock(ck)
+print(f"tile 0's wave: {ck[2] - ck[0]} s_memtime ticks in {(ck[3] - ck[1]) * 10} ns of the 100 MHz clock -> {(ck[2] - ck[0]) / max(1, (ck[3] - ck[1]) * 10):.3f} ticks per ns")
 NW = 16384
 wv = (C.c_ulonglong * (5 * NW))()
 L.cm3d_md_diag_read_waves(wv, NW)
@@ -58,7 +62,7 @@ cu = ((hw >> 8) & 15) | (((hw >> 13) & 7) << 4) | (((hw >> 12) & 1) << 7)
 simd = (hw >> 4) & 3
 print(f"medoid stage {a.elapsed_time(b) * 1e3:.1f} us; {len(t)} tiles; M: min {M.min()} median {int(np.median(M))} mean {M.mean():.0f} max {M.max()}")
 life, front, comp = t[:, 2] - t[:, 0], t[:, 1] - t[:, 0], t[:, 2] - t[:, 1]
-tick = 0.01   # us per s_memtime tick (100 MHz)
+tick = 0.01   # printed unit: 100 s_memtime ticks
 for nm, v in (("lifetime", life), ("start -> first rows staged", front), ("staged -> end", comp)):
     print(f"  {nm:28s} us: min {v.min() * tick:6.2f} p10 {np.percentile(v, 10) * tick:6.2f} median {np.median(v) * tick:6.2f} mean {v.mean() * tick:6.2f} "
           f"p90 {np.percentile(v, 90) * tick:6.2f} max {v.max() * tick:6.2f}")
