@@ -357,7 +357,9 @@ static __device__ __forceinline__ void md_approx_tile(Fetch fetch, float *s_rows
                 c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b2[g], c, 0, 0, 0);        // k = 2, 3
                 c = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3[g], c, 0, 0, 0);         // k = 4, (5: 0 * 0)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) s[g] += md_vsqrt(fmaxf(c[q], 0.0f));        // clamp_min_(0), root, this lane's rows
+                // clamp_min_(0) as a signed-integer maximum on the bits (negative values and -0 -> +0, everything else unchanged;
+                // one instruction where fmaxf() on a matrix-pipe result costs two: it is canonicalised first), root, this lane's rows
+                for (int q = 0; q < 16; ++q) s[g] += md_vsqrt(__int_as_float(max(__float_as_int(c[q]), 0)));
             }
         }
     }
@@ -449,10 +451,18 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
                     md_stage(s_row, c * 64 + lane, r);
                 }
             }
+            // The expansion route takes 8 rows per step: the last chunk is filled up to a multiple of 8 with rows whose value is
+            // -inf for every column (0 * x + ... + (-inf) + n_j), i.e. +0 after clamp_min_(0), a root of +0 and s + 0 = s: the
+            // loop for the odd rows (a third of the instructions of a 100-point list) is never entered.
+            int cnt = min(MD_STAGE, M - i0);
+            if (!direct) {
+                const int pad = (8 - (cnt & 7)) & 7;
+                if (lane < pad) md_stage(s_row, cnt + lane, make_float4(0.0f, 0.0f, 0.0f, -INFINITY));
+                cnt += pad;
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int cnt = min(MD_STAGE, M - i0);
 #ifdef CM3D_DIAG
             if (diag && i0 == 0) t_staged = md_now();
 #endif
