@@ -42,7 +42,7 @@ def packed_rect_bytes(bbox, Wp):
     return int(4 * words.sum())
 
 
-def compulsory_bytes(hb, planes, sum_hits, mode, fused, cloud_stored, rect_bytes):
+def compulsory_bytes(hb, planes, sum_hits, mode, fused, cloud_stored, rect_bytes, hit_rows=None):
     """Bytes every launch MUST move across HBM (per-unit figure x units of one launch).  Nothing here is a
     byte the kernels skip: the full bit-packed masks of SURVEY 8(d) (n*ceil(W*H/8) per frame) are never written nor read
     as a whole -- only `rect_bytes` of them exist -- so they are NOT part of any figure called achieved / frac."""
@@ -51,7 +51,9 @@ def compulsory_bytes(hb, planes, sum_hits, mode, fused, cloud_stored, rect_bytes
     rows = hb.n_raw_rows
     raw = 4 * hb.raw_stride * rows
     cloud = 16 * rows
-    hitw = 4 * rows * planes
+    # hit words exist only for the 256-row blocks that hold an in-mask point (a third of them on the headline shape): the
+    # projection writes, and the compaction reads, those and no others (r03; before: every row's)
+    hitw = 4 * (rows if hit_rows is None else hit_rows) * planes
     runs = 4 * int(hb.rle_counts.size)
     by = {
         # projection launch: raw rows in (fused) or the prepared cloud in, hit words out, cloud out when it is kept.
@@ -507,7 +509,9 @@ def main(argv=None):
         project_alone_ms = float(np.median([a.elapsed_time(b) for a, b in alone]))
         status = eng.check_status()
         results[mode] = dict(dt=dt, per_rank_dt=per_rank_dt, stage_ms=stage_ms, project_alone_ms=project_alone_ms, fused=fused, sum_hits=int(status[2]),
+                             hit_rows=eng.hit_chunk_rows(),
                              n_points=int(status[1]), sum_pairs=int((eng.b.hit_count.to(torch.int64) ** 2).sum().item()),
+                             sum_pairs_long=int((eng.b.hit_count.to(torch.int64) ** 2)[(eng.b.hit_count > 512) & (eng.b.hit_count < 100000)].sum().item()),
                              n_boxes=int((eng.b.flags == 3).sum().item()), max_hits=int(eng.b.hit_count.max().item()),
                              rect_bytes=packed_rect_bytes(eng.b.bbox.cpu().numpy(), eng.b.Wp),
                              n_gathered=None if gathered is None else int(sum(g.shape[0] for g in gathered)))
@@ -521,7 +525,7 @@ def main(argv=None):
     frames_total = args.frames * world * args.steps
     value = frames_total / r["dt"]
     cloud_stored = eng.b.points is not None
-    by = compulsory_bytes(hb, eng.b.planes, r["sum_hits"], main_mode, r["fused"], cloud_stored, r["rect_bytes"])
+    by = compulsory_bytes(hb, eng.b.planes, r["sum_hits"], main_mode, r["fused"], cloud_stored, r["rect_bytes"], r["hit_rows"])
 
     def rate(nbytes, ms):
         return nbytes / (ms * 1e-3) / 1e9
@@ -535,17 +539,19 @@ def main(argv=None):
     # north_star's kernel: projection + in-mask test (one launch per pass), timed by HIP events on its launch stream
     # inside the timed region -- i.e. while the other batches in flight share the GPU with it
     rows = hb.n_raw_rows
-    per_row = (4 * hb.raw_stride if r["fused"] else 16) + 4 * eng.b.planes + (16 if (r["fused"] and cloud_stored) else 0)
+    per_row_in = (4 * hb.raw_stride if r["fused"] else 16) + (16 if (r["fused"] and cloud_stored) else 0)
     roofline = roof("k_project_hits", r["stage_ms"]["project"], "k_project_hits<ONE_PLANE, FUSED, STRIDE>" if r["fused"] else "k_project_hits",
-                    f"bytes that must cross HBM per launch = {per_row} B/row x {rows} rows: "
+                    f"bytes that must cross HBM per launch = {per_row_in} B/row x {rows} rows: "
                     + (f"raw sweep rows read ({4 * hb.raw_stride} B/row)" if r["fused"] else "prepared cloud read (16 B/row)")
-                    + f" + hit words written (4 B/row/plane, {eng.b.planes} plane(s))"
                     + (" + transformed cloud written (16 B/row)" if (r["fused"] and cloud_stored) else "")
+                    + f" + hit words written, 4 B/row/plane ({eng.b.planes} plane(s)) for the {r['hit_rows']} rows in 256-row blocks that hold an "
+                      "in-mask point (the others' words are neither written nor read since r03; cm3d_project_hit_rows counts them on the device's flags)"
                     + "; the bit-packed mask words the launch gathers (bounding-box gated, mostly L2 hits) and the per-frame tables "
                       "are extra traffic and NOT counted, so `frac` cannot be inflated by bytes the kernel skips; avg_launch_ms = HIP events the "
                       "library records on the launch stream right around the kernel, inside the timed region: with several batches in flight "
                       "it holds the time the launch queues behind and shares the chip with the other batches' kernels (rocprof's execution time "
                       "of the same launches: profiles/*_kernel_stats.csv); frac_alone = the same launch with nothing else on the GPU")
+    per_row = round(by["k_project_hits"] / max(1, rows), 2)
     roofline["rows_per_launch"] = rows
     roofline["bytes_per_row"] = per_row
     # the box's own streaming rate beside the nominal peak: device-to-device copy of 1 GiB, read + write bytes
@@ -592,21 +598,34 @@ def main(argv=None):
                       "note": "projection kernel (library events) + the compaction stage (events outside the call: two launches and "
                               "their boundaries), one batch alone; compaction bytes = hit words read + 4 B index + 16 B coordinates "
                               "written per listed point" + ("" if cloud_stored else " + 12 B of its raw row read")}
-    # the medoid against the VECTOR-ALU roof ('report its time separately, not against HBM'): pairs = sum over masks of
-    # (points in the mask)^2, lane-operation slots per pair from the PMC pass of the same launch (SQ_INSTS_VALU x 64 / pairs:
-    # every issued vector instruction occupies 64 lane slots, idle lanes of partly filled 64-column tiles included)
-    VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9      # MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector = 78.6 T lane-operations/s x 2 flop (fma)
+    # The medoid against the VECTOR-ALU roof ('report its time separately, not against HBM').  pairs = sum over masks of
+    # (points in the mask)^2.  Priced in vector-instruction ISSUE SLOTS, the unit the kernel is bound by (MI355X_MICROARCH.md,
+    # 'vector-instruction ISSUE cost': 4 cycles per wave instruction, packed float32 included, 8 for v_rsq / v_sqrt): a SIMD issues
+    # 2.4e9 / 4 slots a second, 1024 SIMDs 614 G, each slot serves 64 lanes.  ALGORITHMIC slots per pair, i.e. what the
+    # reference's float32 arithmetic costs in this instruction set with nothing wasted:
+    #   exact route (lists up to 512 points, csrc/medoid.hip md_rows): 5 packed operations per two pairs for the cdist expansion
+    #     (2.5), clamp_min_ (1), v_rsq (2), its cap for zeros (1), 7 packed operations per two pairs for the correctly rounded
+    #     root (3.5), the ordered sum (1)                                                                           = 11 slots
+    #   first pass of the long lists (md_approx_tile; distances on the matrix pipe): clamp (1), v_sqrt (2), sum (0.5) = 3.5 slots
+    # frac = slots the pairs need / slots the stage's time offers; issued_slots_per_pair (PMC SQ_INSTS_VALU of the same launch,
+    # idle lanes of partly filled tiles, staging, tails and the second pass of the long lists included) says how far the
+    # kernel's own instruction stream is from the algorithmic one.
+    VALU_ISSUE_SLOTS = 256 * 4 * 2.4e9 / 4.0
     md_ms = r["stage_ms"]["medoid"]
     insts = per_kernel.get("k_medoid_insts_valu")
-    slots = (insts * 64.0 / r["sum_pairs"]) if (insts and r["sum_pairs"]) else None
+    pairs_long = r.get("sum_pairs_long", 0)
+    alg_slots = 11.0 * (r["sum_pairs"] - pairs_long) + 3.5 * pairs_long
+    offered = VALU_ISSUE_SLOTS * 64.0 * md_ms * 1e-3
     kernels["medoid"] = {"kernel": "k_medoid_tiles + k_medoid_reduce + k_medoid_long", "bound": "valu", "pairs_per_launch": r["sum_pairs"],
-                         "stage_ms_alone": round(md_ms, 4), "achieved_Gpairs_s": round(r["sum_pairs"] / (md_ms * 1e-3) / 1e9, 1),
-                         "lane_op_slots_per_pair": None if slots is None else round(slots, 1),
-                         "achieved_Tlaneops_s": None if slots is None else round(r["sum_pairs"] * slots / (md_ms * 1e-3) / 1e12, 2),
-                         "peak_Tlaneops_s": round(VALU_PEAK_LANE_OPS / 1e12, 1),
-                         "frac": None if slots is None else round(r["sum_pairs"] * slots / (md_ms * 1e-3) / VALU_PEAK_LANE_OPS, 4),
+                         "pairs_in_long_lists": pairs_long, "stage_ms_alone": round(md_ms, 4),
+                         "achieved_Gpairs_s": round(r["sum_pairs"] / (md_ms * 1e-3) / 1e9, 1),
+                         "algorithmic_slots_per_pair": round(alg_slots / max(1, r["sum_pairs"]), 2),
+                         "issued_slots_per_pair": None if not (insts and r["sum_pairs"]) else round(insts * 64.0 / r["sum_pairs"], 1),
+                         "peak_Gslots_s": round(VALU_ISSUE_SLOTS / 1e9, 1), "unit": "wave-instruction issue slots/s",
+                         "frac": round(alg_slots / offered, 4) if offered else None,
                          "note": "pairs = sum of M^2 over the masks' index lists; the float32 arithmetic per pair is the reference's "
-                                 "(torch.cdist expansion + correctly rounded sqrt + ordered sum); stage time incl. three launch boundaries"}
+                                 "(torch.cdist expansion + correctly rounded sqrt + ordered sum); stage time incl. three launch boundaries; "
+                                 "issued_slots_per_pair is measured on the headline shape (profiles/traffic.json) and absent elsewhere"}
     if not r["fused"]:
         kernels["sweeps"] = roof("k_sweep_xform", r["stage_ms"]["sweeps"], "k_sweep_xform", "HBM streaming, one pass; stage time incl. the launch boundary")
         kernels["sweeps"]["traffic"] = per_kernel.get("k_sweep_xform")

@@ -21,6 +21,8 @@
 // HBM bytes per row that MUST move: 4*raw_stride read + 4 per plane written (+16 when the cloud is kept).
 #include "common.h"
 #include "worklist.h"
+#include <algorithm>
+#include <vector>
 #include <cstdlib>
 
 #ifdef CM3D_DIAG
@@ -1340,6 +1342,33 @@ extern "C" int64_t cm3d_project_workspace_bytes(int32_t n_frames, int32_t max_pt
 {
     if (n_frames <= 0 || max_pts_per_frame <= 0 || planes <= 0) return 0;
     return ph_ws_layout(n_frames, max_pts_per_frame, planes, nullptr, nullptr);
+}
+
+// Accounting aid (bench.py's byte counts; nothing on the path calls it): rows of the batch that lie in a wave-chunk with at
+// least one in-mask point -- the only rows whose hit words the projection writes and the compaction reads.  Synchronous:
+// copies the per-frame tables and the per-chunk flags of `workspace` to the host (after the stream's work has completed).
+extern "C" int cm3d_project_hit_rows(const void *workspace, int64_t workspace_bytes, int32_t n_frames, int32_t max_pts_per_frame,
+                                     int32_t planes, int64_t *rows_out, cm3d_stream_t stream)
+{
+    if (!workspace || !rows_out || n_frames <= 0 || max_pts_per_frame <= 0 || planes <= 0) return CM3D_ERR_ARG;
+    if (workspace_bytes < cm3d_project_workspace_bytes(n_frames, max_pts_per_frame, planes) || ((uintptr_t)workspace & 15)) return CM3D_ERR_WORKSPACE;
+    try {
+        PhWs ws;
+        ph_ws_layout(n_frames, max_pts_per_frame, planes, const_cast<void *>(workspace), &ws);
+        const int nwc_max = (max_pts_per_frame + PH_WC - 1) / PH_WC;
+        std::vector<int32_t> ft((size_t)n_frames * FT_WORDS), info((size_t)n_frames * nwc_max);
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return CM3D_ERR_LAUNCH;
+        if (hipMemcpy(ft.data(), ws.ft, ft.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return CM3D_ERR_LAUNCH;
+        if (hipMemcpy(info.data(), ws.wc_info, info.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return CM3D_ERR_LAUNCH;
+        int64_t rows = 0;
+        for (int f = 0; f < n_frames; ++f) {
+            const int n = ft[(size_t)f * FT_WORDS + 1], nwc = ft[(size_t)f * FT_WORDS + 7];
+            for (int c = 0; c < nwc && c < nwc_max; ++c)
+                if (info[(size_t)f * nwc_max + c] < 0) rows += std::min(PH_WC, n - c * PH_WC);
+        }
+        *rows_out = rows;
+    } catch (...) { return CM3D_ERR_ARG; }
+    return CM3D_OK;
 }
 
 // workgroups of the projection kernel the chip holds at once.  CM3D_PH_BLOCKS overrides (experiments).

@@ -576,6 +576,16 @@ class LiftEngine:
             self.run(masks=masks)
         return g
 
+    def hit_chunk_rows(self) -> int:
+        """Rows of the resident batch that lie in a 256-row block with at least one in-mask point after the last pass: the rows
+        whose hit words the projection wrote and the compaction read (bench.py's byte accounting; synchronises the stream)."""
+        import ctypes
+        b = self.b
+        out = ctypes.c_int64(0)
+        check(self.lib.cm3d_project_hit_rows(_ptr(b.pg_ws), b.pg_ws_bytes, b.F, b.max_pts, b.planes, ctypes.addressof(out),
+                                             torch.cuda.current_stream(self.dev).cuda_stream), "cm3d_project_hit_rows")
+        return int(out.value)
+
     # -- results
     def check_status(self):
         s = self.b.status.cpu().numpy()

@@ -135,6 +135,10 @@ int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int3
  *  ev_start, ev_stop: optional hipEvent_t (NULL = none), recorded on `stream` right before and after the projection
  *        kernel itself -- behind the small per-frame table kernel the call launches first -- for callers that time it */
 int64_t cm3d_project_workspace_bytes(int32_t n_frames, int32_t max_pts_per_frame, int32_t planes);
+/* Accounting aid for bench.py's byte counts (nothing on the path calls it; synchronous): rows of the batch that lie in a block of
+ * 256 rows with at least one in-mask point, read back from the workspace of the last cm3d_(sweep_)project_hits on `stream`. */
+int cm3d_project_hit_rows(const void *workspace, int64_t workspace_bytes, int32_t n_frames, int32_t max_pts_per_frame,
+                          int32_t planes, int64_t *rows_out, cm3d_stream_t stream);
 int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_frames, int32_t max_pts_per_frame,
                       int32_t n_points_total, const float *cams, int32_t n_cams, const int32_t *mask_off,
                       const int32_t *mask_cam, const int32_t *bbox, const uint32_t *packed, int32_t n_masks,
