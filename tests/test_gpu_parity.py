@@ -97,6 +97,35 @@ def test_colsum_bit_exact(oracle):
         assert np.array_equal(cs.view(np.uint32), got["colsum"][o:e].view(np.uint32)), f"mask {m} column sums differ"
 
 
+def test_hit_rows_of_the_byte_accounting(oracle):
+    """bench.py prices the hit words of the 256-row blocks that hold an in-mask point (the only ones the projection writes and
+    the compaction reads); `LiftEngine.hit_chunk_rows` reads the blocks' flags back.  Held to the oracle's index lists: compacted
+    index -> raw row of the frame through the removed-row bits, rows per block of 256."""
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config("c2")
+    frames = [syn.make_frame(cfg, 70 + i) for i in range(3)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 3000, seed=1)]
+    hb = lifting.pack_frames(frames, lanes, [0, 0, 0])
+    eng = lifting.LiftEngine()
+    eng.upload(hb)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    got_rows = eng.hit_chunk_rows()
+    removed = eng.removed_rows()
+    exp = oracle_batch(oracle, frames, lanes, [0, 0, 0], hb)
+    p_off = eng.b.pt_off.cpu().numpy()
+    want = 0
+    for f in range(3):
+        kept = np.flatnonzero(~removed[p_off[f]:p_off[f + 1]])           # raw row of every row of the reference's cloud
+        n = int(p_off[f + 1] - p_off[f])
+        blocks = set()
+        for m in range(hb.mask_off[f], hb.mask_off[f + 1]):
+            blocks.update((kept[exp["hit_idx"][exp["hit_off"][m]:exp["hit_off"][m + 1]]] // 256).tolist())
+        want += sum(min(256, n - 256 * c) for c in blocks)
+    assert 0 < want < int(p_off[-1]) and got_rows == want
+
+
 def test_waymo_shaped_frame(oracle):
     # C4 shape at reduced point count: 5 cameras, 1920x1280 masks, 64 beams
     hb, got, exp = _run("c4", 1, "rle", oracle, n_points=60000)
