@@ -500,6 +500,33 @@ static __device__ __forceinline__ void rw_one_runs(int run, const int (&v)[RW_PE
     }
 }
 
+#ifdef CM3D_DIAG
+// Diagnostic build only (tools/rw_diag.py): s_memtime at the start and the end of every mask's wave, its placement and its run count
+#define RW_DIAG_WAVES 32768
+__device__ int g_rw_diag;
+__device__ unsigned long long g_rw_wave[4 * RW_DIAG_WAVES];
+static __device__ __forceinline__ unsigned long long rw_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+extern "C" int cm3d_rw_diag_set(int flags)
+{
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rw_diag), &flags, sizeof(int)) != hipSuccess) return CM3D_ERR_LAUNCH;
+    void *wv = nullptr;
+    if (hipGetSymbolAddress(&wv, HIP_SYMBOL(g_rw_wave)) != hipSuccess || hipMemset(wv, 0, sizeof(g_rw_wave)) != hipSuccess) return CM3D_ERR_LAUNCH;
+    return hipDeviceSynchronize() == hipSuccess ? CM3D_OK : CM3D_ERR_LAUNCH;
+}
+extern "C" int cm3d_rw_diag_read_waves(unsigned long long *out_host, int n_waves)
+{
+    if (n_waves > RW_DIAG_WAVES) return CM3D_ERR_ARG;
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_rw_wave), 4 * (size_t)n_waves * sizeof(unsigned long long)) == hipSuccess ? CM3D_OK : CM3D_ERR_LAUNCH;
+}
+#endif
+
 __global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uint32_t *__restrict__ cnts_all, const int32_t *__restrict__ rle_off,
                                                                         int n_masks, int W, int H, int Wp, int lds_words,
                                                                         uint32_t *__restrict__ packed, int32_t *__restrict__ bbox, int max_bands, int diag)
@@ -510,6 +537,10 @@ __global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uin
     // max_bands > 1: one workgroup per mask, wave w its band w; 1: four masks per workgroup, one wave each
     const int m = max_bands > 1 ? (int)blockIdx.x : (int)blockIdx.x * RW_WAVES + wave;
     if (m >= n_masks) return;                                   // (max_bands == 1 only; such a workgroup meets no barrier)
+#ifdef CM3D_DIAG
+    const int wdiag = g_rw_diag;
+    const unsigned long long t_start = wdiag ? rw_now() : 0ull;
+#endif
     const int band = max_bands > 1 ? wave : 0;
     uint32_t *s_rows = s_all + (size_t)wave * lds_words;
     const int o = rle_off[m], n = rle_off[m + 1] - o;
@@ -665,6 +696,13 @@ __global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uin
     }
     }
     bminx = cm3d_wave_min(bminx); bminy = cm3d_wave_min(bminy); bmaxx = cm3d_wave_max(bmaxx); bmaxy = cm3d_wave_max(bmaxy);
+#ifdef CM3D_DIAG
+    if (wdiag && lane == 0 && band == 0 && m < RW_DIAG_WAVES) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        g_rw_wave[4 * m] = t_start; g_rw_wave[4 * m + 1] = rw_now();
+        g_rw_wave[4 * m + 2] = ((unsigned long long)xcc << 32) | hw; g_rw_wave[4 * m + 3] = (unsigned long long)n;
+    }
+#endif
     if (nb == 1) {                              // uniform over the workgroup (or max_bands == 1): one band, no hand-over
         if (band == 0 && lane < 4) bbox[4 * m + lane] = lane == 0 ? bminx : lane == 1 ? bminy : lane == 2 ? bmaxx : bmaxy;
         return;
