@@ -8,7 +8,7 @@
 // of the reference's behaviour and is reproduced, not fixed.)
 // Column j lives in one thread and is summed over rows i in ascending order, so the float32
 // column sums do not depend on the launch geometry.  A tile = 64 columns of one mask = one wave; rows are
-// staged through LDS 512 at a time and read back as wave-wide broadcasts, 8 rows per step in packed
+// staged through LDS 256 at a time and read back as wave-wide broadcasts, 8 rows per step in packed
 // float32.  VALU-bound (about 14 issue slots per pair incl. the correctly rounded sqrt); nothing M x M ever
 // touches HBM.  The tiles are worked longest lists first (worklist.h).
 #include "common.h"
@@ -20,7 +20,11 @@
 #endif
 #define MD_THREADS (MD_WAVES * 64)
 #ifndef MD_STAGE
-#define MD_STAGE 512                     // rows of a list staged in a wave's LDS slice at a time (8 KiB)
+// rows of a list staged in a wave's LDS slice at a time (4 KiB).  512 held 32 VGPRs of gathered rows and 32 KiB of LDS per workgroup:
+// alone the launch runs as fast with 256 or 128 (C2 44.5 / 44.8 against 45.3 us), and with three batches in flight the smaller
+// footprint (80 VGPRs instead of 96, half the LDS) is worth 2-3 % of the pass (0.154-0.156 -> 0.151 ms).  Not below MDA_STAGE:
+// the matrix-pipe first pass stages its rows in the same slice.
+#define MD_STAGE 256
 #endif
 
 #ifndef MD_LONG_MIN
@@ -309,6 +313,7 @@ static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float
 // second pass.  A 64-column tile = two 32-column MFMA tiles, one wave (k_medoid_tiles); rows staged through its LDS slice as
 // {-2x, -2z, -2y, n}: lanes 0-31 feed k even (x, z, the 1), lanes 32-63 k odd (y, n, 0).
 #define MDA_STAGE 256
+static_assert(MD_STAGE >= MDA_STAGE, "md_approx_tile stages MDA_STAGE rows in a wave's slice of MD_STAGE rows");
 static __device__ __forceinline__ float md_vsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 template <typename Fetch>
@@ -430,8 +435,8 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
             md_approx_tile(fetch, reinterpret_cast<float *>(s_row), off, M, jt, approx_opt);
             continue;
         }
-        // Rows are staged MD_STAGE (512) at a time: all their index loads, then all their point gathers are in
-        // flight together (two memory latencies per 512 rows; a 64-row pipeline left the longest lists -- the
+        // Rows are staged MD_STAGE (256) at a time: all their index loads, then all their point gathers are in
+        // flight together (two memory latencies per 256 rows; a 64-row pipeline left the longest lists -- the
         // waves the kernel waits for -- bound by one dependent gather per chunk).
         for (int i0 = 0; i0 < M; i0 += MD_STAGE) {
             __builtin_amdgcn_wave_barrier();                  // the previous rows' readers are done
