@@ -780,8 +780,13 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
         CM3D_CHECK_LAUNCH();
         desc = own;
     }
+    // The number of tiles is only known on the device.  A workgroup without a tile leaves after one load, but the chip still has to
+    // dispatch it -- twice, once per instantiation: on the headline shape (5120 masks, 8 k tiles) a grid of 4096 against 2048 is
+    // 1.6 % of the pass with three batches in flight; batches of long lists (C1, C5: 50-400 k tiles) want the large grid, whose
+    // workgroups the hardware hands out as others finish (C5: 2048 workgroups +2 %, 1024 +7 % on the stage).  Half a workgroup
+    // per mask lies between the two.
     int grid = (tile_cap + MD_WAVES - 1) / MD_WAVES;
-    int gmax = 4096;
+    int gmax = n_masks / 2 < 1024 ? 1024 : (n_masks / 2 > 4096 ? 4096 : n_masks / 2);
     if (const char *e = getenv("CM3D_MD_GRID")) gmax = atoi(e);
     if (grid > gmax) grid = gmax;
     hipLaunchKernelGGL(k_medoid_tiles<false>, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,

@@ -1079,9 +1079,11 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *
                                                              int32_t *__restrict__ hit_off, int32_t *__restrict__ tile_off, int tile_cap,
                                                              TileDesc *__restrict__ tile_work, int32_t *__restrict__ status)
 {
-    __shared__ __align__(8) int s_run_all[PH_WAVES][CM3D_MAX_MASKS_PER_FRAME];      // per wave: next output position of every mask of the frame
+    // per wave: next output position of every mask the table allows per frame (nm_cap: 128 bytes per wave on the headline shape;
+    // a fixed [CM3D_MAX_MASKS_PER_FRAME] slice was 16 KiB per workgroup, LDS the kernels of the other batches in flight could not use)
+    extern __shared__ __align__(8) int s_run_dyn[];
     if (blockIdx.y == 0) {
-        md_build_from_counts<PH_THREADS>(n_masks, hit_count, idx_cap, tile_cap, hit_off, tile_off, tile_work, status, &s_run_all[0][0],
+        md_build_from_counts<PH_THREADS>(n_masks, hit_count, idx_cap, tile_cap, hit_off, tile_off, tile_work, status, s_run_dyn,
                                          (int)blockIdx.x, (int)gridDim.x);
         return;
     }
@@ -1097,7 +1099,7 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *
     if (!has) return;
     const int p0 = ft[0], n = ft[1], m0 = ft[2], nm = ft[3], sa = ft[4], ns = ft[5], bits_off = ft[6], fused = ft[FT_FUSED];
     const int planes = (nm + 31) >> 5;
-    int *s_run = s_run_all[wave];
+    int *s_run = s_run_dyn + (size_t)wave * nm_cap;
     const int g = c0 / PH_GRP, cg0 = g * PH_GRP;                       // the wave's group; its first wave-chunk
     const int32_t *grp_f = grp + (size_t)f * zstride;
     const int ngrp_max = (nwc_max + PH_GRP - 1) / PH_GRP;
@@ -1540,9 +1542,11 @@ extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int3
     xs.raw = raw; xs.raw_stride = raw_stride; xs.sweep_xf = sweep_xf; xs.points = (const float4 *)points;
     static int span = 0;
     if (!span) { const char *e = getenv("CM3D_CP_SPAN"); span = e ? atoi(e) : 4; if (span != 2 && span != 8) span = 4; }
+    // dynamic LDS: a slice of nm_cap ints per wave; the builder row needs MD_FROM_COUNTS_LDS ints
+    const size_t cp_lds = sizeof(int) * (size_t)std::max(PH_WAVES * nm_cap, (int)MD_FROM_COUNTS_LDS(PH_THREADS));
 #define CP_LAUNCH(SPAN)                                                                                                          \
     hipLaunchKernelGGL(k_compact_hits<SPAN>, dim3(((nwc_max + SPAN - 1) / SPAN + PH_WAVES - 1) / PH_WAVES, n_frames + 1),         \
-                       dim3(PH_THREADS), 0, st, hit_words, n_points_total, ws.ft, nm_cap, nwc_max, ws.wc_cnt, ws.wc_info, ws.grp,   \
+                       dim3(PH_THREADS), cp_lds, st, hit_words, n_points_total, ws.ft, nm_cap, nwc_max, ws.wc_cnt, ws.wc_info, ws.grp,   \
                        ws.zstride, ws.frame_hits, hit_count, removed_bits, xs, hit_idx, hit_row, (float4 *)hit_xyz, idx_cap,     \
                        n_frames, n_masks, hit_off, tile_off, tile_cap, (TileDesc *)tile_work, status)
     if (span == 8) CP_LAUNCH(8);
