@@ -315,62 +315,115 @@ static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float
 #define MDA_STAGE 256
 static_assert(MD_STAGE >= MDA_STAGE, "md_approx_tile stages MDA_STAGE rows in a wave's slice of MD_STAGE rows");
 static __device__ __forceinline__ float md_vsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// v_sqrt_f32 with the output clamp: the result is held to [0, 1] and a NaN (the root of a negative value) becomes 0 (DX10_CLAMP, on
+// in every kernel of this library) -- clamp_min_(0) and the root in ONE instruction for values known to be <= 1
+static __device__ __forceinline__ float md_vsqrt_clamp01(float x)
+{
+    float r;
+    asm("v_sqrt_f32_e64 %0, %1 clamp" : "=v"(r) : "v"(x));
+    return r;
+}
+// Scaled form of the first pass.  Coordinates times s = 2^-16 scale every product, every sum and every rounding of the chain by
+// exactly s^2 = 2^-32 and its root by exactly s (powers of four in, powers of two out: no rounding changes as long as nothing
+// underflows), so the sums come out as s times the unscaled ones, bit for bit -- and with all distances <= 2^16 m the scaled roots
+// are <= 1, which is what lets md_vsqrt_clamp01 do the clamp.  MDA_N_MAX bounds the squared norms of rows and columns
+// (|p_i - p_j| <= |p_i| + |p_j| <= 2 sqrt(1e9) = 63.2 km, 0.965 after scaling, expansion noise of 64 m^2 included);
+// MDA_N_MIN keeps products of coordinates away from the denormals (a norm of exactly 0 is a point at the origin: all its
+// products are exact zeros).  What is left of underflow inside a chain (one coordinate of 1e-20 m beside another of a metre) is
+// below 4e-29 in the squared distance, 6e-15 in a root: k_medoid_long's bound allows 2e-14 per term.  Chunks of rows or tiles
+// of columns outside these bounds (30 km from the map origin, say) take the unscaled form with the integer clamp.
+#define MDA_S 1.52587890625e-05f
+#define MDA_S2 2.3283064365386963e-10f
+#define MDA_N_MAX 1.0e9f
+#define MDA_N_MIN 1.0e-10f
+static __device__ __forceinline__ bool mda_norm_ok(float n) { return n == 0.0f || (n >= MDA_N_MIN && n < MDA_N_MAX); }
 
 template <typename Fetch>
 static __device__ __forceinline__ void md_approx_tile(Fetch fetch, float *s_rows, int off, int M, int jt, float *__restrict__ approx_out)
 {
     const int lane = cm3d_lane();
     const bool lo = lane < 32;
-    // column operands of the two 32-column groups: lanes 0-31 carry (x, z, n), lanes 32-63 (y, 1, 0)
+    // column operands of the two 32-column groups, SCALED: lanes 0-31 carry (x s, z s, n s^2), lanes 32-63 (y s, 1, 0)
     float b1[2], b2[2], b3[2];
+    bool cols_ok = true;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int j = jt * 64 + g * 32 + (lane & 31);
         float qx = 0.f, qy = 0.f, qz = 0.f;
         if (j < M) { const float4 q = fetch(off + j); qx = q.x; qy = q.y; qz = q.z; }
         const float qn = (qx * qx + qy * qy) + qz * qz;
-        b1[g] = lo ? qx : qy; b2[g] = lo ? qz : 1.0f; b3[g] = lo ? qn : 0.0f;
+        cols_ok &= mda_norm_ok(qn);
+        b1[g] = (lo ? qx : qy) * MDA_S; b2[g] = lo ? qz * MDA_S : 1.0f; b3[g] = lo ? qn * MDA_S2 : 0.0f;
     }
-    float s[2] = {0.f, 0.f};
+    cols_ok = !__ballot(!cols_ok);                            // (uniform)
+    float s[2] = {0.f, 0.f};                                  // in units of s
     for (int i0 = 0; i0 < M; i0 += MDA_STAGE) {
         __builtin_amdgcn_wave_barrier();                      // the previous rows' readers are done
         float4 g4[MDA_STAGE / 64];
 #pragma unroll
         for (int c = 0; c < MDA_STAGE / 64; ++c)
             if (i0 + c * 64 + lane < M) g4[c] = fetch(off + i0 + c * 64 + lane);
+        float4 rr[MDA_STAGE / 64];
+        bool rows_ok = true;
 #pragma unroll
         for (int c = 0; c < MDA_STAGE / 64; ++c) {
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);       // rows past the end: all zeros, and their k = 4 factor is 0 too
+            rr[c] = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past the end: all zeros, and their k = 4 factor is 0 too
             if (i0 + c * 64 + lane < M) {
                 const float4 p = g4[c];
-                r = make_float4(-2.0f * p.x, -2.0f * p.z, -2.0f * p.y, (p.x * p.x + p.y * p.y) + p.z * p.z);
+                rr[c] = make_float4(-2.0f * p.x, -2.0f * p.z, -2.0f * p.y, (p.x * p.x + p.y * p.y) + p.z * p.z);
+                rows_ok &= mda_norm_ok(rr[c].w);
             }
+        }
+        const bool scaled = cols_ok && !__ballot(!rows_ok);   // (uniform) this chunk of rows in the scaled form
+#pragma unroll
+        for (int c = 0; c < MDA_STAGE / 64; ++c) {
+            float4 r = rr[c];
+            if (scaled) r = make_float4(r.x * MDA_S, r.y * MDA_S, r.z * MDA_S, r.w * MDA_S2);
             *reinterpret_cast<float4 *>(s_rows + 4 * (c * 64 + lane)) = r;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int cnt = min(MDA_STAGE, M - i0);
-        for (int r0 = 0; r0 < cnt; r0 += 32) {
-            const int row = r0 + (lane & 31);
-            const float2 a = *reinterpret_cast<const float2 *>(s_rows + 4 * row + (lo ? 0 : 2));
-            const float a3 = (lo && row < cnt) ? 1.0f : 0.0f;
+        if (scaled) {
+            for (int r0 = 0; r0 < cnt; r0 += 32) {
+                const int row = r0 + (lane & 31);
+                const float2 a = *reinterpret_cast<const float2 *>(s_rows + 4 * row + (lo ? 0 : 2));
+                const float a3 = (lo && row < cnt) ? 1.0f : 0.0f;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[g], c, 0, 0, 0);        // k = 0, 1
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b2[g], c, 0, 0, 0);        // k = 2, 3
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3[g], c, 0, 0, 0);         // k = 4, (5: 0 * 0)
+                for (int g = 0; g < 2; ++g) {
+                    f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[g], c, 0, 0, 0);        // k = 0, 1
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b2[g], c, 0, 0, 0);        // k = 2, 3
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3[g], c, 0, 0, 0);         // k = 4, (5: 0 * 0)
 #pragma unroll
-                // clamp_min_(0) as a signed-integer maximum on the bits (negative values and -0 -> +0, everything else unchanged;
-                // one instruction where fmaxf() on a matrix-pipe result costs two: it is canonicalised first), root, this lane's rows
-                for (int q = 0; q < 16; ++q) s[g] += md_vsqrt(__int_as_float(max(__float_as_int(c[q]), 0)));
+                    for (int q = 0; q < 16; ++q) s[g] += md_vsqrt_clamp01(c[q]);             // clamp_min_(0) and root in one, this lane's rows
+                }
+            }
+        } else {
+            // the unscaled form (rare): operands back to their own scale (exact unless a coordinate underflowed when it was scaled: such
+            // a column has a norm below MDA_N_MIN), clamp_min_(0) as a signed-integer maximum on the bits (negative values and -0 -> +0;
+            // fmaxf() on a matrix-pipe result costs two instructions, it is canonicalised first), the root brought to the sums' scale
+            for (int r0 = 0; r0 < cnt; r0 += 32) {
+                const int row = r0 + (lane & 31);
+                const float2 a = *reinterpret_cast<const float2 *>(s_rows + 4 * row + (lo ? 0 : 2));
+                const float a3 = (lo && row < cnt) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float u1 = b1[g] * 65536.0f, u2 = lo ? b2[g] * 65536.0f : 1.0f, u3 = b3[g] * 4294967296.0f;
+                    f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, u1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, u2, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, u3, c, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) s[g] += md_vsqrt(__int_as_float(max(__float_as_int(c[q]), 0))) * MDA_S;
+                }
             }
         }
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const float tot = s[g] + __shfl_xor(s[g], 32, 64);   // the two halves of the rows of column lane & 31
+        const float tot = (s[g] + __shfl_xor(s[g], 32, 64)) * 65536.0f;     // the two halves of the rows of column lane & 31; back to metres
         const int j = jt * 64 + g * 32 + lane;
         if (lo && j < M) approx_out[off + j] = tot;
     }
@@ -541,7 +594,8 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
 // rounded ones, summed in some order.  With t_i the exact and t'_i the approximate terms (|t'_i - t_i| <= 2^-23 t_i, or
 // <= 1e-15 below 1e-30) and float32 sums of non-negative terms (each add rounds by <= 2^-24 of a partial sum, and partial
 // sums never exceed the final sum, whatever the order), |A_j - S_j| <= (2^-23 sum_i t_i + M 1e-15) + M 2^-24 (A_j + S_j) up to
-// factors 1 + O(M 2^-24); solved for A_j this stays below E_j = 1.01 (M + 2) 2^-23 A_j + M 2e-15 for M < 10^5.  A column can
+// factors 1 + O(M 2^-24); solved for A_j this stays below E_j = 1.01 (M + 2) 2^-23 A_j + M 2e-15 for M < 10^5 (M 2e-14 is what the code allows: the
+// scaled form of the first pass, md_approx_tile, may lose 6e-15 per term to underflow inside a chain).  A column can
 // only be the (first) minimum of the exact sums if A_j - E_j <= min_k (A_k + E_k); those few columns -- the points within
 // centimetres of the medoid -- get their exact float32 sums here.  A non-finite A_j makes every column a candidate; lists
 // of 10^5 points and more stay on the one-pass route.
@@ -612,7 +666,7 @@ __global__ __launch_bounds__(64 * MDL_WAVES, 2) void k_medoid_long(const float4 
     const float4 *P = hit_row ? points + pt_off[mask_frame[m]] : points;
     auto fetch = [&](int q) { return hit_row ? P[hit_row[q]] : P[q]; };
     const float *A = approx + off;
-    const double rel = 1.01 * (double)(M + 2) * 1.1920928955078125e-07, abs_e = (double)M * 2e-15;
+    const double rel = 1.01 * (double)(M + 2) * 1.1920928955078125e-07, abs_e = (double)M * 2e-14;
     auto better = [](float s1, int j1, float s2, int j2) {   // is (s1,j1) ahead of (s2,j2)?  (torch.argmin order)
         const bool n1 = s1 != s1, n2 = s2 != s2;
         if (n1 != n2) return n1;

@@ -334,6 +334,36 @@ def test_two_pass_medoid_on_near_ties(oracle):
         assert got == want, name
 
 
+def test_first_pass_forms_of_the_long_lists(oracle):
+    """The matrix-pipe first pass of lists longer than 512 points runs on coordinates scaled by 2^-16 (root and clamp_min_ in one
+    instruction, csrc/medoid.hip md_approx_tile) wherever the squared norms of a chunk's rows and a tile's columns lie in
+    {0} or [1e-10, 1e9), and unscaled elsewhere.  Lists on both sides of every bound, and lists that mix the forms chunk by chunk
+    (256 rows) and tile by tile (64 columns): the position must be the one the exact one-pass route and the oracle find."""
+    from cm3d_amd import ops
+    rng = np.random.default_rng(5)
+
+    def cloud(centre, n, spread=(1.5, 0.8, 0.4)):
+        return np.asarray(centre, np.float64) + rng.normal(0, spread, (n, 3))
+    cases = {
+        "vehicle frame (norms of a few m^2)": cloud([8.0, -3.0, 0.5], 900),
+        "1.7 km": cloud([612.0, 1634.0, 1.5], 1400),
+        "31 km: norms just below 1e9": cloud([22000.0, 22300.0, 1.5], 800),
+        "32 km: norms just above 1e9, unscaled": cloud([22400.0, 22400.0, 1.5], 800),
+        "60 km": cloud([42000.0, 43000.0, 2.0], 700),
+        "the origin and points within a micrometre of it among ordinary ones": np.concatenate(
+            [cloud([8.0, -3.0, 0.5], 300), np.zeros((2, 3)), rng.normal(0, 3e-7, (5, 3)), cloud([8.0, -3.0, 0.5], 500)]),
+        "a far chunk of rows behind near ones": np.concatenate([cloud([612.0, 1634.0, 1.5], 600), cloud([30000.0, 30000.0, 1.5], 300)]),
+    }
+    for name, pts in cases.items():
+        p32 = np.ascontiguousarray(pts.astype(np.float32))
+        assert p32.shape[0] > 512
+        want = oracle.medoid(np.concatenate([p32, np.zeros((len(p32), 1), np.float32)], 1), np.arange(len(p32)))
+        exact, _ = ops.get_medoid(p32.T, want_colsum=True)
+        got = ops.get_medoid(p32.T)
+        assert exact == want, name
+        assert got == want, name
+
+
 def test_every_route_of_the_medoid_root_equals_the_oracle(oracle):
     """k_medoid_tiles takes the root of a step of squared distances on one of four routes (csrc/medoid.hip md_rows): without any
     test when the norms of the list prove every value to be 0 or inside [1e-30, 1e30) (SAFE), packed after a test of the
