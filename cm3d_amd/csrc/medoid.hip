@@ -196,7 +196,20 @@ static __device__ __forceinline__ float md_asqrt(float x) { return x < 1.0e-30f 
 static __device__ __forceinline__ bool md_col_safe(float qn) { return qn >= 1.0e-22f && qn < 2.0e29f; }
 static __device__ __forceinline__ bool md_row_safe(float n) { return n < 2.0e29f; }
 
-template <bool DIRECT, bool APPROX = false, bool SAFE = false>
+// v_pk_add_f32 with the output clamp: both halves held to [0, 1], a NaN becomes 0 (DX10_CLAMP; tools/ubench/pk_clamp.hip shows the
+// chip doing it).  On coordinates scaled by 2^-16 (md_approx_tile's comment: every value of the chain scales by exactly 2^-32, every
+// distance by 2^-16, and all of them are below 1) the LAST addition of the expansion, + n_j, does clamp_min_(0) on the way.
+static __device__ __forceinline__ f2 md_pk_add_clamp01(f2 a, f2 b)
+{
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// SCALED (with SAFE): rows and column are scaled by 2^-16 (norms by 2^-32) and every squared distance is below 1 -- the caller has
+// checked the norms (mda_norm_ok) --, so clamp_min_(0) rides on the last addition and the 8 v_max_f32 of a step are gone; s is in
+// scaled units.
+template <bool DIRECT, bool APPROX = false, bool SAFE = false, bool SCALED = false>
 static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float qx, float qy, float qz, float qn, float s)
 {
 #ifndef MD_U
@@ -232,10 +245,16 @@ static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float
             for (int u = 0; u < U; ++u) d[u] = PK_FMA(((f2){B[u].x, B[u].y}), (f2)(qz), d[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) d[u] = d[u] + (f2){B[u].z, B[u].w};                     // fma(n_i, 1, acc)
+            if (SCALED) {
+                const f2 qn2 = (f2)(qn);
 #pragma unroll
-            for (int u = 0; u < U; ++u) d[u] = d[u] + qn;                                       // fma(1, n_j, acc)
+                for (int u = 0; u < U; ++u) d[u] = md_pk_add_clamp01(d[u], qn2);                // fma(1, n_j, acc) and clamp_min_(0)
+            } else {
 #pragma unroll
-            for (int u = 0; u < U; ++u) d[u] = __builtin_elementwise_max(d[u], (f2)(0.0f));     // clamp_min_(0): v_pk_max_f32
+                for (int u = 0; u < U; ++u) d[u] = d[u] + qn;                                   // fma(1, n_j, acc)
+#pragma unroll
+                for (int u = 0; u < U; ++u) d[u] = __builtin_elementwise_max(d[u], (f2)(0.0f)); // clamp_min_(0)
+            }
         }
         if (SAFE && !DIRECT && !APPROX) {
 #pragma unroll
@@ -482,6 +501,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
         }
         float s = 0.f;
         const bool col_safe = !__ballot(act && !md_col_safe(qn));
+        const bool col_scal = !__ballot(act && !mda_norm_ok(qn));           // the column side of the scaled form (md_rows<.., SCALED>)
         const bool direct = M <= 25;
         const bool approx = approx_opt != nullptr && md_two_pass(M);      // long list: approximate sums (k_medoid_approx), k_medoid_long later
         if (WITH_LONG && approx && MD_APPROX_MFMA) {
@@ -494,7 +514,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
         for (int i0 = 0; i0 < M; i0 += MD_STAGE) {
             __builtin_amdgcn_wave_barrier();                  // the previous rows' readers are done
             float4 g[MD_STAGE / 64];
-            bool rows_safe = true;
+            bool rows_safe = true, rows_scal = true;
 #pragma unroll
             for (int c = 0; c < MD_STAGE / 64; ++c)
                 if (i0 + c * 64 + lane < M) g[c] = fetch(off + i0 + c * 64 + lane);
@@ -504,8 +524,19 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
                     float4 r = g[c];
                     r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
                     rows_safe &= md_row_safe(r.w);
+                    rows_scal &= mda_norm_ok(r.w);
                     // the expansion branch only ever needs -2x, -2y, -2z of a row (exact products)
                     if (!direct) { r.x = -2.0f * r.x; r.y = -2.0f * r.y; r.z = -2.0f * r.z; }
+                    g[c] = r;
+                }
+            }
+            // this chunk in the scaled form (md_rows<.., SCALED>)?  (uniform)
+            const bool scaled = !direct && !approx && col_scal && !__ballot(!rows_scal);
+#pragma unroll
+            for (int c = 0; c < MD_STAGE / 64; ++c) {
+                if (i0 + c * 64 + lane < M) {
+                    float4 r = g[c];
+                    if (scaled) r = make_float4(r.x * MDA_S, r.y * MDA_S, r.z * MDA_S, r.w * MDA_S2);
                     md_stage(s_row, c * 64 + lane, r);
                 }
             }
@@ -525,9 +556,12 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
             if (diag && i0 == 0) t_staged = md_now();
 #endif
             const bool safe = col_safe && !__ballot(!rows_safe);
-            s = direct ? md_rows<true>(s_row, cnt, qx, qy, qz, qn, s)
-                       : (approx ? md_rows<false, true>(s_row, cnt, qx, qy, qz, qn, s)
-                                 : (safe ? md_rows<false, false, true>(s_row, cnt, qx, qy, qz, qn, s) : md_rows<false>(s_row, cnt, qx, qy, qz, qn, s)));
+            if (scaled)         // s goes in and comes out in its own units: the powers of two are exact both ways
+                s = md_rows<false, false, true, true>(s_row, cnt, qx * MDA_S, qy * MDA_S, qz * MDA_S, qn * MDA_S2, s * MDA_S) * 65536.0f;
+            else
+                s = direct ? md_rows<true>(s_row, cnt, qx, qy, qz, qn, s)
+                           : (approx ? md_rows<false, true>(s_row, cnt, qx, qy, qz, qn, s)
+                                     : (safe ? md_rows<false, false, true>(s_row, cnt, qx, qy, qz, qn, s) : md_rows<false>(s_row, cnt, qx, qy, qz, qn, s)));
         }
         if (approx) {
             if (act) approx_opt[off + j] = s;
