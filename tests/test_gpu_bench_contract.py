@@ -31,8 +31,13 @@ def test_lifting_bench_line():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "traffic" in rf
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
-    # bytes = what must move: rows x (raw row + hit word), nothing the kernel skips; no fraction anywhere above 1
-    assert rf["bytes_per_launch"] == rf["rows_per_launch"] * rf["bytes_per_row"] and rf["bytes_per_row"] == 4 * 5 + 4
+    # bytes = what must move: every raw row (20 B) + a hit word (4 B) for the rows of 256-row blocks that hold an in-mask point -- the
+    # only hit words the launch writes; nothing the kernel skips is counted; no fraction anywhere above 1
+    rows, nbytes = rf["rows_per_launch"], rf["bytes_per_launch"]
+    assert (nbytes - 20 * rows) % 4 == 0 and 0 < (nbytes - 20 * rows) // 4 <= rows
+    assert abs(rf["bytes_per_row"] - nbytes / rows) < 0.01 and 20 < rf["bytes_per_row"] <= 24
+    md = d["kernels"]["medoid"]
+    assert md["bound"] == "valu" and 0 < md["frac"] < 1 and 3.5 <= md["algorithmic_slots_per_pair"] <= 11.0
     assert d["config"]["cloud_materialised"] is False and d["ranks_in_group"] == 1
 
     def fracs(o):
