@@ -464,9 +464,11 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
                                                               const int32_t *__restrict__ hit_row,
                                                               const TileDesc *__restrict__ desc,
                                                               TileBest *__restrict__ tile_best, int tile_cap,
-                                                              float *__restrict__ colsum_opt, float *__restrict__ approx_opt)
+                                                              float *__restrict__ colsum_opt, float *__restrict__ approx_opt,
+                                                              int32_t *__restrict__ long_list)
 {
     __shared__ float4 s_row_all[MD_WAVES][MD_STAGE];
+    if (!WITH_LONG && blockIdx.x == 0 && threadIdx.x == 0) long_list[0] = 0;      // k_medoid_reduce counts the long masks into it
     const int wave = threadIdx.x >> 6, lane = cm3d_lane();
 #ifdef CM3D_DIAG
     const int diag = g_md_diag & 1;
@@ -601,11 +603,24 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
                                                        const int32_t *__restrict__ tile_off,
                                                        const int32_t *__restrict__ hit_row, int idx_cap,
                                                        const TileBest *__restrict__ tile_best, int tile_cap, int two_pass,
+                                                       int32_t *__restrict__ long_list,
                                                        int32_t *__restrict__ medoid_pos, float *__restrict__ centroid)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_masks) return;
-    if (two_pass && md_two_pass(hit_off[m + 1] - hit_off[m])) return;      // k_medoid_long's
+    // k_medoid_long's masks go on its list (long_list[0] = how many, zeroed by the tile kernel; then the mask numbers, in whatever
+    // order the atomics make it): its workgroups then share the long masks evenly -- walking ALL masks in strides of the grid gave
+    // a workgroup as many long masks as chance would have it (C1: 1.1 on average, 5 or 6 at most, and the launch lasts as long as those)
+    const bool is_long = two_pass && m < n_masks && md_two_pass(hit_off[m + 1] - hit_off[m]);
+    {
+        const uint64_t lm = __ballot(is_long);
+        if (lm) {
+            int base = 0;
+            if (cm3d_lane() == 0) base = atomicAdd(&long_list[0], (int)__popcll(lm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (is_long) long_list[1 + base + cm3d_mbcnt(lm)] = m;
+        }
+    }
+    if (m >= n_masks || is_long) return;
     const int t0 = tile_off[m], t1 = min(tile_off[m + 1], tile_cap);
     int bj = -1;
     float bs = 0.f;
@@ -681,7 +696,7 @@ static __device__ __forceinline__ float md_exact_colsum_rows(Fetch fetch, int of
 __global__ __launch_bounds__(64 * MDL_WAVES, 2) void k_medoid_long(const float4 *__restrict__ points, const int32_t *__restrict__ pt_off,
                                                                 const int32_t *__restrict__ mask_frame, int n_masks,
                                                                 const int32_t *__restrict__ hit_off, const int32_t *__restrict__ hit_row,
-                                                                int idx_cap, const float *__restrict__ approx,
+                                                                int idx_cap, const float *__restrict__ approx, const int32_t *__restrict__ long_list,
                                                                 int32_t *__restrict__ medoid_pos, float *__restrict__ centroid)
 {
     __shared__ float4 s_row[MD_STAGE];
@@ -692,8 +707,10 @@ __global__ __launch_bounds__(64 * MDL_WAVES, 2) void k_medoid_long(const float4 
     __shared__ int s_n, s_all;
     const int lane = cm3d_lane(), t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // a workgroup walks masks blockIdx.x, + gridDim.x, ...: most lists are short and cost one scalar load here
-    for (int m = blockIdx.x; m < n_masks; m += gridDim.x) {
+    // a workgroup takes entries blockIdx.x, + gridDim.x, ... of the list of long masks (k_medoid_reduce)
+    const int n_long = min(long_list[0], n_masks);
+    for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
+    const int m = long_list[1 + li];
     const int off = hit_off[m], M = hit_off[m + 1] - off;
     if (!md_two_pass(M) || off + M > idx_cap) continue;                    // the whole workgroup
     __syncthreads();                                                       // the previous long mask's LDS state is done with
@@ -841,7 +858,9 @@ extern "C" int64_t cm3d_medoid_workspace_bytes(int32_t n_masks, int32_t idx_cap)
 {
     if (n_masks <= 0 || idx_cap <= 0) return 0;
     // work list + per-tile results + the first-pass column sums of the long lists
-    return md_tile_cap(n_masks, idx_cap) * (int64_t)(sizeof(TileBest) + sizeof(TileDesc)) + (int64_t)idx_cap * (int64_t)sizeof(float);
+    // ... + the list of the long masks (count, then mask numbers: k_medoid_reduce -> k_medoid_long)
+    return md_tile_cap(n_masks, idx_cap) * (int64_t)(sizeof(TileBest) + sizeof(TileDesc)) + (int64_t)idx_cap * (int64_t)sizeof(float) +
+           ((int64_t)n_masks + 4) * (int64_t)sizeof(int32_t);
 }
 
 extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_frame, int32_t n_masks,
@@ -862,6 +881,7 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     static int two_pass_env = -1;
     if (two_pass_env < 0) { const char *e = getenv("CM3D_MD_TWO_PASS"); two_pass_env = e ? atoi(e) : 1; }
     float *approx = (two_pass_env && !colsum_opt) ? (float *)(best + tile_cap) : nullptr;
+    int32_t *long_list = (int32_t *)((float *)(best + tile_cap) + idx_cap);         // [0] = number of long masks, then their numbers
     const TileDesc *desc = (const TileDesc *)tile_work;
     if (!desc) {                                   // no work list from cm3d_compact_hits: build it here
         hipLaunchKernelGGL(k_medoid_desc, dim3(1), dim3(1024), 0, st, n_masks, hit_off, tile_off, idx_cap, tile_cap, own);
@@ -878,19 +898,19 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     if (const char *e = getenv("CM3D_MD_GRID")) gmax = atoi(e);
     if (grid > gmax) grid = gmax;
     hipLaunchKernelGGL(k_medoid_tiles<false>, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
-                       tile_off, hit_row, desc, best, tile_cap, colsum_opt, approx);
+                       tile_off, hit_row, desc, best, tile_cap, colsum_opt, approx, long_list);
     CM3D_CHECK_LAUNCH();
     if (approx) {             // (without a first pass -- colsum_opt, CM3D_MD_TWO_PASS=0 -- the light instantiation takes every batch)
         hipLaunchKernelGGL(k_medoid_tiles<true>, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
-                           tile_off, hit_row, desc, best, tile_cap, colsum_opt, approx);
+                           tile_off, hit_row, desc, best, tile_cap, colsum_opt, approx, long_list);
         CM3D_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_medoid_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, (const float4 *)points, pt_off, mask_frame,
-                       n_masks, hit_off, tile_off, hit_row, idx_cap, best, tile_cap, approx ? 1 : 0, medoid_pos, centroid);
+                       n_masks, hit_off, tile_off, hit_row, idx_cap, best, tile_cap, approx ? 1 : 0, long_list, medoid_pos, centroid);
     CM3D_CHECK_LAUNCH();
     if (approx) {
         hipLaunchKernelGGL(k_medoid_long, dim3(n_masks < 1024 ? n_masks : 1024), dim3(64 * MDL_WAVES), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks, hit_off,
-                           hit_row, idx_cap, approx, medoid_pos, centroid);
+                           hit_row, idx_cap, approx, long_list, medoid_pos, centroid);
         CM3D_CHECK_LAUNCH();
     }
     return CM3D_OK;
