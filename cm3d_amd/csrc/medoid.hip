@@ -351,6 +351,11 @@ static __device__ __forceinline__ float md_vsqrt_clamp01(float x)
 // products are exact zeros).  What is left of underflow inside a chain (one coordinate of 1e-20 m beside another of a metre) is
 // below 4e-29 in the squared distance, 6e-15 in a root: k_medoid_long's bound allows 2e-14 per term.  Chunks of rows or tiles
 // of columns outside these bounds (30 km from the map origin, say) take the unscaled form with the integer clamp.
+#if defined(__gfx950__) || !defined(__HIP_DEVICE_COMPILE__)
+#define MD_SCALED_ROUTES 1               // verified on gfx950 (cm3d_selftest_mfma at every engine start; tools/ubench/pk_clamp.hip)
+#else
+#define MD_SCALED_ROUTES 0               // any other target: the unscaled forms
+#endif
 #define MDA_S 1.52587890625e-05f
 #define MDA_S2 2.3283064365386963e-10f
 #define MDA_N_MAX 1.0e9f
@@ -393,7 +398,7 @@ static __device__ __forceinline__ void md_approx_tile(Fetch fetch, float *s_rows
                 rows_ok &= mda_norm_ok(rr[c].w);
             }
         }
-        const bool scaled = cols_ok && !__ballot(!rows_ok);   // (uniform) this chunk of rows in the scaled form
+        const bool scaled = MD_SCALED_ROUTES && cols_ok && !__ballot(!rows_ok);   // (uniform) this chunk of rows in the scaled form
 #pragma unroll
         for (int c = 0; c < MDA_STAGE / 64; ++c) {
             float4 r = rr[c];
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
                 }
             }
             // this chunk in the scaled form (md_rows<.., SCALED>)?  (uniform)
-            const bool scaled = !direct && !approx && col_scal && !__ballot(!rows_scal);
+            const bool scaled = MD_SCALED_ROUTES && !direct && !approx && col_scal && !__ballot(!rows_scal);
 #pragma unroll
             for (int c = 0; c < MD_STAGE / 64; ++c) {
                 if (i0 + c * 64 + lane < M) {
@@ -993,6 +998,21 @@ __global__ __launch_bounds__(64) void k_selftest_mfma(uint64_t seed, int tiles_p
             // (a first product of -0 would come out of the MFMA as +0: both are clamped to 0 before the root)
             if (__float_as_uint(acc) != __float_as_uint(c[q]) && !(acc == 0.0f && c[q] == 0.0f)) ++bad;
         }
+    }
+    // The scaled routes (md_rows<.., SCALED>, md_approx_tile) rest on two more instruction-level facts, checked here as well: the
+    // output clamp of v_pk_add_f32 and of v_sqrt_f32 holds results to [0, 1], turns NaN, negative values and -inf into 0, and leaves
+    // everything inside the range (denormals included) as it is.
+    if (blockIdx.x == 0) {
+        const float in_a[8] = {0.25f, -0.5f, 1.5f, -1e-20f, __int_as_float(0x7FC00000), -INFINITY, 3e-39f, 0.999999f};
+        const float in_b[8] = {0.25f, 0.25f, 0.0f, 0.0f, 0.0f, 0.1f, 0.0f, 1e-7f};
+        const float a = in_a[lane & 7], b = in_b[lane & 7];
+        const float plain = a + b;
+        const float want = plain != plain ? 0.0f : (plain < 0.0f ? 0.0f : (plain > 1.0f ? 1.0f : plain));
+        const f2 got = md_pk_add_clamp01((f2){a, b}, (f2){b, a});
+        if (__float_as_uint(got.x) != __float_as_uint(want) || __float_as_uint(got.y) != __float_as_uint(want)) ++bad;
+        const float x = (lane & 1) ? -(float)(lane + 1) * 0.01f : (float)(lane + 1) * 0.015f;        // negative: 0; positive (< 1): the plain root
+        const float wr = x < 0.0f ? 0.0f : md_vsqrt(x);
+        if (__float_as_uint(md_vsqrt_clamp01(x)) != __float_as_uint(wr)) ++bad;
     }
     if (bad) atomicAdd(n_bad, bad);
 }
