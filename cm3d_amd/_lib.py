@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3D_LIB") or os.path.join(_HERE, "libcm3d_hip.so")      # CM3D_LIB: experiments only
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 CAM_STRIDE = 64
 SWEEP_XF_STRIDE = 24
 MAX_CAMS = 8
@@ -17,6 +17,7 @@ MAX_MASKS_PER_FRAME = 1024
 BOX_STRIDE = 10
 MEDOID_TILE = 64
 STATUS_WORDS = 4
+BBOX_STRIDE = 8          # int32 per mask in `bbox`: eroded bounds [0..3], stored rectangle xw0, y0, wc, rows [4..7] (include/cm3d_hip.h)
 MAX_MATCH_BOXES = 1024
 MAX_FUSED_SWEEPS = 16
 MATCH_BOX_STRIDE = 6

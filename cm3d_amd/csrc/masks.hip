@@ -70,12 +70,14 @@ static __device__ __forceinline__ void erode_tile_store(const uint32_t *s_rows, 
     }
 }
 
-__global__ void k_bbox_init(int32_t *__restrict__ bbox, int n)
+__global__ void k_bbox_init(int32_t *__restrict__ bbox, int n, int Wp, int H)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        bbox[4 * i + 0] = 0x7FFFFFFF; bbox[4 * i + 1] = 0x7FFFFFFF;
-        bbox[4 * i + 2] = -1;         bbox[4 * i + 3] = -1;
+        bbox[CM3D_BBOX_STRIDE * i + 0] = 0x7FFFFFFF; bbox[CM3D_BBOX_STRIDE * i + 1] = 0x7FFFFFFF;
+        bbox[CM3D_BBOX_STRIDE * i + 2] = -1;         bbox[CM3D_BBOX_STRIDE * i + 3] = -1;
+        // stored rectangle: the whole image, rows of Wp words (k_erode_pack)
+        bbox[CM3D_BBOX_STRIDE * i + 4] = 0; bbox[CM3D_BBOX_STRIDE * i + 5] = 0; bbox[CM3D_BBOX_STRIDE * i + 6] = Wp; bbox[CM3D_BBOX_STRIDE * i + 7] = H;
     }
 }
 
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(EP_THREADS) void k_erode_pack(const uint8_t *__rest
         }
     }
     __syncthreads();
-    erode_tile_store(s_rows, lw, Wp, 0, y0 - 1, rows, W, Wp, packed + (size_t)m * H * Wp, bbox + 4 * m);
+    erode_tile_store(s_rows, lw, Wp, 0, y0 - 1, rows, W, Wp, packed + (size_t)m * H * Wp, bbox + CM3D_BBOX_STRIDE * m);
 }
 
 static inline int ep_band_rows(int Wp)
@@ -160,7 +162,7 @@ extern "C" int cm3d_erode_pack(const uint8_t *dense, int32_t n_masks, int32_t W,
     const int band_rows = ep_band_rows(Wp);
     if (band_rows < 1) return CM3D_ERR_ARG;
     const int bands = (H + band_rows - 1) / band_rows;
-    hipLaunchKernelGGL(k_bbox_init, dim3((n_masks + 255) / 256), dim3(256), 0, st, bbox, n_masks);
+    hipLaunchKernelGGL(k_bbox_init, dim3((n_masks + 255) / 256), dim3(256), 0, st, bbox, n_masks, (W + 31) / 32, H);
     CM3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_erode_pack, dim3(bands, n_masks), dim3(EP_THREADS), (size_t)(band_rows + 2) * (Wp + 2) * 4, st, dense, W, H,
                        Wp, band_rows, packed, bbox);
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rle_ends(const uint32_t *__restr
     const int o = rle_off[m], n = rle_off[m + 1] - o;
     if (threadIdx.x == 0) {
         s_lo[0] = 0x7FFFFFFF; s_lo[1] = 0x7FFFFFFF; s_hi[0] = -1; s_hi[1] = -1;
-        if (bbox) { bbox[4 * m + 0] = 0x7FFFFFFF; bbox[4 * m + 1] = 0x7FFFFFFF; bbox[4 * m + 2] = -1; bbox[4 * m + 3] = -1; }
+        if (bbox) { bbox[CM3D_BBOX_STRIDE * m + 0] = 0x7FFFFFFF; bbox[CM3D_BBOX_STRIDE * m + 1] = 0x7FFFFFFF; bbox[CM3D_BBOX_STRIDE * m + 2] = -1; bbox[CM3D_BBOX_STRIDE * m + 3] = -1; }
     }
     int carry = 0;
     int ylo = 0x7FFFFFFF, yhi = -1, xlo = 0x7FFFFFFF, xhi = -1;
@@ -367,7 +369,8 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
     }
     const int ry0 = s_rect[0], ry1 = min(s_rect[2], H - 1);
     if (s_rect[2] < 0) {                        // empty mask
-        if (threadIdx.x == 0) { bbox[4 * m + 0] = 0x7FFFFFFF; bbox[4 * m + 1] = 0x7FFFFFFF; bbox[4 * m + 2] = -1; bbox[4 * m + 3] = -1; }
+        if (threadIdx.x == 0) { bbox[CM3D_BBOX_STRIDE * m + 0] = 0x7FFFFFFF; bbox[CM3D_BBOX_STRIDE * m + 1] = 0x7FFFFFFF; bbox[CM3D_BBOX_STRIDE * m + 2] = -1; bbox[CM3D_BBOX_STRIDE * m + 3] = -1; }
+        if (threadIdx.x >= 4 && threadIdx.x < 8) bbox[CM3D_BBOX_STRIDE * m + threadIdx.x] = 0;
         return;
     }
     const int xw0 = s_rect[1] >> 5, wc = (min(s_rect[3], W - 1) >> 5) - xw0 + 1, lw = wc + 2;
@@ -429,7 +432,9 @@ __global__ __launch_bounds__(EP_THREADS) void k_rle_erode_pack(const uint32_t *_
         erode_tile_store(s_rows, lw, wc, xw0, ya, rows, W, Wp, packed + (size_t)m * H * Wp, s_bb);
     }
     __syncthreads();
-    if (threadIdx.x < 4) bbox[4 * m + threadIdx.x] = s_bb[threadIdx.x];
+    if (threadIdx.x < 4) bbox[CM3D_BBOX_STRIDE * m + threadIdx.x] = s_bb[threadIdx.x];
+    // this form stores image rows as they are: the stored rectangle is the whole image
+    if (threadIdx.x >= 4 && threadIdx.x < 8) bbox[CM3D_BBOX_STRIDE * m + threadIdx.x] = threadIdx.x == 6 ? Wp : (threadIdx.x == 7 ? H : 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -534,9 +539,11 @@ __global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uin
     extern __shared__ __align__(16) uint32_t s_all[];
     __shared__ int s_part[RW_WAVES][4];                         // the bands' shares of the bounding box
     const int lane = cm3d_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // max_bands > 1: one workgroup per mask, wave w its band w; 1: four masks per workgroup, one wave each
-    const int m = max_bands > 1 ? (int)blockIdx.x : (int)blockIdx.x * RW_WAVES + wave;
-    if (m >= n_masks) return;                                   // (max_bands == 1 only; such a workgroup meets no barrier)
+    // max_bands > 1: one workgroup per mask, wave w its band w; 1: one wave per mask, and a wave goes on to mask + (waves of the
+    // launch) when the grid is smaller than the number of masks (the launcher holds it to a few waves per SIMD: see there)
+    const int m_first = max_bands > 1 ? (int)blockIdx.x : (int)blockIdx.x * RW_WAVES + wave;
+    const int m_stride = max_bands > 1 ? (int)gridDim.x : (int)gridDim.x * RW_WAVES;
+    for (int m = m_first; m < n_masks; m += m_stride) {         // (max_bands > 1: the grid covers the masks, one round, uniform over the workgroup)
 #ifdef CM3D_DIAG
     const int wdiag = g_rw_diag;
     const unsigned long long t_start = wdiag ? rw_now() : 0ull;
@@ -547,6 +554,7 @@ __global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uin
     const uint32_t *cnts = cnts_all + o;
     const int nb = max(1, min(max_bands, (n + RW_BAND_RUNS - 1) / RW_BAND_RUNS));     // bands = waves at work on this mask
     int bminx = 0x7FFFFFFF, bminy = 0x7FFFFFFF, bmaxx = -1, bmaxy = -1;               // bounding box of the band's eroded pixels
+    int rect_x = 0, rect_y = 0, rect_w = 0, rect_h = 0;                               // the stored rectangle (uniform; every band finds the same)
     if (band < nb) {
     const float rcpW = 1.0f / (float)W;
     // ---- pass 1: rectangle of the set pixels (the 1-runs of the first chunk stay in registers)
@@ -586,6 +594,7 @@ __global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uin
     const int bandr = (my1 - my0 + nb) / nb;
     const int ry0 = my0 + band * bandr, ry1 = min(my1, ry0 + bandr - 1);
     const int xw0 = xlo >> 5, wc = (min(xhi, W - 1) >> 5) - xw0 + 1, lw = wc + 2;
+    rect_x = xw0; rect_y = my0; rect_w = wc; rect_h = my1 - my0 + 1;
     int br = lds_words / lw - 2;                // output rows per tile
     br = min(br, ry1 - ry0 + 1);
     const uint32_t pad = (W & 31) ? ~((1u << (W & 31)) - 1u) : 0u;
@@ -673,10 +682,14 @@ __global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uin
                 row += 2 * lw;
                 const int xw = xw0 + c;
                 const uint32_t keep = xw == Wp - 1 ? tail_mask : 0xFFFFFFFFu;
-                uint32_t *dst = out_mask + (size_t)(ya + 1 + r0) * Wp + xw;
+                // the eroded words go out as PACKED ROWS OF THE RECTANGLE of the mask's set pixels (word columns xw0 .. xw0 + wc - 1, rows
+                // my0 .. my1), one row behind the other: consecutive stores fill whole cache lines.  At the image's row stride a mask's
+                // 40-byte row pieces were 1.5 M partial-line writes per batch, and with three batches in flight they cost every kernel
+                // that streams from HBM beside them: 20 of 142 us per pass (tools/stage_ablate.py), 4 in this form.
+                uint32_t *dst = out_mask + (size_t)(ya + 1 + r0 - my0) * wc + (xw - xw0);
                 uint32_t colany = 0u;
                 int first = 0x7FFFFFFF, last = -1;
-                for (int r = r0; r < r1; ++r, row += lw, dst += Wp) {
+                for (int r = r0; r < r1; ++r, row += lw, dst += wc) {
                     const uint32_t h2 = hrow(row);
                     const uint32_t e = h0 & h1 & h2 & keep;
                     h0 = h1; h1 = h2;
@@ -704,15 +717,19 @@ __global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uin
     }
 #endif
     if (nb == 1) {                              // uniform over the workgroup (or max_bands == 1): one band, no hand-over
-        if (band == 0 && lane < 4) bbox[4 * m + lane] = lane == 0 ? bminx : lane == 1 ? bminy : lane == 2 ? bmaxx : bmaxy;
-        return;
+        if (band == 0 && lane < 8)
+            bbox[CM3D_BBOX_STRIDE * m + lane] = lane == 0 ? bminx : lane == 1 ? bminy : lane == 2 ? bmaxx : lane == 3 ? bmaxy
+                                                : lane == 4 ? rect_x : lane == 5 ? rect_y : lane == 6 ? rect_w : rect_h;
+        continue;
     }
     if (lane < 4) s_part[wave][lane] = lane == 0 ? bminx : lane == 1 ? bminy : lane == 2 ? bmaxx : bmaxy;
     __syncthreads();
     if (wave == 0 && lane < 4) {
         int v = s_part[0][lane];
         for (int w = 1; w < RW_WAVES; ++w) v = lane < 2 ? min(v, s_part[w][lane]) : max(v, s_part[w][lane]);
-        bbox[4 * m + lane] = v;
+        bbox[CM3D_BBOX_STRIDE * m + lane] = v;
+    }
+    if (wave == 0 && lane >= 4 && lane < 8) bbox[CM3D_BBOX_STRIDE * m + lane] = lane == 4 ? rect_x : lane == 5 ? rect_y : lane == 6 ? rect_w : rect_h;
     }
 }
 
@@ -760,13 +777,11 @@ extern "C" int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rl
     if (lds_words / (Wp + 2) - 2 < 1) return CM3D_ERR_ARG;      // tile height of a full-width mask
     (void)workspace;                                            // reserved (the run ends are not materialised)
     // ordinary masks (on average at most 1024 runs): one wave per mask; lists of thousands of runs: one workgroup per mask
-    static int form = -1, lds_wave = 0, rle_diag = 0, bands = 1;
+    static int form = -1, lds_wave = 0, bands = 1;
     if (form < 0) {
         const char *bd = getenv("CM3D_RLE_BANDS");                // 1: a wave per mask; 2..4: a workgroup per mask, its rows in up to that many bands
         bands = bd ? atoi(bd) : 1;
         if (bands < 1 || bands > RW_WAVES) bands = 1;
-        const char *dg = getenv("CM3D_RLE_DIAG");                 // experiments only: 1 no stores, 2 no erosion, 4 no paint, 8 stop behind pass 1
-        rle_diag = dg ? atoi(dg) : 0;
         const char *e = getenv("CM3D_RLE_FORM");                  // "wave" / "block" force one form (experiments, tests)
         form = e ? (e[0] == 'w' ? 1 : 2) : 0;
         const char *w = getenv("CM3D_RLEW_LDS_WORDS");
@@ -782,7 +797,13 @@ extern "C" int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rl
             if (hipFuncSetAttribute((const void *)k_rle_erode_pack_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CM3D_ERR_LAUNCH;
             lds_allowed = lds;
         }
-        hipLaunchKernelGGL(k_rle_erode_pack_wave, dim3(bands > 1 ? n_masks : (n_masks + RW_WAVES - 1) / RW_WAVES), dim3(RW_THREADS), lds, st,
+        const char *dg = getenv("CM3D_RLE_DIAG");                     // experiments only (read per call: tools/stage_ablate.py switches it
+        const int rle_diag = dg ? atoi(dg) : 0;                       // between passes): 1 no stores, 2 no erosion, 4 no paint, 8 stop behind pass 1
+        int grid = bands > 1 ? n_masks : (n_masks + RW_WAVES - 1) / RW_WAVES;
+        static int gcap = -1;
+        if (gcap < 0) { const char *e = getenv("CM3D_RLE_GRID"); gcap = e ? atoi(e) : 0; }
+        if (bands == 1 && gcap > 0 && grid > gcap) grid = gcap;
+        hipLaunchKernelGGL(k_rle_erode_pack_wave, dim3(grid), dim3(RW_THREADS), lds, st,
                            rle_counts, rle_off, n_masks, W, H, Wp, lds_wave, packed, bbox, bands, rle_diag);
     } else {
         hipLaunchKernelGGL(k_rle_erode_pack, dim3(n_masks), dim3(EP_THREADS), (size_t)lds_words * 4, st, rle_counts, rle_off, W, H, Wp,

@@ -449,24 +449,26 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
     // ballot rank.  Every mask is loaded once per pass (twice when the frame has more than 64 masks).
     int4 *ment = ment_all + (size_t)f * nm_cap * 2;
     const int mg = ft_margin;
-    auto load_mask = [&](int k, int &cam, int4 &bb) {
+    auto load_mask = [&](int k, int &cam, int4 &bb, int4 &rc) {      // bb: bounds of the eroded pixels; rc: the stored rectangle (xw0, y0, wc, rows)
         cam = -1;
         bb = make_int4(0, 0, -1, -1);
+        rc = make_int4(0, 0, 0, 0);
         if (k < nm) {
             cam = mask_cam[m0 + k];
-            bb = bbox[m0 + k];
+            bb = bbox[2 * (m0 + k)];
+            rc = bbox[2 * (m0 + k) + 1];
             if (cam < 0 || cam >= n_cams) { atomicOr(&status[0], 4); cam = -1; }         // such a mask gets no points
             else if (!(bb.z >= bb.x && bb.w >= bb.y)) cam = -1;                          // empty after the erosion
         }
     };
     int cam0;
-    int4 bb0;
-    load_mask(lane, cam0, bb0);                      // the first 64 masks stay in registers for both passes
+    int4 bb0, rc0;
+    load_mask(lane, cam0, bb0, rc0);                 // the first 64 masks stay in registers for both passes
     int cnt = 0;                                     // lane c: masks of camera c
     for (int k0 = 0; k0 < nm; k0 += 64) {
         int cam = cam0;
-        int4 bb = bb0;
-        if (k0) load_mask(k0 + lane, cam, bb);
+        int4 bb = bb0, rc = rc0;
+        if (k0) load_mask(k0 + lane, cam, bb, rc);
         for (int c = 0; c < n_cams; ++c) {
             const int x = (int)__popcll(__ballot(cam == c));
             cnt += lane == c ? x : 0;
@@ -481,21 +483,24 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
     }
     for (int k0 = 0; k0 < nm; k0 += 64) {
         int cam = cam0;
-        int4 bb = bb0;
-        if (k0) load_mask(k0 + lane, cam, bb);
+        int4 bb = bb0, rc = rc0;
+        if (k0) load_mask(k0 + lane, cam, bb, rc);
         const int k = k0 + lane;
         for (int c = 0; c < n_cams; ++c) {
             const uint64_t mk = __ballot(cam == c);
             const int base = __builtin_amdgcn_readlane(first, c);
             // entry, first half: corner and extent of the bounding box as 16-bit pairs (y in the high half, like the pixel
-            // codes), mask number inside the frame, first word of the mask in `packed` (a batch holds < 2^31 mask words);
+            // codes), mask number inside the frame | words per stored row << 16, word number of the mask's (0, 0) in `packed`;
             // second half: the box grown by the approximate projection's margin, in its pixel grid shifted by +1
             // ([x0 + 1 - mg, x1 + 1 + mg], low end clamped at 0), again as corner and extent
             if (cam == c) {
                 const int e = base + cm3d_mbcnt(mk);
                 const int lx = max(bb.x + 1 - mg, 0), ly = max(bb.y + 1 - mg, 0);
                 const int hx = min(bb.z + 1 + mg, 32766), hy = min(bb.w + 1 + mg, 32766);        // (approximate codes stop at 32001; -1 stays outside)
-                ment[2 * e] = make_int4(bb.x | (bb.y << 16), (bb.z - bb.x) | ((bb.w - bb.y) << 16), k, (int)((uint32_t)(m0 + k) * mask_words));
+                // word (xw, y) of the mask = slot + (y - y0) * wc + xw - xw0 = [slot - y0 * wc - xw0] + y * wc + xw: the bracket is the
+                // entry's word number (signed: it may lie before the slot; a batch holds < 2^31 mask words), wc rides on the mask number
+                ment[2 * e] = make_int4(bb.x | (bb.y << 16), (bb.z - bb.x) | ((bb.w - bb.y) << 16), k | (rc.z << 16),
+                                        (int)((uint32_t)(m0 + k) * mask_words) - rc.y * rc.z - rc.x);
                 ment[2 * e + 1] = make_int4(lx | (ly << 16), (hx - lx) | ((hy - ly) << 16), 0, 0);
             }
             first += lane == c ? (int)__popcll(mk) : 0;
@@ -944,11 +949,12 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             // px = iv << 16 | iu (two 16-bit halves; -1 = outside): byte offset of the point's word inside a mask and its bit,
             // once per camera
             PH_COUNT(3, 1);
-            uint32_t wo4[PH_PT];
+            uint32_t xw4[PH_PT], iv4[PH_PT];                        // word column and row of the pixel: a mask's rows have its own stride
 #pragma unroll
             for (int j = 0; j < PH_PT; ++j) {
-                const uint32_t iu = (uint32_t)px[j] & 0xFFFFu, iv = (uint32_t)px[j] >> 16;
-                wo4[j] = (iv * (uint32_t)Wp + (iu >> 5)) << 2;
+                const uint32_t iu = (uint32_t)px[j] & 0xFFFFu;
+                iv4[j] = (uint32_t)px[j] >> 16;
+                xw4[j] = iu >> 5;
             }
             // the candidate masks of this camera (sorted entries: bounding box, mask number, first word), PH_MB at a time:
             // all entries, then all mask words of the batch are requested before the first one is used (one memory round
@@ -973,12 +979,14 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
                 for (int b = 0; b < PH_MB; ++b) {
 #pragma unroll
                     for (int j = 0; j < PH_PT; ++j) word[b][j] = 0u;
-                    kb[b] = ei[b] >= 0 ? __builtin_amdgcn_readfirstlane(en[b].z) : -1;
+                    const int kw = ei[b] >= 0 ? __builtin_amdgcn_readfirstlane(en[b].z) : -1;
+                    kb[b] = kw < 0 ? -1 : (kw & 0xFFFF);
                     if (kb[b] < 0) continue;                        // past the last candidate (wave-uniform)
+                    const uint32_t wcm = (uint32_t)kw >> 16;        // words per stored row of this mask
                     PH_COUNT(5, 1);
                     const us2 org = __builtin_bit_cast(us2, __builtin_amdgcn_readfirstlane(en[b].x));
                     const us2 ext = __builtin_bit_cast(us2, __builtin_amdgcn_readfirstlane(en[b].y));
-                    const char *mw = reinterpret_cast<const char *>(packed) + ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane(en[b].w) << 2);
+                    const char *mw = reinterpret_cast<const char *>(packed) + ((long long)__builtin_amdgcn_readfirstlane(en[b].w) << 2);
 #pragma unroll
                     for (int j = 0; j < PH_PT; ++j) {
                         // inside the box <=> (x - x0 <= rx) and (y - y0 <= ry) as unsigned 16-bit halves; -1 (0xFFFF, 0xFFFF) is
@@ -986,7 +994,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
                         const us2 d = __builtin_bit_cast(us2, px[j]) - org;
                         const us2 m = __builtin_elementwise_min(d, ext);
                         if (__builtin_bit_cast(uint32_t, m) == __builtin_bit_cast(uint32_t, d))
-                            word[b][j] = *reinterpret_cast<const uint32_t *>(mw + wo4[j]);
+                            word[b][j] = *reinterpret_cast<const uint32_t *>(mw + ((iv4[j] * wcm + xw4[j]) << 2));
                     }
                 }
 #pragma unroll
@@ -1406,7 +1414,7 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
         return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_project_workspace_bytes(n_frames, max_pts_per_frame, planes) || ((uintptr_t)workspace & 15)) return CM3D_ERR_WORKSPACE;
     // a mask's first word in `packed` travels as a 32-bit word offset in its table entry (k_frame_tables): ~95 k masks of 1600x900
-    if ((int64_t)n_masks * H * ((W + 31) / 32) > 0xFFFFFFFFll) return CM3D_ERR_ARG;
+    if ((int64_t)n_masks * H * ((W + 31) / 32) > 0x7FFFFFFFll) return CM3D_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     PhWs ws;
     ph_ws_layout(n_frames, max_pts_per_frame, planes, workspace, &ws);

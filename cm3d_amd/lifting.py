@@ -320,7 +320,7 @@ class LiftEngine:
         if M <= 0 or F <= 0 or S <= 0 or hb.n_raw_rows <= 0:
             raise ValueError("empty batch")
         nm_max = int(np.diff(hb.mask_off).max())
-        if hb.n_masks * hb.height * ((hb.width + 31) // 32) > 0xFFFFFFFF:
+        if hb.n_masks * hb.height * ((hb.width + 31) // 32) > 0x7FFFFFFF:
             raise ValueError(f"{hb.n_masks} masks of {hb.width}x{hb.height} in one batch: their bit-packed words no longer fit a 32-bit offset "
                              "(split the batch)")
         if nm_max > _lib.MAX_MASKS_PER_FRAME:
@@ -352,7 +352,7 @@ class LiftEngine:
         b.pt_off = e(F + 1)
         b.status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=d)
         b.packed = e(M, H, Wp)
-        b.bbox = e(M, 4)
+        b.bbox = e(M, _lib.BBOX_STRIDE)        # [0..3] bounds of the eroded pixels, [4..7] the rectangle `packed` stores
         b.hit_words = e(b.planes, b.pt_cap)
         b.hit_count = e(M); b.hit_off = e(M + 1); b.tile_off = e(M + 1)
         b.hit_idx = e(b.idx_cap); b.hit_xyz = e(b.idx_cap, 4, dtype=torch.float32)
@@ -636,7 +636,7 @@ class LiftEngine:
         out = dict(
             pt_off=np.concatenate([[0], np.cumsum(kept_per_frame)]).astype(np.int32),
             hit_off=b.hit_off.cpu().numpy(), hit_idx=b.hit_idx[:n_idx].cpu().numpy(), hit_xyz=b.hit_xyz[:n_idx].cpu().numpy(),
-            bbox=b.bbox.cpu().numpy(), medoid_pos=b.medoid_pos.cpu().numpy(), centroid=b.centroid.cpu().numpy(),
+            bbox=b.bbox[:, :4].cpu().numpy(), medoid_pos=b.medoid_pos.cpu().numpy(), centroid=b.centroid.cpu().numpy(),
             lane_idx=b.lane_idx.cpu().numpy(), lane_dist=b.lane_dist.cpu().numpy(), centroid_global=b.centroid_g.cpu().numpy(),
             box=b.box.cpu().numpy(), flags=b.flags.cpu().numpy())
         if b.points is not None:

@@ -60,12 +60,13 @@ def decode(rles, as_counts=False):
 
 
 def erode(dense_masks):
-    """cv2.erode(mask, ones((3,3))) for a stack of masks, bit-packed: returns (packed (n,H,Wp) int32, bbox (n,4))."""
+    """cv2.erode(mask, ones((3,3))) for a stack of masks, bit-packed: returns (packed (n,H,Wp) int32, bbox (n,8): bounds of the eroded
+    pixels [0..3] and the rectangle `packed` stores [4..7] -- here the whole image; unpack_bits turns both into pixels)."""
     L = _lib.lib()
     d = dense_masks if torch.is_tensor(dense_masks) else _t(dense_masks, np.uint8)
     n, H, W = d.shape
     packed = _e(n, H, (W + 31) // 32)
-    bbox = _e(n, 4)
+    bbox = _e(n, _lib.BBOX_STRIDE)
     check(L.cm3d_erode_pack(d.data_ptr(), n, W, H, packed.data_ptr(), bbox.data_ptr(), _st()), "cm3d_erode_pack")
     return packed, bbox
 
@@ -78,18 +79,29 @@ def erode_rle(rle_counts_list, W, H):
     n = len(rle_counts_list)
     d_c, d_o = _t(allc.view(np.int32)), _t(off)
     packed = torch.zeros(n, H, (W + 31) // 32, dtype=torch.int32, device=_dev())
-    bbox = _e(n, 4)
+    bbox = _e(n, _lib.BBOX_STRIDE)
     ws = _ws(L.cm3d_rle_workspace_bytes(allc.size))
     check(L.cm3d_rle_erode_pack(d_c.data_ptr(), d_o.data_ptr(), n, allc.size, W, H, packed.data_ptr(), bbox.data_ptr(),
                                 ws.data_ptr(), ws.numel(), _st()), "cm3d_rle_erode_pack")
     return packed, bbox
 
 
-def unpack_bits(packed, W):
-    """(n,H,Wp) int32 bit-packed -> (n,H,W) uint8 numpy (host helper for tests/tools)."""
+def unpack_bits(packed, W, bbox=None):
+    """(n,H,Wp) int32 bit-packed -> (n,H,W) uint8 numpy (host helper for tests/tools).  bbox (n,8) from erode / erode_rle: a
+    mask's slot holds the rows of its stored rectangle (xw0, y0, wc, rows = bbox[:, 4:8]) one behind the other
+    (include/cm3d_hip.h); without it the slots are read as whole images."""
     p = packed.cpu().numpy().view(np.uint32)
+    n, H, Wp = p.shape
+    if bbox is not None:
+        rc = (bbox.cpu().numpy() if torch.is_tensor(bbox) else np.asarray(bbox))[:, 4:8]
+        full = np.zeros_like(p)
+        flat = p.reshape(n, -1)
+        for i, (xw0, y0, wc, rows) in enumerate(rc.tolist()):
+            if wc > 0 and rows > 0:
+                full[i, y0:y0 + rows, xw0:xw0 + wc] = flat[i, :rows * wc].reshape(rows, wc)
+        p = full
     bits = ((p[..., None] >> np.arange(32, dtype=np.uint32)) & 1).astype(np.uint8)
-    return bits.reshape(p.shape[0], p.shape[1], -1)[:, :, :W]
+    return bits.reshape(n, H, -1)[:, :, :W]
 
 
 # ----------------------------------------------------------------------------- a4-a8

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CM3D_ABI_VERSION 2
+#define CM3D_ABI_VERSION 3
 
 #define CM3D_OK 0
 #define CM3D_ERR_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
@@ -41,6 +41,7 @@ extern "C" {
 #define CM3D_SWEEP_XF_STRIDE 24  /* floats per sweep transform, see cm3d_sweep_prep   */
 #define CM3D_MAX_CAMS 8          /* cameras per frame                                  */
 #define CM3D_MAX_MASKS_PER_FRAME 1024
+#define CM3D_BBOX_STRIDE 8                 /* int32 per mask in `bbox` (ABI v3): eroded bounds [0..3], stored rectangle [4..7] */
 #define CM3D_BOX_STRIDE 10       /* doubles per box record, see cm3d_box_nms           */
 #define CM3D_MEDOID_TILE 64      /* columns per medoid tile (one wave)                 */
 #define CM3D_MAX_MATCH_BOXES 1024 /* boxes per sample and side, see cm3d_bev_match    */
@@ -102,14 +103,20 @@ int cm3d_rle_to_dense(const uint32_t *rle_counts, const int32_t *rle_off, int32_
  * Replaces cv2.erode(mask, ones((3,3))) + astype(bool) + transpose + H2D at
  * 2d_to_3d.py:526-527,542-544.  Out-of-image neighbours are ignored.
  *  dense   uint8[n][H][W]   non-zero = set
- *  packed  uint32[n][H][Wp] OUT, Wp = (W+31)/32, bit (x&31) of word [y][x>>5] = eroded pixel (x,y)
- *  bbox    int32[n][4]      OUT x0,y0,x1,y1 inclusive bounds of the eroded mask (x0>x1 when empty) */
+ *  packed  uint32[n][H*Wp]  OUT, Wp = (W+31)/32: one slot of H*Wp words per mask.  A mask's eroded bits are stored as the rows of a
+ *          RECTANGLE of whole words (ABI v3): word columns xw0 .. xw0+wc-1, image rows y0 .. y0+rows-1, row after row from the start
+ *          of the slot, wc words each: bit (x&31) of slot word (y - y0) * wc + (x>>5) - xw0 = eroded pixel (x,y).  cm3d_erode_pack
+ *          stores the whole image (xw0 = y0 = 0, wc = Wp, rows = H: the layout of ABI v2); cm3d_rle_erode_pack the rectangle of the
+ *          mask's set pixels, so that a mask's words are contiguous in memory.  Words outside the rectangle are unspecified, and
+ *          n*H*Wp must stay below 2^31 (mask offsets are signed 32-bit word numbers).
+ *  bbox    int32[n][CM3D_BBOX_STRIDE] OUT: [0..3] x0,y0,x1,y1 inclusive bounds of the eroded mask (x0>x1 when empty),
+ *          [4..7] xw0, y0, wc, rows of the stored rectangle (all 0 for a mask without a set pixel) */
 int cm3d_erode_pack(const uint8_t *dense, int32_t n_masks, int32_t W, int32_t H, uint32_t *packed,
                     int32_t *bbox, cm3d_stream_t stream);
 
 /* f1: same result straight from run lengths, no dense intermediate
- * (fuses 2d_to_3d.py:425 with :526-527,542-544).  Only the rows that can hold an eroded pixel are
- * written: `packed` rows outside [bbox.y0, bbox.y1] are unspecified (nothing downstream reads them). */
+ * (fuses 2d_to_3d.py:425 with :526-527,542-544).  Stores the rectangle of the mask's set pixels (see `packed` above): only words
+ * that can hold an eroded pixel are written. */
 int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int32_t n_masks, int32_t total_runs,
                         int32_t W, int32_t H, uint32_t *packed, int32_t *bbox, void *workspace,
                         int64_t workspace_bytes, cm3d_stream_t stream);
