@@ -71,7 +71,7 @@ base = timed(())
 print(f"{name} x{F}, {DEPTH} batches in flight: full pass {base:.1f} us")
 # parts of the mask kernel (CM3D_RLE_DIAG, read per call): without its stores the packed masks of the earlier passes stay valid
 # (only bit 1 keeps what follows valid: the other switches leave empty bounding boxes behind)
-for bits, what in ((1, "the mask kernel's stores"), (17, "... stores as packed rows of the rectangle (scratch)"), (1, "the mask kernel's stores (again)")):
+for bits, what in ((1, "the mask kernel's stores"),):
     os.environ["CM3D_RLE_DIAG"] = str(bits)
     t = timed(())
     print(f"  without {what:44s} {t:7.1f} us   ({base - t:+6.1f})", flush=True)
