@@ -568,6 +568,9 @@ def main(argv=None):
     roofline["batches_in_flight"] = depth
     roofline["avg_launch_ms_alone"] = round(r["project_alone_ms"], 4)      # the same launch with nothing else on the GPU
     roofline["frac_alone"] = round(rate(by["k_project_hits"], r["project_alone_ms"]) / HBM_PEAK_GBS, 4)
+    # the same against what a plain stream gets on THIS box (the device copy above: reads + writes), not the nominal peak
+    if roofline["measured_copy_GBs"] > 0:
+        roofline["frac_alone_vs_measured_copy"] = round(rate(by["k_project_hits"], r["project_alone_ms"]) / roofline["measured_copy_GBs"], 4)
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     per_kernel = {}
     if os.path.exists(traffic_file):
@@ -577,6 +580,8 @@ def main(argv=None):
             if args.frames == int(tr.get("frames_per_gpu", 256)) and not args.set and not args.keep_cloud:
                 per_kernel = tr.get(f"{args.config}_{main_mode}", {})
                 roofline["traffic"] = per_kernel.get("k_project_hits")
+                if roofline["traffic"] and roofline.get("measured_copy_GBs", 0) > 0:      # measured HBM bytes of the launch over its time alone
+                    roofline["traffic_frac_alone_vs_measured_copy"] = round(rate(roofline["traffic"], r["project_alone_ms"]) / roofline["measured_copy_GBs"], 4)
         except (OSError, ValueError):
             pass
     mask_kernel = "k_erode_pack" if main_mode == "dense" else "k_rle_erode_pack_wave"
