@@ -49,6 +49,7 @@ SIGNATURES = {
     "cm3d_selftest_mfma": (_i32, [C.c_uint64, _i32, _p, _p]),
     "cm3d_medoid_workspace_bytes": (_i64, [_i32, _i32]),
     "cm3d_medoid": (_i32, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _p]),
+    "cm3d_medoid2": (_i32, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
     "cm3d_lane_grid_bytes": (_i64, [_i32, _i32]),
     "cm3d_lane_grid_build": (_i32, [_p, _p, _i32, _i32, _p, _i64, _p]),
     "cm3d_lane_nn_workspace_bytes": (_i64, [_i32]),

@@ -470,10 +470,15 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
                                                               const TileDesc *__restrict__ desc,
                                                               TileBest *__restrict__ tile_best, int tile_cap,
                                                               float *__restrict__ colsum_opt, float *__restrict__ approx_opt,
-                                                              int32_t *__restrict__ long_list)
+                                                              int32_t *__restrict__ long_list, int32_t *__restrict__ feedback)
 {
     __shared__ float4 s_row_all[MD_WAVES][MD_STAGE];
-    if (!WITH_LONG && blockIdx.x == 0 && threadIdx.x == 0) long_list[0] = 0;      // k_medoid_reduce counts the long masks into it
+    if (!WITH_LONG && blockIdx.x == 0 && threadIdx.x == 0) {
+        long_list[0] = 0;                                                         // k_medoid_reduce counts the long masks into it
+        // what the caller may use as a hint for the NEXT batch (cm3d_medoid2): does this one hold a list the two-pass route
+        // would take?  The work list is ordered longest lists first: its first entry says (conservatively, inside its class).
+        if (feedback) feedback[0] = (min(tile_off[n_masks], tile_cap) > 0 && desc[0].M > CM3D_MEDOID_TILE * MD_UNI) ? 1 : 0;
+    }
     const int wave = threadIdx.x >> 6, lane = cm3d_lane();
 #ifdef CM3D_DIAG
     const int diag = g_md_diag & 1;
@@ -873,6 +878,15 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
                            const int32_t *tile_work, int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
                            int64_t workspace_bytes, cm3d_stream_t stream)
 {
+    return cm3d_medoid2(points, pt_off, mask_frame, n_masks, hit_off, tile_off, hit_row, idx_cap, tile_work, medoid_pos, centroid, colsum_opt,
+                        workspace, workspace_bytes, 0, nullptr, stream);
+}
+
+extern "C" int cm3d_medoid2(const float *points, const int32_t *pt_off, const int32_t *mask_frame, int32_t n_masks,
+                            const int32_t *hit_off, const int32_t *tile_off, const int32_t *hit_row, int32_t idx_cap,
+                            const int32_t *tile_work, int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
+                            int64_t workspace_bytes, int32_t flags, int32_t *feedback, cm3d_stream_t stream)
+{
     if (!points || !hit_off || !tile_off || !medoid_pos || !centroid || !workspace) return CM3D_ERR_ARG;
     if (hit_row && (!pt_off || !mask_frame)) return CM3D_ERR_ARG;           // hit_row == NULL: `points` is the hit_xyz array
     if (n_masks <= 0 || idx_cap <= 0) return CM3D_ERR_ARG;
@@ -885,7 +899,9 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     // two passes for long lists unless the caller wants every exact column sum (colsum_opt) or CM3D_MD_TWO_PASS=0
     static int two_pass_env = -1;
     if (two_pass_env < 0) { const char *e = getenv("CM3D_MD_TWO_PASS"); two_pass_env = e ? atoi(e) : 1; }
-    float *approx = (two_pass_env && !colsum_opt) ? (float *)(best + tile_cap) : nullptr;
+    // (flags & 1: the caller expects no long list in this batch -- the one-pass route is exact for every length, so a wrong
+    // expectation costs time, never a result -- and two launches that would find nothing to do are not made)
+    float *approx = (two_pass_env && !colsum_opt && !(flags & 1)) ? (float *)(best + tile_cap) : nullptr;
     int32_t *long_list = (int32_t *)((float *)(best + tile_cap) + idx_cap);         // [0] = number of long masks, then their numbers
     const TileDesc *desc = (const TileDesc *)tile_work;
     if (!desc) {                                   // no work list from cm3d_compact_hits: build it here
@@ -903,11 +919,11 @@ extern "C" int cm3d_medoid(const float *points, const int32_t *pt_off, const int
     if (const char *e = getenv("CM3D_MD_GRID")) gmax = atoi(e);
     if (grid > gmax) grid = gmax;
     hipLaunchKernelGGL(k_medoid_tiles<false>, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
-                       tile_off, hit_row, desc, best, tile_cap, colsum_opt, approx, long_list);
+                       tile_off, hit_row, desc, best, tile_cap, colsum_opt, approx, long_list, feedback);
     CM3D_CHECK_LAUNCH();
     if (approx) {             // (without a first pass -- colsum_opt, CM3D_MD_TWO_PASS=0 -- the light instantiation takes every batch)
         hipLaunchKernelGGL(k_medoid_tiles<true>, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
-                           tile_off, hit_row, desc, best, tile_cap, colsum_opt, approx, long_list);
+                           tile_off, hit_row, desc, best, tile_cap, colsum_opt, approx, long_list, feedback);
         CM3D_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_medoid_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, (const float4 *)points, pt_off, mask_frame,

@@ -305,6 +305,10 @@ class LiftEngine:
         self.side = torch.cuda.Stream(device=d)              # lane-grid build overlaps the point/mask stages
         self.grid_done = torch.cuda.Event()
         self.fused_sweeps = os.environ.get("CM3D_FUSED_SWEEPS", "1") == "1"    # 0: separate sweep and projection launches
+        # the medoid stage's feedback word (stage_medoid): starts at 1 = "expect long lists"
+        self._md_hint = os.environ.get("CM3D_MD_HINT", "1") == "1"
+        self._md_fb = torch.ones(4, dtype=torch.int32).pin_memory()
+        self._md_fb_np = self._md_fb.numpy()
         self.prior_wlh = torch.from_numpy(self.classes.prior_wlh).to(d)
         self.is_vehicle = torch.from_numpy(self.classes.is_vehicle).to(d)
         self.nms_thr = torch.from_numpy(self.classes.nms_thr).to(d)
@@ -500,9 +504,17 @@ class LiftEngine:
                                          _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_compact_hits")
 
     def stage_medoid(self, st):
+        """The medoid stage.  Lists of more than 512 points go a two-pass route that costs two launches even when a batch holds no
+        such list (they find that out on the device: 2-3 % of a pass with three batches in flight).  The first launch leaves word 0
+        of `self._md_fb` -- page-locked host memory the device writes directly, no copy -- saying whether THIS batch held one; the next
+        pass of this engine reads whatever has arrived by then and, if the last batch it heard of had none, asks for the one-pass
+        route only (cm3d_medoid2 flags bit 0).  That route is exact for every length: a stale hint costs time on one pass, never a
+        result."""
         b = self.b
-        check(self.lib.cm3d_medoid(_ptr(b.hit_xyz), 0, 0, b.M, _ptr(b.hit_off), _ptr(b.tile_off), 0, b.idx_cap, _ptr(b.tile_work),
-                                   _ptr(b.medoid_pos), _ptr(b.centroid), _ptr(b.colsum), _ptr(b.ws), b.ws_bytes, st), "cm3d_medoid")
+        flags = 1 if (self._md_hint and int(self._md_fb_np[0]) == 0) else 0
+        check(self.lib.cm3d_medoid2(_ptr(b.hit_xyz), 0, 0, b.M, _ptr(b.hit_off), _ptr(b.tile_off), 0, b.idx_cap, _ptr(b.tile_work),
+                                    _ptr(b.medoid_pos), _ptr(b.centroid), _ptr(b.colsum), _ptr(b.ws), b.ws_bytes, flags,
+                                    self._md_fb.data_ptr(), st), "cm3d_medoid2")
 
     def stage_lane_grid(self, st):
         """Spatial index of the lane tables.  It depends on the lane tables only, so `run` issues it on

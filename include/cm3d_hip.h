@@ -220,6 +220,17 @@ int cm3d_medoid(const float *points, const int32_t *pt_off, const int32_t *mask_
                 const int32_t *hit_off, const int32_t *tile_off, const int32_t *hit_row, int32_t idx_cap,
                 const int32_t *tile_work, int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
                 int64_t workspace_bytes, cm3d_stream_t stream);
+/* The same with a hint and a feedback word (ABI v3), for callers that run batch after batch:
+ *  flags     bit 0: expect no list of more than 448 points in this batch -- every list then takes the exact one-pass route and the two
+ *            launches of the two-pass route that would find nothing to do are not made.  Only ever a matter of time: the one-pass
+ *            route is exact for every length.
+ *  feedback  optional int32[1] the DEVICE can write (device memory, or page-locked host memory that is mapped into the device's address
+ *            space: then the caller reads it without a copy): 1 if this batch holds such a list, else 0, written by the first launch.
+ *            cm3d_amd.lifting.LiftEngine feeds it back as the next pass's flag. */
+int cm3d_medoid2(const float *points, const int32_t *pt_off, const int32_t *mask_frame, int32_t n_masks,
+                 const int32_t *hit_off, const int32_t *tile_off, const int32_t *hit_row, int32_t idx_cap,
+                 const int32_t *tile_work, int32_t *medoid_pos, float *centroid, float *colsum_opt, void *workspace,
+                 int64_t workspace_bytes, int32_t flags, int32_t *feedback, cm3d_stream_t stream);
 
 /* Diagnostic for the tests: `count` pseudo-random (numerator, denominator) pairs, denominators over the projection
  * kernel's shortcut domain [1e-30, 1e30), quotients next to integers over-represented, through the kernel's division

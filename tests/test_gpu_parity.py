@@ -97,6 +97,31 @@ def test_colsum_bit_exact(oracle):
         assert np.array_equal(cs.view(np.uint32), got["colsum"][o:e].view(np.uint32)), f"mask {m} column sums differ"
 
 
+def test_medoid_hint_never_changes_a_result(oracle):
+    """LiftEngine feeds the medoid stage's feedback word (does this batch hold a list of more than 512 points?) back as the next
+    pass's hint (cm3d_medoid2).  A batch without long lists, then -- in the same engine, so with a hint that says "none" -- a batch
+    full of them, then the short one again: every pass must give the oracle's results, whatever the hint said."""
+    import torch
+    from cm3d_amd import lifting
+    short_cfg, long_cfg = syn.config("tiny"), syn.config("c1")
+    eng = lifting.LiftEngine()
+    seen = []
+    for cfg, seed, n in ((short_cfg, 5, 4), (long_cfg, 9, 1), (short_cfg, 6, 4)):
+        frames = [syn.make_frame(cfg, seed + i) for i in range(n)]
+        lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 3000, seed=1)]
+        hb = lifting.pack_frames(frames, lanes, [0] * n)
+        exp = oracle_batch(oracle, frames, lanes, [0] * n, hb)
+        eng.upload(hb)
+        for _ in range(3):                          # pass 1 runs on the previous batch's hint, pass 2 and 3 on this batch's
+            eng.run(masks="rle")
+            torch.cuda.synchronize()
+            seen.append(int(eng._md_fb_np[0]))
+            got = eng.download()
+            _compare(hb, got, exp)
+        assert (np.diff(exp["hit_off"]).max() > 512) == bool(seen[-1])
+    assert seen[:3] == [0, 0, 0] and seen[3:6] == [1, 1, 1] and seen[6:] == [0, 0, 0]
+
+
 def test_hit_rows_of_the_byte_accounting(oracle):
     """bench.py prices the hit words of the 256-row blocks that hold an in-mask point (the only ones the projection writes and
     the compaction reads); `LiftEngine.hit_chunk_rows` reads the blocks' flags back.  Held to the oracle's index lists: compacted
