@@ -267,12 +267,28 @@ def lift_scenes(tables, scene_names, mask_dir, classes, device, n_sweeps=3, rati
 REFERENCE_BUCKETS = ("io", "points in mask", "medoid", "drivable", "closest lane", "nms")       # the reference's timer (:368-378)
 
 
-def _native_batch_head(nt, names, mask_dir, n_sweeps, ratio, classes, missing_ok, lane_cache, sub=None):
+def _native_batch_lanes(nt, names, lane_cache):
+    """The scenes' lane tables (one per map location, cached) and the table every frame of the batch uses."""
+    lanes, frame_lane, locs = [], [], []
+    for k, name in enumerate(names):
+        loc = nt.location(name)
+        if loc not in lane_cache:
+            lane_cache[loc] = np.asarray(nusc_io.load_lane_points(nt.dataroot, loc), np.float64).astype(np.float32).reshape(-1, 3)   # torch.Tensor(...) at :278
+        lanes.append(lane_cache[loc])
+        locs.append(loc)
+        frame_lane.extend([k] * nt.scene_samples(name))
+    return lanes, frame_lane, locs
+
+
+def _native_batch_head(nt, names, mask_dir, n_sweeps, ratio, classes, missing_ok, lane_cache, sub=None, pool=None):
     """First host stage of a batch on the native route: table walk, <f>_data.json, mask pickles + RLE strings (reader.Tables /
-    reader.Manifest) and the scenes' lane tables.  Returns what _native_batch_tail needs, or None when the batch needs the Python
-    reader (frames without masks to be dropped, mixed mask sizes, a pickle the native parser does not know)."""
+    reader.Manifest) and the scenes' lane tables -- the latter on `pool` (a one-thread executor) beside the former when one is
+    given: a job whose scenes all have their own map location loads a table per scene.  Returns what _native_batch_tail needs, or
+    None when the batch needs the Python reader (frames without masks to be dropped, mixed mask sizes, a pickle the native parser
+    does not know)."""
     from .reader import ERR_FORMAT, ReaderError
     t = [time.perf_counter()]
+    lanes_job = pool.submit(_native_batch_lanes, nt, names, lane_cache) if pool is not None else None
     try:
         man = nt.manifest(names, mask_dir, n_sweeps, ratio, classes.names, missing_ok)
         t.append(time.perf_counter())
@@ -288,14 +304,7 @@ def _native_batch_head(nt, names, mask_dir, n_sweeps, ratio, classes, missing_ok
     W, H = int(wh[0, 0]), int(wh[0, 1])
     if (wh[:, 0] != W).any() or (wh[:, 1] != H).any():
         return None
-    lanes, frame_lane, locs = [], [], []
-    for k, name in enumerate(names):
-        loc = nt.location(name)
-        if loc not in lane_cache:
-            lane_cache[loc] = np.asarray(nusc_io.load_lane_points(nt.dataroot, loc), np.float64).astype(np.float32).reshape(-1, 3)   # torch.Tensor(...) at :278
-        lanes.append(lane_cache[loc])
-        locs.append(loc)
-        frame_lane.extend([k] * nt.scene_samples(name))
+    lanes, frame_lane, locs = lanes_job.result() if lanes_job is not None else _native_batch_lanes(nt, names, lane_cache)
     t.append(time.perf_counter())
     if sub is not None:
         for key, a in (("host table walk + data.json", 0), ("host mask files", 1), ("host lane tables", 2)):
@@ -365,11 +374,14 @@ def lift_scenes_native(nt, scene_names, mask_dir, classes, device, row_to_out, n
     # three host threads in a row: (1) table walk, data files, mask files and lane tables of batch k+2, (2) the sweep files of
     # batch k+1 into a page-locked buffer, (3) this one: upload and launches of batch k.  The native calls release the
     # interpreter lock, so the three really overlap.
+    from concurrent.futures import ThreadPoolExecutor
+    lane_pool = ThreadPoolExecutor(max_workers=1)
+
     def heads():
         for b0 in range(0, len(scene_names), scenes_per_batch):
             names = list(scene_names[b0:b0 + scenes_per_batch])
             t0 = time.time()
-            head = _native_batch_head(nt, names, mask_dir, n_sweeps, ratio, classes, missing_ok, lane_cache, timer)
+            head = _native_batch_head(nt, names, mask_dir, n_sweeps, ratio, classes, missing_ok, lane_cache, timer, lane_pool)
             yield names, head, time.time() - t0
 
     def prepared():
@@ -400,6 +412,7 @@ def lift_scenes_native(nt, scene_names, mask_dir, classes, device, row_to_out, n
             timer["host upload + launches"] = timer.get("host upload + launches", 0.0) + time.time() - t2
             timer["gpu lifting"] = timer.get("gpu lifting", 0.0) + time.time() - t1
     drain(0)
+    lane_pool.shutdown(wait=False)
     if records:
         return torch.cat(records, 0)
     return torch.zeros(0, 10, dtype=torch.float64, device=device)
@@ -466,19 +479,35 @@ def main(argv=None):
             sample_rows = {t: i for i, t in enumerate(tabs.t["sample"].keys())}
             return toks, [_tokens_as_rows(hb, sample_rows) for hb in batches]
         # one rank: every finished batch's share of the result file is formatted right away, under the GPU work of the next ones
+        # (on a thread of its own: formatting a batch's boxes takes as long as uploading and launching the next batch)
+        import queue
+        import threading
         parts, next_first, streamed = [], [0], [world == 1]
+        write_q = queue.Queue()
+
+        def write_worker():
+            while True:
+                item = write_q.get()
+                if item is None:
+                    return
+                rec_np, first, count = item
+                t0 = time.time()
+                if rec_np is None or first != next_first[0]:
+                    streamed[0] = False
+                elif streamed[0]:
+                    parts.append(lifting.nuscenes_results_json_native(rec_np, tokens, classes, None, part=(first, count)))
+                    next_first[0] = first + count
+                timer["write"] += time.time() - t0
+        writer = threading.Thread(target=write_worker, daemon=True)
+        writer.start()
 
         def on_records(rec_np, first, count):
-            t0 = time.time()
-            if rec_np is None or first != next_first[0]:
-                streamed[0] = False
-            elif streamed[0]:
-                parts.append(lifting.nuscenes_results_json_native(rec_np, tokens, classes, None, part=(first, count)))
-                next_first[0] = first + count
-            timer["write"] += time.time() - t0
+            write_q.put((rec_np, first, count))
         mine = lift_scenes_native(nt, names[lo:hi], args.mask_dir, classes, device, row_to_out, args.n_sweeps, args.ratio, args.masks, timer,
                                   scenes_per_batch=max(1, args.scenes_per_batch), missing_ok=args.missing_ok, python_batch=python_batch,
                                   on_records=on_records if world == 1 else None)
+        write_q.put(None)
+        writer.join()
         streamed[0] = streamed[0] and next_first[0] == len(tokens)
     else:
         tables = tables_py()
