@@ -49,7 +49,7 @@ def compulsory_bytes(hb, planes, sum_hits, mode, fused, cloud_stored, rect_bytes
     F, M = hb.n_frames, hb.n_masks
     W, H = hb.width, hb.height
     rows = hb.n_raw_rows
-    raw = 4 * hb.raw_stride * rows
+    raw = hb.bytes_per_row * rows
     cloud = 16 * rows
     # hit words exist only for the 256-row blocks that hold an in-mask point (a third of them on the headline shape): the
     # projection writes, and the compaction reads, those and no others (r03; before: every row's)
@@ -539,10 +539,10 @@ def main(argv=None):
     # north_star's kernel: projection + in-mask test (one launch per pass), timed by HIP events on its launch stream
     # inside the timed region -- i.e. while the other batches in flight share the GPU with it
     rows = hb.n_raw_rows
-    per_row_in = (4 * hb.raw_stride if r["fused"] else 16) + (16 if (r["fused"] and cloud_stored) else 0)
+    per_row_in = (hb.bytes_per_row if r["fused"] else 16) + (16 if (r["fused"] and cloud_stored) else 0)
     roofline = roof("k_project_hits", r["stage_ms"]["project"], "k_project_hits<ONE_PLANE, FUSED, STRIDE>" if r["fused"] else "k_project_hits",
                     f"bytes that must cross HBM per launch = {per_row_in} B/row x {rows} rows: "
-                    + (f"raw sweep rows read ({4 * hb.raw_stride} B/row)" if r["fused"] else "prepared cloud read (16 B/row)")
+                    + (f"raw sweep rows read ({hb.bytes_per_row} B/row, layout {'quads: x,y,z of four rows side by side, the unused columns stay on the host' if hb.quads else 'rows as in the .bin files'})" if r["fused"] else "prepared cloud read (16 B/row)")
                     + (" + transformed cloud written (16 B/row)" if (r["fused"] and cloud_stored) else "")
                     + f" + hit words written, 4 B/row/plane ({eng.b.planes} plane(s)) for the {r['hit_rows']} rows in 256-row blocks that hold an "
                       "in-mask point (the others' words are neither written nor read since r03; cm3d_project_hit_rows counts them on the device's flags)"

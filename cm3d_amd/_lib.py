@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3D_LIB") or os.path.join(_HERE, "libcm3d_hip.so")      # CM3D_LIB: experiments only
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 CAM_STRIDE = 64
 SWEEP_XF_STRIDE = 24
 MAX_CAMS = 8
@@ -21,6 +21,7 @@ BBOX_STRIDE = 8          # int32 per mask in `bbox`: eroded bounds [0..3], store
 MAX_MATCH_BOXES = 1024
 MAX_FUSED_SWEEPS = 16
 MATCH_BOX_STRIDE = 6
+RAW_QUADS = 3            # raw_stride value of the quad layout (include/cm3d_hip.h, cm3d_sweep_prep)
 
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -30,7 +31,7 @@ SIGNATURES = {
     "cm3d_error_string": (C.c_char_p, [_i32]),
     "cm3d_removed_words": (_i64, [_i32, _i32]),
     "cm3d_batch_begin": (_i32, [_p, _p, _i32, _p, _i64, _p]),
-    "cm3d_sweep_prep": (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _i32, _f32, _p, _i32, _p, _p, _p, _p]),
+    "cm3d_sweep_prep": (_i32, [_p, _i32, _p, _p, _i32, _i32, _p, _p, _i32, _f32, _p, _i32, _p, _p, _p, _p]),
     "cm3d_rle_workspace_bytes": (_i64, [_i32]),
     "cm3d_rle_to_dense": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p]),
     "cm3d_erode_pack": (_i32, [_p, _i32, _i32, _i32, _p, _p, _p]),
@@ -39,9 +40,9 @@ SIGNATURES = {
     "cm3d_project_hit_rows": (_i32, [_p, _i64, _i32, _i32, _i32, _p, _p]),
     "cm3d_project_hits": (_i32, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32,
                                  _p, _p, _p, _p, _i64, _p, _p, _p]),
-    "cm3d_sweep_project_hits": (_i32, [_p, _i32, _p, _i32, _i32, _p, _p, _f32, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p,
+    "cm3d_sweep_project_hits": (_i32, [_p, _i32, _p, _p, _i32, _i32, _p, _p, _f32, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p,
                                        _p, _p, _i32, _i32, _i32, _f32, _i32, _p, _p, _p, _p, _i64, _p, _p, _p]),
-    "cm3d_compact_hits": (_i32, [_p, _i32, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p,
+    "cm3d_compact_hits": (_i32, [_p, _i32, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p,
                                  _i64, _p]),
     "cm3d_tile_work_bytes": (_i64, [_i32, _i32]),
     "cm3d_selftest_sqrt": (_i32, [C.c_uint32, C.c_uint32, _p, _p, _p]),

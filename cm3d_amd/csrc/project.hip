@@ -324,7 +324,7 @@ static __device__ void wedge_setup(const float *cm_global, int W, int H, float m
 }
 
 struct PhSweepIn {
-    const float *raw; int raw_stride; const int32_t *sweep_row_off; const float *sweep_xf; const int32_t *frame_sweep_off;
+    const float *raw; const float *intensity; int raw_stride; const int32_t *sweep_row_off; const float *sweep_xf; const int32_t *frame_sweep_off;
     int n_frames, n_sweeps; float halfw; float4 *points_out; int pt_cap; int32_t *pt_off_out; uint32_t *removed_bits;
 };
 
@@ -394,6 +394,7 @@ __global__ __launch_bounds__(64) void k_frame_tables(const PhSweepIn sw, int fus
         ns = sw.frame_sweep_off[f + 1] - sa;
         p0 = sw.sweep_row_off[sa];
         n = sw.sweep_row_off[sa + ns] - p0;
+        if (sw.raw_stride == CM3D_RAW_QUADS && (p0 & 3) && lane == 0) atomicOr(&status[0], 8);      // quad layout: a frame starts on a quad
         if (lane == 0) {
             sw.pt_off_out[f] = p0;
             if (f == n_frames - 1) {
@@ -534,8 +535,8 @@ template <bool KEEP>
 struct PhRows { static constexpr int S = KEEP ? 4 : 3; float v[4 * S]; };
 
 template <int STRIDE, bool KEEP>
-static __device__ __forceinline__ void ph_load_rows(PhRows<KEEP> &r, const float *__restrict__ src, int stride, size_t row0, int nvalid,
-                                                    int lane, int diag = 0)
+static __device__ __forceinline__ void ph_load_rows(PhRows<KEEP> &r, const float *__restrict__ src, const float *__restrict__ aux, int stride,
+                                                    size_t row0, int nvalid, int lane, int diag = 0)
 {
     constexpr int S = PhRows<KEEP>::S;
     if (PH_DIAG(8)) {
@@ -545,6 +546,32 @@ static __device__ __forceinline__ void ph_load_rows(PhRows<KEEP> &r, const float
             r.v[j * S] = (float)(i & 1023) * 0.05f - 20.f; r.v[j * S + 1] = (float)((i >> 10) & 63) * 0.5f - 8.f;
             r.v[j * S + 2] = -1.f;
             if (KEEP) r.v[j * S + 3] = 0.f;
+        }
+        return;
+    }
+    if (STRIDE == CM3D_RAW_QUADS) {
+        // quad layout (cm3d_hip.h): rows 4q..4q+3 of the batch are 12 floats x0..3 y0..3 z0..3 -- the lane's four rows are one
+        // 48-byte piece, three 16-byte loads; 12 bytes per row cross HBM and nothing else.  The fourth column, when the cloud
+        // is kept, comes from the intensity plane (`aux`, may be NULL: zeros).  Every frame starts on a quad (k_frame_tables
+        // checks), and a frame's last quad exists whole (its spare rows belong to the frame: NaN rows, see the header).
+        float q[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) q[k] = (k < 8) ? 1e30f : 0.f;
+        float w4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (4 * lane < nvalid) {
+            const float4 *p = reinterpret_cast<const float4 *>(src + (row0 + (size_t)(4 * lane)) * 3);
+            const float4 a = p[0], b = p[1], c = p[2];
+            q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+            q[8] = c.x; q[9] = c.y; q[10] = c.z; q[11] = c.w;
+            if (KEEP && aux) {
+                const float4 t = *reinterpret_cast<const float4 *>(aux + row0 + (size_t)(4 * lane));
+                w4[0] = t.x; w4[1] = t.y; w4[2] = t.z; w4[3] = t.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PH_PT; ++j) {
+            r.v[j * S] = q[j]; r.v[j * S + 1] = q[4 + j]; r.v[j * S + 2] = q[8 + j];
+            if (KEEP) r.v[j * S + 3] = w4[j];
         }
         return;
     }
@@ -608,7 +635,8 @@ static __device__ __forceinline__ int ph_sweep_of(const int32_t *srow, int ns, i
 // dropped rows are NaN points.
 template <bool ONE_PLANE, bool FUSED, int STRIDE, bool KEEP>
 __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
-    const float *__restrict__ src, int src_stride, const float *__restrict__ sweep_xf, float halfw, float4 *__restrict__ points_out,
+    const float *__restrict__ src, const float *__restrict__ src_aux, int src_stride, const float *__restrict__ sweep_xf, float halfw,
+    float4 *__restrict__ points_out,
     uint32_t *__restrict__ removed_bits, const int32_t *__restrict__ ft_all, const int4 *__restrict__ ment_all,
     const float *__restrict__ cams, int n_cams, const uint32_t *__restrict__ packed, int W, int H, int Wp, float min_dist, int nm_cap,
     int nwc_max, int n_points_total, uint32_t *__restrict__ hit_words, int32_t *__restrict__ hit_count, int32_t *__restrict__ wc_cnt,
@@ -646,8 +674,14 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
     // the chunk lists of the frame: taken[s] = entries of list s handed out so far (zeroed by k_frame_tables)
     int32_t *const taken = queue + (size_t)f * tpf;
     int list = slot, lists_left = PH_STEAL_LISTS;
+#ifdef CM3D_DIAG
+    int static_next = 0;                                            // diag bit 512: fixed shares, no draws (timing only)
+#endif
     auto draw = [&](int l) {                                        // request the next entry of list l; the answer is read later
         int v = 0;
+#ifdef CM3D_DIAG
+        if (diag & 512) return l == slot ? static_next++ : (1 << 20);
+#endif
         if (lane == 0) v = atomicAdd(&taken[l], 1);
         return v;
     };
@@ -683,7 +717,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
         return c;
     };
     PhRows<KEEP> cur;
-    ph_load_rows<STRIDE, KEEP>(cur, src, src_stride, (size_t)p0 + (size_t)slot * PH_WC, min(PH_WC, n - slot * PH_WC), lane, PH_DIAG(8));
+    ph_load_rows<STRIDE, KEEP>(cur, src, src_aux, src_stride, (size_t)p0 + (size_t)slot * PH_WC, min(PH_WC, n - slot * PH_WC), lane, PH_DIAG(8));
     {
 #pragma unroll
         for (int q = 0; q < CAM_Q; ++q) reinterpret_cast<float4 *>(s_cam)[lane + 64 * q] = t_cam[q];
@@ -698,7 +732,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
     int chunk = chunk_of(draw_v, slot);
     if (chunk >= nwc) return;                                       // a late start: the others have been through this frame's lists
     if (chunk != slot)                                              // entry 0 was gone
-        ph_load_rows<STRIDE, KEEP>(cur, src, src_stride, (size_t)p0 + (size_t)chunk * PH_WC, min(PH_WC, n - chunk * PH_WC), lane, PH_DIAG(8));
+        ph_load_rows<STRIDE, KEEP>(cur, src, src_aux, src_stride, (size_t)p0 + (size_t)chunk * PH_WC, min(PH_WC, n - chunk * PH_WC), lane, PH_DIAG(8));
     int c_nxt = chunk_of(draw2_v, slot);
     PH_STAMP(0);                                                    // frame setup
 
@@ -733,7 +767,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             }
             if (lane < 32) {
                 cnt_row[lane] = pend_cnt;
-                if (pend_cnt) atomicAdd(&grp_f[(pend_chunk / PH_GRP) * nm_cap + lane], pend_cnt);
+                if (pend_cnt && !PH_DIAG(256)) atomicAdd(&grp_f[(pend_chunk / PH_GRP) * nm_cap + lane], pend_cnt);
             }
         } else {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -767,7 +801,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
         // what the compaction wants to know about the chunk before it touches anything else of it
         if (lane == 0) {
             wc_info_f[pend_chunk] = pend_drop | (any ? (int)0x80000000 : 0);
-            if (pend_drop) atomicAdd(&grp_f[ngrp_max * nm_cap + pend_chunk / PH_GRP], pend_drop);
+            if (pend_drop && !PH_DIAG(256)) atomicAdd(&grp_f[ngrp_max * nm_cap + pend_chunk / PH_GRP], pend_drop);
         }
     };
     int draw_from = list;
@@ -832,7 +866,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
         flush_results();
         PhRows<KEEP> nxt;
         if (c_nxt < nwc) {
-            ph_load_rows<STRIDE, KEEP>(nxt, src, src_stride, (size_t)p0 + (size_t)c_nxt * PH_WC, min(PH_WC, n - c_nxt * PH_WC), lane, PH_DIAG(8));
+            ph_load_rows<STRIDE, KEEP>(nxt, src, src_aux, src_stride, (size_t)p0 + (size_t)c_nxt * PH_WC, min(PH_WC, n - c_nxt * PH_WC), lane, PH_DIAG(8));
             draw_from = list;
             draw_v = draw(list);                                    // the chunk after that one: answered during the camera loop
         }
@@ -1071,7 +1105,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
 //    mask bit: four ballots, rank = hits in lower lanes + own hits in earlier rows.  Every hit also gets its coordinates
 //    (gathered from the cloud when there is one, else re-derived from the raw row with the projection kernel's very fma
 //    chains).  No workgroup barrier on this path; no atomics on anything that is an output.
-struct PhXyzSrc { const float *raw; int raw_stride; const float *sweep_xf; const float4 *points; };
+struct PhXyzSrc { const float *raw; const float *intensity; int raw_stride; const float *sweep_xf; const float4 *points; };
 // CP_SPAN: consecutive wave-chunks per wave (a template parameter; divides PH_GRP)
 
 template <int CP_SPAN>
@@ -1261,10 +1295,18 @@ __global__ __launch_bounds__(256) void k_hit_xyz(const PhXyzSrc xs, const int32_
         float4 out;
         if (xs.points) out = xs.points[tag.x];
         else {
-            const float *p = xs.raw + (size_t)tag.x * xs.raw_stride;
+            float x, y, z, w;
+            if (xs.raw_stride == CM3D_RAW_QUADS) {              // quad layout: x, y, z of row r at 12 (r >> 2) + (r & 3) + 0 / 4 / 8
+                const float *p = xs.raw + (size_t)(tag.x >> 2) * 12 + (tag.x & 3);
+                x = p[0]; y = p[4]; z = p[8];
+                w = xs.intensity ? xs.intensity[tag.x] : 0.f;
+            } else {
+                const float *p = xs.raw + (size_t)tag.x * xs.raw_stride;
+                x = p[0]; y = p[1]; z = p[2]; w = p[3];
+            }
             float bx, by, bz;
-            ph_xform(xs.sweep_xf + (size_t)tag.y * CM3D_SWEEP_XF_STRIDE, p[0], p[1], p[2], bx, by, bz);
-            out = make_float4(bx, by, bz, p[3]);
+            ph_xform(xs.sweep_xf + (size_t)tag.y * CM3D_SWEEP_XF_STRIDE, x, y, z, bx, by, bz);
+            out = make_float4(bx, by, bz, w);
         }
         hit_xyz[pos] = out;
     }
@@ -1428,7 +1470,8 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
     const int stride = fused ? sw.raw_stride : 4;
     const bool keep = fused && sw.points_out != nullptr;
     // variants: prepared cloud | raw rows of 5, 4, any number of columns, each with and without the cloud store
-    const int which = !fused ? 0 : (stride == 5 ? 1 : (stride == 4 ? 2 : 3)) + (keep ? 3 : 0);
+    // ... | quad layout (12 bytes per row), with and without the cloud store
+    const int which = !fused ? 0 : stride == CM3D_RAW_QUADS ? (keep ? 8 : 7) : (stride == 5 ? 1 : (stride == 4 ? 2 : 3)) + (keep ? 3 : 0);
     const bool one = planes_cap == 1;
     const void *fn;
 #define PH_PICK(ONE)                                                                                                             \
@@ -1437,19 +1480,21 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
      : which == 2 ? (const void *)k_project_hits<ONE, true, 4, false>                                                            \
      : which == 3 ? (const void *)k_project_hits<ONE, true, 0, false>                                                            \
      : which == 4 ? (const void *)k_project_hits<ONE, true, 5, true>                                                             \
-     : which == 5 ? (const void *)k_project_hits<ONE, true, 4, true> : (const void *)k_project_hits<ONE, true, 0, true>)
+     : which == 5 ? (const void *)k_project_hits<ONE, true, 4, true>                                                             \
+     : which == 6 ? (const void *)k_project_hits<ONE, true, 0, true>                                                             \
+     : which == 7 ? (const void *)k_project_hits<ONE, true, CM3D_RAW_QUADS, false> : (const void *)k_project_hits<ONE, true, CM3D_RAW_QUADS, true>)
     if (one) fn = PH_PICK(true);
     else fn = PH_PICK(false);
 #undef PH_PICK
     size_t lds = one ? 0 : (size_t)PHK_WAVES * ((size_t)planes_cap * PH_WC * sizeof(uint32_t) + (size_t)nm_cap * sizeof(int));
     if (!one) {
-        static size_t lds_allowed[7] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+        static size_t lds_allowed[9] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
         if (lds > lds_allowed[which]) {
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CM3D_ERR_LAUNCH;
             lds_allowed[which] = lds;
         }
     }
-    static int blocks_one[7] = {0, 0, 0, 0, 0, 0, 0};                        // cached for the register-only variants (no dynamic LDS)
+    static int blocks_one[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                        // cached for the register-only variants (no dynamic LDS)
     int target = one ? blocks_one[which] : 0;
     if (!target) {
         target = ph_target_blocks(fn, lds);
@@ -1464,7 +1509,7 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
     if (tpf < 1) tpf = 1;
     const int gx = (int)(((long long)n_frames * tpf + PHK_WAVES - 1) / PHK_WAVES);
 #define PH_LAUNCH(ONE, FUSED, STRIDE, KEEP)                                                                                      \
-    hipLaunchKernelGGL((k_project_hits<ONE, FUSED, STRIDE, KEEP>), dim3(gx), dim3(PHK_THREADS), lds, st, src, stride, sw.sweep_xf,       \
+    hipLaunchKernelGGL((k_project_hits<ONE, FUSED, STRIDE, KEEP>), dim3(gx), dim3(PHK_THREADS), lds, st, src, sw.intensity, stride, sw.sweep_xf, \
                        sw.halfw, sw.points_out, sw.removed_bits, ws.ft, ws.ment, cams, n_cams, packed, W, H, Wp, min_dist, nm_cap, \
                        nwc_max, n_points_total, hit_words, hit_count, ws.wc_cnt, n_frames, tpf, ws.queue, ws.wc_info, ws.grp, ws.zstride,     \
                        ws.frame_hits)
@@ -1476,7 +1521,9 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
         else if (which == 3) PH_LAUNCH(ONE, true, 0, false);                                                                     \
         else if (which == 4) PH_LAUNCH(ONE, true, 5, true);                                                                      \
         else if (which == 5) PH_LAUNCH(ONE, true, 4, true);                                                                      \
-        else PH_LAUNCH(ONE, true, 0, true);                                                                                      \
+        else if (which == 6) PH_LAUNCH(ONE, true, 0, true);                                                                      \
+        else if (which == 7) PH_LAUNCH(ONE, true, CM3D_RAW_QUADS, false);                                                        \
+        else PH_LAUNCH(ONE, true, CM3D_RAW_QUADS, true);                                                                         \
     } while (0)
     hipLaunchKernelGGL(k_frame_tables, dim3(n_frames), dim3(64), 0, st, sw, fused ? 1 : 0, pt_off, n_frames, cams, n_cams, mask_off, mask_cam,
                        (const int4 *)bbox, W, H, min_dist, nm_cap, max_pts_per_frame, (uint32_t)H * (uint32_t)Wp, ws.ft, ws.ment, ws.queue, tpf,
@@ -1506,7 +1553,7 @@ extern "C" int cm3d_project_hits(const float *points, const int32_t *pt_off, int
                      stream);
 }
 
-extern "C" int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
+extern "C" int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const float *intensity, const int32_t *sweep_row_off, int32_t n_sweeps,
                                        int32_t max_sweeps_per_frame, const float *sweep_xf, const int32_t *frame_sweep_off,
                                        float halfw, float *points, int32_t pt_cap, int32_t *pt_off, uint32_t *removed_bits,
                                        int32_t n_frames, int32_t max_pts_per_frame, int32_t n_points_total,
@@ -1516,10 +1563,12 @@ extern "C" int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, con
                                        void *workspace, int64_t workspace_bytes, void *ev_start, void *ev_stop, cm3d_stream_t stream)
 {
     if (!raw || !sweep_row_off || !sweep_xf || !frame_sweep_off || !pt_off || !removed_bits) return CM3D_ERR_ARG;
-    if (raw_stride < 4 || n_sweeps <= 0 || pt_cap <= 0 || ((uintptr_t)points & 15)) return CM3D_ERR_ARG;
+    if ((raw_stride < 4 && raw_stride != CM3D_RAW_QUADS) || n_sweeps <= 0 || pt_cap <= 0 || ((uintptr_t)points & 15)) return CM3D_ERR_ARG;
+    if (raw_stride == CM3D_RAW_QUADS && (((uintptr_t)raw & 15) || ((uintptr_t)intensity & 15))) return CM3D_ERR_ARG;
+    if (raw_stride != CM3D_RAW_QUADS && intensity) return CM3D_ERR_ARG;                       // rows carry their own fourth column
     if (max_sweeps_per_frame <= 0 || max_sweeps_per_frame > PH_MAX_SWEEPS) return CM3D_ERR_ARG;
     PhSweepIn sw;
-    sw.raw = raw; sw.raw_stride = raw_stride; sw.sweep_row_off = sweep_row_off; sw.sweep_xf = sweep_xf;
+    sw.raw = raw; sw.intensity = intensity; sw.raw_stride = raw_stride; sw.sweep_row_off = sweep_row_off; sw.sweep_xf = sweep_xf;
     sw.frame_sweep_off = frame_sweep_off; sw.n_frames = n_frames; sw.n_sweeps = n_sweeps; sw.halfw = halfw;
     sw.points_out = (float4 *)points; sw.pt_cap = pt_cap; sw.pt_off_out = pt_off; sw.removed_bits = removed_bits;
     return ph_launch(&sw, nullptr, nullptr, n_frames, max_pts_per_frame, n_points_total, cams, n_cams, mask_off, mask_cam, bbox, packed,
@@ -1528,7 +1577,7 @@ extern "C" int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, con
 
 extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int32_t n_frames, int32_t max_pts_per_frame,
                                  int32_t n_points_total, const int32_t *mask_off, int32_t n_masks, const int32_t *hit_count,
-                                 const uint32_t *removed_bits, const float *raw, int32_t raw_stride, const float *sweep_xf,
+                                 const uint32_t *removed_bits, const float *raw, int32_t raw_stride, const float *intensity, const float *sweep_xf,
                                  const float *points, int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx, int32_t *hit_row,
                                  float *hit_xyz, int32_t idx_cap, int32_t *tile_work, int32_t *status, void *workspace,
                                  int64_t workspace_bytes, cm3d_stream_t stream)
@@ -1536,7 +1585,8 @@ extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int3
     if (!hit_words || !mask_off || !hit_count || !hit_off || !tile_off || !hit_idx || !status || !workspace) return CM3D_ERR_ARG;
     if (planes <= 0 || n_frames <= 0 || max_pts_per_frame <= 0 || n_points_total <= 0 || n_masks <= 0 || idx_cap <= 0)
         return CM3D_ERR_ARG;
-    if (hit_xyz && !points && !(raw && sweep_xf && raw_stride >= 4)) return CM3D_ERR_ARG;        // nothing to take the coordinates from
+    if (hit_xyz && !points && !(raw && sweep_xf && (raw_stride >= 4 || raw_stride == CM3D_RAW_QUADS))) return CM3D_ERR_ARG;        // nothing to take the coordinates from
+    if (intensity && raw_stride != CM3D_RAW_QUADS) return CM3D_ERR_ARG;
     if (((uintptr_t)hit_xyz & 15) || ((uintptr_t)points & 15)) return CM3D_ERR_ARG;
     if (workspace_bytes < cm3d_project_workspace_bytes(n_frames, max_pts_per_frame, planes) || ((uintptr_t)workspace & 15)) return CM3D_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1547,7 +1597,7 @@ extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int3
     const int64_t tile_cap64 = md_tile_cap(n_masks, idx_cap);
     const int tile_cap = (int)(tile_cap64 > 0x7FFFFFFF ? 0x7FFFFFFF : tile_cap64);
     PhXyzSrc xs;
-    xs.raw = raw; xs.raw_stride = raw_stride; xs.sweep_xf = sweep_xf; xs.points = (const float4 *)points;
+    xs.raw = raw; xs.intensity = intensity; xs.raw_stride = raw_stride; xs.sweep_xf = sweep_xf; xs.points = (const float4 *)points;
     static int span = 0;
     if (!span) { const char *e = getenv("CM3D_CP_SPAN"); span = e ? atoi(e) : 4; if (span != 2 && span != 8) span = 4; }
     // dynamic LDS: a slice of nm_cap ints per wave; the builder row needs MD_FROM_COUNTS_LDS ints

@@ -16,7 +16,7 @@
                                   // LDS-staged slab copy; raw rows are read once -> non-temporal loads keep the
                                   // Infinity Cache for the transformed cloud that k_project_hits reads next)
 
-__global__ __launch_bounds__(SW_THREADS) void k_sweep_xform(const float *__restrict__ raw, int raw_stride,
+__global__ __launch_bounds__(SW_THREADS) void k_sweep_xform(const float *__restrict__ raw, int raw_stride, const float *__restrict__ intensity,
                                                              const int32_t *__restrict__ sweep_row_off,
                                                              const float *__restrict__ sweep_xf,
                                                              const int32_t *__restrict__ frame_sweep_off, int n_frames,
@@ -64,12 +64,16 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_xform(const float *__restr
         const int i = k * SW_THREADS + t;
         const bool live = i < cnt;
         float x = 1e30f, y = 1e30f, z = 0.f, w = 0.f;
-        if (live) {
+        const int g = row_base + i;
+        if (live && raw_stride == CM3D_RAW_QUADS) {      // quad layout (cm3d_hip.h): x, y, z of row g at 12 (g >> 2) + (g & 3) + 0 / 4 / 8
+            const float *p = raw + (size_t)(g >> 2) * 12 + (g & 3);
+            x = __builtin_nontemporal_load(p); y = __builtin_nontemporal_load(p + 4); z = __builtin_nontemporal_load(p + 8);
+            w = intensity ? __builtin_nontemporal_load(intensity + g) : 0.f;
+        } else if (live) {
             const float *p = src + (size_t)i * raw_stride;
             x = __builtin_nontemporal_load(p); y = __builtin_nontemporal_load(p + 1);
             z = __builtin_nontemporal_load(p + 2); w = __builtin_nontemporal_load(p + 3);
         }
-        const int g = row_base + i;
         const bool drop = live && fabsf(x) < halfw && fabsf(y) < halfw;      // reference drops this row (2d_to_3d.py:442-445)
         if (drop) {
             const int r = g - frame_row0;
@@ -89,18 +93,19 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_xform(const float *__restr
     }
 }
 
-extern "C" int cm3d_sweep_prep(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
+extern "C" int cm3d_sweep_prep(const float *raw, int32_t raw_stride, const float *intensity, const int32_t *sweep_row_off, int32_t n_sweeps,
                                int32_t max_rows_per_sweep, const float *sweep_xf, const int32_t *frame_sweep_off,
                                int32_t n_frames, float halfw, float *points, int32_t pt_cap, int32_t *pt_off,
                                uint32_t *removed_bits, int32_t *status, cm3d_stream_t stream)
 {
     if (!raw || !sweep_row_off || !sweep_xf || !frame_sweep_off || !points || !pt_off || !removed_bits || !status)
         return CM3D_ERR_ARG;
-    if (raw_stride < 4 || n_sweeps <= 0 || n_frames <= 0 || max_rows_per_sweep <= 0 || pt_cap <= 0) return CM3D_ERR_ARG;
+    if ((raw_stride < 4 && raw_stride != CM3D_RAW_QUADS) || n_sweeps <= 0 || n_frames <= 0 || max_rows_per_sweep <= 0 || pt_cap <= 0) return CM3D_ERR_ARG;
+    if (intensity && raw_stride != CM3D_RAW_QUADS) return CM3D_ERR_ARG;
     if ((uintptr_t)points & 15) return CM3D_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sweep_xform, dim3((max_rows_per_sweep + SW_ROWS - 1) / SW_ROWS, n_sweeps), dim3(SW_THREADS), 0, st, raw,
-                       raw_stride, sweep_row_off, sweep_xf, frame_sweep_off, n_frames, n_sweeps, halfw, (float4 *)points, pt_cap,
+                       raw_stride, intensity, sweep_row_off, sweep_xf, frame_sweep_off, n_frames, n_sweeps, halfw, (float4 *)points, pt_cap,
                        pt_off, removed_bits, status);
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;

@@ -120,6 +120,8 @@ class HostBatch:
     height: int
     tokens: List[str]
     labels: List[List[str]]
+    intensity: Optional[np.ndarray] = None    # quad layout only: (rows,) float32, the rows' fourth column (None: not uploaded)
+    frame_rows: Optional[np.ndarray] = None   # quad layout only: (F,) rows of each frame without its padding rows
     pose_rt: Optional[np.ndarray] = None      # (F,12) float32, Waymo: vehicle -> global rotate/translate
     pose_inv: Optional[np.ndarray] = None     # (F,16) float32, Waymo: inverse of the float32 frame pose
     ego_box: bool = True                      # nuScenes drops the ego-box points (:442-445); Waymo does not
@@ -136,11 +138,65 @@ class HostBatch:
     def n_raw_rows(self):
         return int(self.sweep_row_off[-1])
 
+    @property
+    def quads(self):
+        return self.raw_stride == _lib.RAW_QUADS
+
+    @property
+    def n_real_rows(self):
+        """Rows the files held (the quad layout's padding rows left out)."""
+        return self.n_raw_rows if self.frame_rows is None else int(np.sum(self.frame_rows))
+
+    @property
+    def bytes_per_row(self):
+        """Bytes of a raw row that cross HBM in the projection launch."""
+        return 12 if self.quads else 4 * self.raw_stride
+
+
+def rows_to_quads(raw, sweep_row_off, frame_sweep_off, keep_intensity=True):
+    """Row-major sweeps (rows, >= 4 columns) -> the quad layout of include/cm3d_hip.h (cm3d_sweep_prep): every frame padded to a
+    multiple of 4 rows with NaN rows that belong to its last sweep, rows 4q..4q+3 stored as x0..3 y0..3 z0..3.
+    Returns (quads (R/4, 3, 4) float32, intensity (R,) float32 or None, sweep_row_off' (S+1,), frame_rows (F,)).
+    What the native reader does while it fills the page-locked batch (cm3d_amd.reader); this is the numpy form for
+    batches packed from arrays."""
+    raw = np.asarray(raw, np.float32)
+    sro = np.asarray(sweep_row_off, np.int64)
+    fso = np.asarray(frame_sweep_off, np.int64)
+    F = len(fso) - 1
+    frame_rows = (sro[fso[1:]] - sro[fso[:-1]]).astype(np.int32)
+    padded = (frame_rows.astype(np.int64) + 3) // 4 * 4
+    new_start = np.concatenate([[0], np.cumsum(padded)])
+    R = int(new_start[-1])
+    xyz = np.full((R, 3), np.nan, np.float32)
+    inten = np.zeros(R, np.float32) if keep_intensity else None
+    new_sro = np.zeros(len(sro), np.int64)
+    for f in range(F):
+        a, b = int(sro[fso[f]]), int(sro[fso[f + 1]])
+        d = int(new_start[f]) - a
+        xyz[a + d:b + d] = raw[a:b, :3]
+        if keep_intensity:
+            inten[a + d:b + d] = raw[a:b, 3]
+        new_sro[fso[f]:fso[f + 1]] = sro[fso[f]:fso[f + 1]] + d
+    new_sro[fso[-1]:] = R                      # the end of the last sweep = the padded end of the batch
+    # sweeps of a frame stay back to back; a frame's padding rows sit behind its last sweep, in front of the next frame's first
+    quads = np.ascontiguousarray(xyz.reshape(R // 4, 4, 3).transpose(0, 2, 1))
+    return quads, inten, new_sro.astype(np.int32), frame_rows
+
+
+def default_layout():
+    """Layout of the raw rows in a packed batch: "quads" (12 bytes per row cross HBM; include/cm3d_hip.h) unless
+    CM3D_RAW_LAYOUT=rows asks for the files' own rows."""
+    return os.environ.get("CM3D_RAW_LAYOUT", "quads")
+
 
 def pack_frames(frames: Sequence, lane_tables: Sequence[np.ndarray], frame_lane: Sequence[int],
-                classes: Optional[ClassTable] = None) -> HostBatch:
-    """frames: objects with the attributes of cm3d_amd.synthetic.Frame."""
+                classes: Optional[ClassTable] = None, layout: Optional[str] = None) -> HostBatch:
+    """frames: objects with the attributes of cm3d_amd.synthetic.Frame.  layout: "rows" (the sweeps as they are) or
+    "quads" (rows_to_quads); None = default_layout()."""
     classes = classes or ClassTable.nuscenes()
+    layout = layout or default_layout()
+    if layout not in ("rows", "quads"):
+        raise ValueError(layout)
     W, H = frames[0].width, frames[0].height
     n_cams = frames[0].cams.shape[0]
     raws, xfs, row_off, fso = [], [], [0], [0]
@@ -191,10 +247,16 @@ def pack_frames(frames: Sequence, lane_tables: Sequence[np.ndarray], frame_lane:
     lane32 = [np.asarray(t, np.float64).astype(np.float32).reshape(-1, 3) for t in lane_tables]   # torch.Tensor(...) at :278
     lane_off = np.concatenate([[0], np.cumsum([t.shape[0] for t in lane32])]).astype(np.int32)
     i32 = lambda a: np.asarray(a, np.int32)
+    raw = np.concatenate(raws, 0) if raws else np.zeros((0, stride), np.float32)
+    intensity = frame_rows = None
+    row_off = i32(row_off)
+    if layout == "quads":
+        raw, intensity, row_off, frame_rows = rows_to_quads(raw, row_off, fso)
+        stride = _lib.RAW_QUADS
     return HostBatch(
-        raw=np.concatenate(raws, 0) if raws else np.zeros((0, stride), np.float32), raw_stride=stride,
-        sweep_row_off=i32(row_off), sweep_xf=np.concatenate(xfs, 0), frame_sweep_off=i32(fso),
-        max_rows_per_sweep=max(1, max(r.shape[0] for r in raws)), cams=np.stack(cams), n_cams=n_cams,
+        raw=raw, raw_stride=stride, intensity=intensity, frame_rows=frame_rows,
+        sweep_row_off=row_off, sweep_xf=np.concatenate(xfs, 0), frame_sweep_off=i32(fso),
+        max_rows_per_sweep=max(1, int(np.diff(row_off).max())) if len(row_off) > 1 else 1, cams=np.stack(cams), n_cams=n_cams,
         mask_off=i32(mask_off), mask_cam=i32(mask_cam), mask_frame=i32(mask_frame),
         rle_counts=np.concatenate(cnts).astype(np.uint32) if cnts else np.zeros(0, np.uint32), rle_off=i32(rle_off),
         class_id=i32(class_id), score=np.asarray(score, np.float64),
@@ -397,6 +459,7 @@ class LiftEngine:
         # asynchronously; the small arrays above are pageable, their copies block the host until everything queued before them on
         # the stream is done -- behind the 180 MB of a C2 batch's sweeps that was the whole transfer time (4 ms), per batch.
         b.rle_counts = t(hb.rle_counts.view(np.int32))
+        b.intensity = t(hb.intensity) if hb.intensity is not None else None
         b.raw = t(hb.raw)
         self.b = b
         return b
@@ -439,7 +502,7 @@ class LiftEngine:
 
     def stage_sweeps(self, st):
         b = self.b
-        check(self.lib.cm3d_sweep_prep(_ptr(b.raw), b.hb.raw_stride, _ptr(b.sweep_row_off), b.S, b.hb.max_rows_per_sweep,
+        check(self.lib.cm3d_sweep_prep(_ptr(b.raw), b.hb.raw_stride, _ptr(b.intensity), _ptr(b.sweep_row_off), b.S, b.hb.max_rows_per_sweep,
                                        _ptr(b.sweep_xf), _ptr(b.frame_sweep_off), b.F, b.halfw, _ptr(b.points), b.pt_cap,
                                        _ptr(b.pt_off), _ptr(b.removed_bits), _ptr(b.status), st), "cm3d_sweep_prep")
 
@@ -486,7 +549,7 @@ class LiftEngine:
         stage_sweeps + stage_project, the cloud crosses HBM once less.  Needs the masks of the batch (stage_masks) first."""
         b = self.b
         e0, e1 = self._raw_events(events)
-        check(self.lib.cm3d_sweep_project_hits(_ptr(b.raw), b.hb.raw_stride, _ptr(b.sweep_row_off), b.S, b.max_sweeps, _ptr(b.sweep_xf),
+        check(self.lib.cm3d_sweep_project_hits(_ptr(b.raw), b.hb.raw_stride, _ptr(b.intensity), _ptr(b.sweep_row_off), b.S, b.max_sweeps, _ptr(b.sweep_xf),
                                                _ptr(b.frame_sweep_off), b.halfw, _ptr(b.points), b.pt_cap, _ptr(b.pt_off),
                                                _ptr(b.removed_bits), b.F, b.max_pts, b.pt_cap, _ptr(b.cams),
                                                b.hb.n_cams, _ptr(b.mask_off), _ptr(b.mask_cam), _ptr(b.bbox), _ptr(b.packed), b.M, b.W,
@@ -499,7 +562,7 @@ class LiftEngine:
         from_raw = b.points is None
         check(self.lib.cm3d_compact_hits(_ptr(b.hit_words), b.planes, b.F, b.max_pts, b.pt_cap, _ptr(b.mask_off), b.M, _ptr(b.hit_count),
                                          _ptr(b.removed_bits), _ptr(b.raw) if from_raw else 0, b.hb.raw_stride,
-                                         _ptr(b.sweep_xf) if from_raw else 0, _ptr(b.points), _ptr(b.hit_off), _ptr(b.tile_off),
+                                         _ptr(b.intensity) if from_raw else 0, _ptr(b.sweep_xf) if from_raw else 0, _ptr(b.points), _ptr(b.hit_off), _ptr(b.tile_off),
                                          _ptr(b.hit_idx), 0, _ptr(b.hit_xyz), b.idx_cap, _ptr(b.tile_work), _ptr(b.status),
                                          _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_compact_hits")
 
@@ -610,6 +673,8 @@ class LiftEngine:
                             "raise hits_per_point")
         if s[0] & 4:
             raise Cm3dError("a frame has too many masks or a cam_num is out of range")
+        if s[0] & 8:
+            raise Cm3dError("quad layout: a frame does not start on a multiple of 4 rows")
         return s
 
     def removed_rows(self):
@@ -643,6 +708,10 @@ class LiftEngine:
         n_rows, n_idx = int(s[1]), int(s[2])
         pt_off_rows = b.pt_off.cpu().numpy()
         keep = ~self.removed_rows()[:n_rows]
+        if b.hb.frame_rows is not None:         # quad layout: a frame's padding rows are not rows of the reference's cloud
+            for f in range(b.F):
+                p0 = int(pt_off_rows[f])
+                keep[p0 + int(b.hb.frame_rows[f]):int(pt_off_rows[f + 1])] = False
         kept_per_frame = np.add.reduceat(keep.astype(np.int64), pt_off_rows[:-1]) if n_rows else np.zeros(b.F, np.int64)
         kept_per_frame = np.where(np.diff(pt_off_rows) > 0, kept_per_frame, 0)
         out = dict(

@@ -127,7 +127,7 @@ def points_in_masks(points, cams, packed, bbox, cam_nums, W, H, min_dist=2.3):
                               mask_cam.data_ptr(), bbox.data_ptr(), packed.data_ptr(), n, W, H, float(np.float32(min_dist)), planes,
                               hit_words.data_ptr(), hit_count.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), 0, 0, st),
           "cm3d_project_hits")
-    check(L.cm3d_compact_hits(hit_words.data_ptr(), planes, 1, N, N, mask_off.data_ptr(), n, hit_count.data_ptr(), 0, 0, 0, 0,
+    check(L.cm3d_compact_hits(hit_words.data_ptr(), planes, 1, N, N, mask_off.data_ptr(), n, hit_count.data_ptr(), 0, 0, 0, 0, 0,
                               pts.data_ptr(), hit_off.data_ptr(), tile_off.data_ptr(), hit_idx.data_ptr(), 0, 0, cap, 0,
                               status.data_ptr(), ws.data_ptr(), ws.numel(), st), "cm3d_compact_hits")
     s = status.cpu().numpy()

@@ -126,7 +126,7 @@ def prepare_scene_batch(task):
     # one engine call per mask size (all cameras of nuScenes share one)
     for (W, H) in sorted({(frames[i].width, frames[i].height) for i in live}):
         sel = [i for i in live if (frames[i].width, frames[i].height) == (W, H)]
-        batches.append(lifting.pack_frames([frames[i] for i in sel], lanes, [frame_lane[i] for i in sel], classes))
+        batches.append(lifting.pack_frames([frames[i] for i in sel], lanes, [frame_lane[i] for i in sel], classes, layout="rows"))
     if through_shm:                         # reader process: the sweeps (nearly all of the bytes) go through shared memory
         from multiprocessing import shared_memory
         for hb in batches:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CM3D_ABI_VERSION 3
+#define CM3D_ABI_VERSION 4
 
 #define CM3D_OK 0
 #define CM3D_ERR_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
@@ -39,6 +39,7 @@ extern "C" {
 
 #define CM3D_CAM_STRIDE 64       /* floats per camera record, see cm3d_project_hits   */
 #define CM3D_SWEEP_XF_STRIDE 24  /* floats per sweep transform, see cm3d_sweep_prep   */
+#define CM3D_RAW_QUADS 3         /* raw_stride value that selects the quad layout of the raw rows, see cm3d_sweep_prep (ABI v4) */
 #define CM3D_MAX_CAMS 8          /* cameras per frame                                  */
 #define CM3D_MAX_MASKS_PER_FRAME 1024
 #define CM3D_BBOX_STRIDE 8                 /* int32 per mask in `bbox` (ABI v3): eroded bounds [0..3], stored rectangle [4..7] */
@@ -49,7 +50,8 @@ extern "C" {
 
 /* status word written by kernels (int32[4] in device memory, zero it per batch):
  *  [0] bit0: point capacity overflow (cm3d_sweep_prep), bit1: hit-index capacity
- *      overflow (cm3d_compact_hits), bit2: too many masks in a frame / cams out of range
+ *      overflow (cm3d_compact_hits), bit2: too many masks in a frame / cams out of range,
+ *      bit3: quad layout with a frame that does not start on a quad (cm3d_sweep_project_hits)
  *  [1] total points produced by cm3d_sweep_prep
  *  [2] total hit indices required by cm3d_compact_hits
  *  [3] total medoid tiles */
@@ -73,7 +75,16 @@ int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, uint3
  * they are written as NaN points (inert downstream) and marked in a bit set, and cm3d_compact_hits turns row
  * indices into indices of the reference's compacted cloud.  So point p of frame f sits at row pt_off[f]+p
  * of its raw rows.
- *  raw          float[rows][raw_stride]   all sweeps of the batch, back to back
+ *  raw          float[rows][raw_stride]   all sweeps of the batch, back to back (raw_stride >= 4: the .bin files' rows), or
+ *                                         raw_stride == CM3D_RAW_QUADS (ABI v4): the QUAD layout, float[ceil(rows/4)][3][4] --
+ *                                         rows 4q..4q+3 of the batch as x0 x1 x2 x3 y0 y1 y2 y3 z0 z1 z2 z3, 16-byte aligned.
+ *                                         12 bytes per row cross HBM (the path never reads the .bin files' ring index, and the
+ *                                         intensity only for the points it lists), a lane's four rows are three 16-byte loads.
+ *                                         In this layout every frame's first row is a multiple of 4: the loader pads a frame
+ *                                         with up to 3 rows of NaN coordinates, which belong to the frame's last sweep and are
+ *                                         rows like any other (never dropped, in no mask, at the end of the frame, so no index
+ *                                         of a real row moves); status bit 8 reports a frame that starts inside a quad
+ *  intensity    float[rows] or NULL       quad layout only: the rows' fourth column (goes into points / hit_xyz; NULL: zeros)
  *  sweep_row_off int32[S+1]               row offsets of the sweeps into raw
  *  sweep_xf     float[S][24]              [0..8] R_cs, [9..11] t_cs, [12..20] R_ego, [21..23] t_ego (float32,
  *                                         exactly the tensors the reference passes to rotate/translate)
@@ -83,7 +94,7 @@ int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, uint3
  *  removed_bits uint32[cm3d_removed_words(rows, F)] IN/OUT  one bit per dropped row; must be zero on entry
  *                                         (cm3d_batch_begin).  Frame f's bits start at word (pt_off[f] >> 5) + 8 f,
  *                                         bit (r & 31) of word r >> 5 for its frame-local row r */
-int cm3d_sweep_prep(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
+int cm3d_sweep_prep(const float *raw, int32_t raw_stride, const float *intensity, const int32_t *sweep_row_off, int32_t n_sweeps,
                     int32_t max_rows_per_sweep, const float *sweep_xf, const int32_t *frame_sweep_off,
                     int32_t n_frames, float halfw, float *points, int32_t pt_cap, int32_t *pt_off,
                     uint32_t *removed_bits, int32_t *status, cm3d_stream_t stream);
@@ -160,9 +171,9 @@ int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_fram
  * only need the in-mask points, which cm3d_compact_hits re-derives from the raw rows into hit_xyz); non-NULL = the cloud
  * is also written, bit for bit what cm3d_sweep_prep writes.  max_sweeps_per_frame (host-side knowledge of
  * frame_sweep_off) must be <= 16; use the two separate calls otherwise.  Arguments as in cm3d_sweep_prep and
- * cm3d_project_hits.  Rows of 4 or 5 floats (the reference's .bin layouts) take the fast path: 16-byte loads. */
+ * cm3d_project_hits.  Rows of 4 or 5 floats (the reference's .bin layouts) and the quad layout have their own instantiations. */
 #define CM3D_MAX_FUSED_SWEEPS 16
-int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t *sweep_row_off, int32_t n_sweeps,
+int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const float *intensity, const int32_t *sweep_row_off, int32_t n_sweeps,
                             int32_t max_sweeps_per_frame, const float *sweep_xf, const int32_t *frame_sweep_off,
                             float halfw, float *points, int32_t pt_cap, int32_t *pt_off, uint32_t *removed_bits,
                             int32_t n_frames, int32_t max_pts_per_frame, int32_t n_points_total,
@@ -174,7 +185,7 @@ int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t 
 /* ---- a7-a8: ordered compaction of the hits ----------------------------------
  * Replaces torch.where + the two .cpu() index-tracking steps at 2d_to_3d.py:606,613-617.
  *  removed_bits  from cm3d_sweep_prep / cm3d_sweep_project_hits (NULL when the points were not produced by them)
- *  raw, raw_stride, sweep_xf  the raw rows the fused launch read (NULL when `points` is given)
+ *  raw, raw_stride, intensity, sweep_xf  the raw rows the fused launch read (NULL when `points` is given)
  *  points   float[pt_cap][4] the transformed cloud, or NULL when it was not materialised
  *  hit_off  int32[n_masks+1] OUT exclusive scan of hit_count
  *  tile_off int32[n_masks+1] OUT exclusive scan of ceil(hit_count/CM3D_MEDOID_TILE)
@@ -193,7 +204,7 @@ int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const int32_t 
  * a one-thread-per-point launch then fetches and transforms the listed rows (all gathers in flight at once). */
 int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int32_t n_frames, int32_t max_pts_per_frame,
                       int32_t n_points_total, const int32_t *mask_off, int32_t n_masks, const int32_t *hit_count,
-                      const uint32_t *removed_bits, const float *raw, int32_t raw_stride, const float *sweep_xf,
+                      const uint32_t *removed_bits, const float *raw, int32_t raw_stride, const float *intensity, const float *sweep_xf,
                       const float *points, int32_t *hit_off, int32_t *tile_off, int32_t *hit_idx, int32_t *hit_row,
                       float *hit_xyz, int32_t idx_cap, int32_t *tile_work, int32_t *status, void *workspace,
                       int64_t workspace_bytes, cm3d_stream_t stream);

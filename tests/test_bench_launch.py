@@ -52,8 +52,12 @@ def test_byte_accounting_counts_only_bytes_that_move():
     assert bench.packed_rect_bytes(bbox, 50) == 4 * (163 // 32 - 64 // 32 + 1) * 50
 
     class HB:
-        n_frames, n_masks, width, height, raw_stride, n_raw_rows = 2, 2, 1600, 900, 5, 70000
+        n_frames, n_masks, width, height, raw_stride, n_raw_rows, bytes_per_row = 2, 2, 1600, 900, 5, 70000, 20
         rle_counts = np.zeros(1000, np.uint32)
+
+    class HBQ(HB):              # the quad layout: 12 bytes of a row cross HBM
+        raw_stride, bytes_per_row = 3, 12
+    assert bench.compulsory_bytes(HBQ, 1, 5000, "rle", True, False, 1000)["k_project_hits"] == 70000 * (12 + 4)
     by = bench.compulsory_bytes(HB, 1, 5000, "rle", True, False, 1000)
     assert by["k_project_hits"] == 70000 * (20 + 4)                       # raw rows in, hit words out, no cloud, no phantom masks
     assert bench.compulsory_bytes(HB, 1, 5000, "rle", True, True, 1000)["k_project_hits"] == 70000 * (20 + 4 + 16)

@@ -475,7 +475,7 @@ def _full_size(cfg_name, n_batch, oracle):
 def test_c4_waymo_shape_at_full_size(oracle):
     """BASELINE C4: 180 k points, 5 cameras, 20 masks of 1920x1280 per frame."""
     hb, a, cnt = _full_size("c4", 12, oracle)
-    assert hb.n_raw_rows == 12 * 180000 and (hb.width, hb.height, hb.n_cams) == (1920, 1280, 5)
+    assert hb.n_real_rows == 12 * 180000 and (hb.width, hb.height, hb.n_cams) == (1920, 1280, 5)
     assert a["hit_idx"].size > 20000
 
 
@@ -483,7 +483,7 @@ def test_c5_ten_sweeps_eighty_masks_at_full_size(oracle):
     """BASELINE C5: 10 sweeps x 35 k points and 80 masks of 1600x900 per frame (3 hit-word planes, lists of thousands of
     points: the two-pass medoid on the batch, the exact one -- keep_colsum -- on the frame compared with the oracle)."""
     hb, a, cnt = _full_size("c5", 6, oracle)
-    assert hb.n_raw_rows == 6 * 350000 and int(np.diff(hb.mask_off).max()) == 80 and int(np.diff(hb.frame_sweep_off).max()) == 10
+    assert hb.n_real_rows == 6 * 350000 and int(np.diff(hb.mask_off).max()) == 80 and int(np.diff(hb.frame_sweep_off).max()) == 10
     assert cnt.max() > 512 and a["hit_idx"].size > 100000
 
 

@@ -88,7 +88,7 @@ def test_pack_frames_layout_and_validation():
     lanes = [syn.make_lane_table([600, 1600], 500, seed=0)]
     hb = lifting.pack_frames(frames, lanes, [0, 0, 0])
     assert hb.n_frames == 3 and hb.n_masks == 3 * cfg.n_masks
-    assert hb.sweep_row_off[-1] == sum(r.shape[0] for f in frames for r in f.sweeps_raw)
+    assert hb.n_real_rows == sum(r.shape[0] for f in frames for r in f.sweeps_raw)
     assert np.array_equal(hb.mask_frame, np.repeat(np.arange(3), cfg.n_masks))
     assert hb.lane.dtype == np.float32 and hb.lane_off.tolist() == [0, 500]
     # labels are renamed like get_detection_name and mapped to the class table
