@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <vector>
 #include <cstdlib>
+#include <type_traits>
 
 #ifdef CM3D_DIAG
 // Diagnostic build only (make diag -> libcm3d_hip_diag.so; tools/ph_diag.py): ablation switches and per-phase
@@ -71,6 +72,9 @@ extern "C" int cm3d_diag_read(unsigned long long *out_host)
 {
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_ph_stamp), 8 * sizeof(unsigned long long)) == hipSuccess ? CM3D_OK : CM3D_ERR_LAUNCH;
 }
+// k_project_q: stages of the chunk loop that run (project_q.h); CM3D_PQ_STAGE sets the start value (PMC passes per stage)
+int g_pq_stage = getenv("CM3D_PQ_STAGE") ? atoi(getenv("CM3D_PQ_STAGE")) : 99;
+extern "C" int cm3d_diag_pq_stage(int stage) { g_pq_stage = stage; return CM3D_OK; }
 #else
 #define PH_DIAG(bit) 0
 #define PH_STAMP(k) do { } while (0)
@@ -844,11 +848,15 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             }
             drop_now = 0;
             if (__ballot(nib != 0u)) {
-                drop_now = __builtin_amdgcn_readfirstlane(cm3d_wave_sum(__popc(nib)));
+                // (r04: ballots and data-parallel-primitive moves instead of nine dependent ds_bpermute round trips, see project_q.h)
+#pragma unroll
+                for (int j = 0; j < PH_PT; ++j) drop_now += (int)__popcll(__ballot((nib >> j) & 1u));
                 // this chunk's 8 words of the frame's removed-row bits (zeroed by cm3d_batch_begin): lane l holds bits 4(l&7)..+3 of word l>>3
-                uint32_t vv = nib << (4 * (lane & 7));
-                vv |= (uint32_t)__shfl_xor((int)vv, 1, 64); vv |= (uint32_t)__shfl_xor((int)vv, 2, 64); vv |= (uint32_t)__shfl_xor((int)vv, 4, 64);
-                if ((lane & 7) == 0) removed_bits[(size_t)bits_off + 8 * chunk + (lane >> 3)] = vv;
+                int vv = (int)(nib << (4 * (lane & 7)));
+                vv |= __builtin_amdgcn_update_dpp(0, vv, 0xB1, 0xF, 0xF, true);
+                vv |= __builtin_amdgcn_update_dpp(0, vv, 0x4E, 0xF, 0xF, true);
+                vv |= __builtin_amdgcn_update_dpp(0, vv, 0x104, 0xF, 0xF, true);
+                if ((lane & 7) == 0) removed_bits[(size_t)bits_off + 8 * chunk + (lane >> 3)] = (uint32_t)vv;
             }
         } else {
 #pragma unroll
@@ -1091,6 +1099,8 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
     }
 #endif
 }
+
+#include "project_q.h"
 
 // The compaction: hit words -> ascending index lists (hit_idx) and the coordinates of every listed point (hit_xyz).
 // grid (ceil(ceil(nwc_max / CP_SPAN) / 4), F + 1), one launch for everything behind the projection:
@@ -1486,19 +1496,26 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
     if (one) fn = PH_PICK(true);
     else fn = PH_PICK(false);
 #undef PH_PICK
-    size_t lds = one ? 0 : (size_t)PHK_WAVES * ((size_t)planes_cap * PH_WC * sizeof(uint32_t) + (size_t)nm_cap * sizeof(int));
-    if (!one) {
+    // the quad layout has its own kernel (project_q.h) for frames of up to 96 masks; CM3D_PQ=0: k_project_hits reads the quads
+    static int pq_on = -1;
+    if (pq_on < 0) { const char *e = getenv("CM3D_PQ"); pq_on = e ? atoi(e) : 1; }
+    const bool pq = pq_on && (which == 7 || which == 8) && planes_cap <= 3;
+    if (pq) fn = one ? (keep ? (const void *)k_project_q<1, true> : (const void *)k_project_q<1, false>)
+                     : (keep ? (const void *)k_project_q<3, true> : (const void *)k_project_q<3, false>);
+    size_t lds = (one || pq) ? 0 : (size_t)PHK_WAVES * ((size_t)planes_cap * PH_WC * sizeof(uint32_t) + (size_t)nm_cap * sizeof(int));
+    if (!one && !pq) {
         static size_t lds_allowed[9] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
         if (lds > lds_allowed[which]) {
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CM3D_ERR_LAUNCH;
             lds_allowed[which] = lds;
         }
     }
-    static int blocks_one[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                        // cached for the register-only variants (no dynamic LDS)
-    int target = one ? blocks_one[which] : 0;
+    static int blocks_one[9 + 4] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // cached for the register-only variants (no dynamic LDS)
+    const int slot_id = pq ? 9 + (one ? 0 : 2) + (keep ? 1 : 0) : which;
+    int target = (one || pq) ? blocks_one[slot_id] : 0;
     if (!target) {
         target = ph_target_blocks(fn, lds);
-        if (one) blocks_one[which] = target;
+        if (one || pq) blocks_one[slot_id] = target;
     }
     // tickets per frame: about PH_OVERSUB times as many waves as the chip holds at once (see the kernel's header), at least
     // two wave-chunks per ticket when the frames are that long
@@ -1531,7 +1548,22 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
     CM3D_CHECK_LAUNCH();
     // optional timing events around the projection kernel itself (the table kernel above is not part of it)
     if (ev_start && hipEventRecord((hipEvent_t)ev_start, st) != hipSuccess) return CM3D_ERR_LAUNCH;
-    if (one) PH_LAUNCH_S(true);
+    if (pq) {
+        PqArgs qa;
+        qa.raw = src; qa.inten = sw.intensity; qa.sweep_xf = sw.sweep_xf; qa.points_out = sw.points_out; qa.removed_bits = sw.removed_bits;
+        qa.ft_all = ws.ft; qa.ment_all = ws.ment; qa.cams = cams; qa.packed = packed; qa.hit_words = hit_words; qa.hit_count = hit_count;
+        qa.wc_cnt = ws.wc_cnt; qa.queue = ws.queue; qa.wc_info = ws.wc_info; qa.grp = ws.grp; qa.frame_hits = ws.frame_hits;
+        qa.halfw = sw.halfw; qa.min_dist = min_dist; qa.n_cams = n_cams; qa.W = W; qa.H = H; qa.nm_cap = nm_cap; qa.nwc_max = nwc_max;
+        qa.n_points_total = n_points_total; qa.n_frames = n_frames; qa.tpf = tpf; qa.zstride = ws.zstride;
+        qa.stage = 99;
+#ifdef CM3D_DIAG
+        qa.stage = g_pq_stage;
+#endif
+        if (one) { if (keep) hipLaunchKernelGGL((k_project_q<1, true>), dim3(gx), dim3(PHK_THREADS), 0, st, qa);
+                   else hipLaunchKernelGGL((k_project_q<1, false>), dim3(gx), dim3(PHK_THREADS), 0, st, qa); }
+        else { if (keep) hipLaunchKernelGGL((k_project_q<3, true>), dim3(gx), dim3(PHK_THREADS), 0, st, qa);
+               else hipLaunchKernelGGL((k_project_q<3, false>), dim3(gx), dim3(PHK_THREADS), 0, st, qa); }
+    } else if (one) PH_LAUNCH_S(true);
     else PH_LAUNCH_S(false);
     if (ev_stop && hipEventRecord((hipEvent_t)ev_stop, st) != hipSuccess) return CM3D_ERR_LAUNCH;
 #undef PH_LAUNCH_S
