@@ -6,6 +6,7 @@
 #include "../../include/cm3d_reader.h"
 
 #include <atomic>
+#include <limits>
 #include <condition_variable>
 #include <cstring>
 #include <fcntl.h>
@@ -414,6 +415,91 @@ extern "C" int cm3d_reader_load_sweeps(cm3d_reader *r, const char *const *paths,
             // (a file that changed size between the two looks is an I/O error, not a buffer overrun)
             if (fd < 0 || fstat(fd, &st) != 0 || st.st_size != n * row_bytes || !read_fully(fd, raw_out + a * stride, (size_t)(n * row_bytes))) bad = i;
             if (fd >= 0) close(fd);
+        });
+        if (bad >= 0) { if (bad_index) *bad_index = bad; return CM3D_RD_ERR_IO; }
+        return CM3D_RD_OK;
+    } catch (...) {
+        return CM3D_RD_ERR_IO;
+    }
+}
+
+// The same files into the QUAD layout of include/cm3d_hip.h (cm3d_sweep_prep): x, y, z of batch rows 4q..4q+3 side by side (12 floats per
+// quad), every frame padded to a multiple of 4 rows with NaN rows that belong to its last sweep.  Of a row's 20 bytes in the file 12 reach
+// the batch (16 with the intensity plane); the ring index never leaves the page cache.  A task reads its file in pieces of PIECE rows into a
+// buffer of its own (L2-sized) and scatters them: 3 (4) stores per row -- a sweep may start anywhere inside a quad, so the rows of one file
+// and the next can share a quad; they never share a float.
+extern "C" int cm3d_reader_load_sweeps_quads(cm3d_reader *r, const char *const *paths, int32_t n_files, int32_t file_stride,
+                                             const int32_t *frame_sweep_off, int32_t n_frames, float *quads_out, float *intensity_out,
+                                             int64_t cap_rows, int32_t *sweep_row_off, int32_t *frame_rows, int32_t *bad_index)
+{
+    if (!r || !paths || n_files < 0 || file_stride < 4 || !frame_sweep_off || n_frames < 0 || !sweep_row_off || !frame_rows ||
+        (!quads_out && cap_rows > 0) || ((uintptr_t)quads_out & 15))
+        return CM3D_RD_ERR_ARG;
+    if (bad_index) *bad_index = -1;
+    try {
+        if (frame_sweep_off[0] != 0 || frame_sweep_off[n_frames] != n_files) return CM3D_RD_ERR_ARG;
+        const int64_t row_bytes = (int64_t)file_stride * 4;
+        std::vector<int64_t> file_rows((size_t)n_files);
+        for (int i = 0; i < n_files; ++i) {
+            struct stat st;
+            if (!paths[i] || stat(paths[i], &st) != 0 || !S_ISREG(st.st_mode)) { if (bad_index) *bad_index = i; return CM3D_RD_ERR_IO; }
+            if (st.st_size % row_bytes) { if (bad_index) *bad_index = i; return CM3D_RD_ERR_FORMAT; }
+            file_rows[i] = st.st_size / row_bytes;
+        }
+        // padded numbering: sweeps of a frame back to back, the next frame on the next multiple of 4
+        int64_t rows = 0;
+        for (int f = 0; f < n_frames; ++f) {
+            if (frame_sweep_off[f + 1] < frame_sweep_off[f]) return CM3D_RD_ERR_ARG;
+            int64_t fr = 0;
+            for (int i = frame_sweep_off[f]; i < frame_sweep_off[f + 1]; ++i) {
+                sweep_row_off[i] = (int32_t)(rows + fr);
+                fr += file_rows[i];
+                if (rows + fr > 0x7FFFFFF0) { if (bad_index) *bad_index = i; return CM3D_RD_ERR_CAPACITY; }
+            }
+            frame_rows[f] = (int32_t)fr;
+            rows += (fr + 3) & ~(int64_t)3;
+        }
+        sweep_row_off[n_files] = (int32_t)rows;
+        // (a frame's padding belongs to its last sweep: sweep_row_off of the next frame's first sweep is the padded start, set above)
+        if (rows > cap_rows) return CM3D_RD_ERR_CAPACITY;
+        const float qnan = std::numeric_limits<float>::quiet_NaN();
+        for (int f = 0; f < n_frames; ++f) {                            // the padding rows (at most 3 per frame)
+            const int i1 = frame_sweep_off[f + 1];
+            if (i1 == frame_sweep_off[f]) continue;
+            const int64_t end = (int64_t)sweep_row_off[frame_sweep_off[f]] + frame_rows[f], pend = (end + 3) & ~(int64_t)3;
+            for (int64_t q = end; q < pend; ++q) {
+                float *d = quads_out + (q >> 2) * 12 + (q & 3);
+                d[0] = qnan; d[4] = qnan; d[8] = qnan;
+                if (intensity_out) intensity_out[q] = 0.f;
+            }
+        }
+        std::atomic<int> bad{-1};
+        constexpr int64_t PIECE = 4096;                                 // rows per read: 80 KB of a 5-column file
+        r->pool.run(n_files, [&](int i) {
+            const int64_t a = sweep_row_off[i], n = file_rows[i];
+            if (n == 0) return;
+            const int fd = open(paths[i], O_RDONLY);
+            struct stat st;
+            if (fd < 0 || fstat(fd, &st) != 0 || st.st_size != n * row_bytes) { bad = i; if (fd >= 0) close(fd); return; }
+            std::vector<float> buf((size_t)(PIECE * file_stride));
+            for (int64_t r0 = 0; r0 < n; r0 += PIECE) {
+                const int64_t m = std::min(PIECE, n - r0);
+                size_t off = 0;
+                const size_t want = (size_t)(m * row_bytes);
+                while (off < want) {
+                    const ssize_t got = pread(fd, (char *)buf.data() + off, want - off, (off_t)(r0 * row_bytes + (int64_t)off));
+                    if (got <= 0) { bad = i; close(fd); return; }
+                    off += (size_t)got;
+                }
+                const float *src = buf.data();
+                int64_t q = a + r0;
+                for (int64_t k = 0; k < m; ++k, ++q, src += file_stride) {
+                    float *d = quads_out + (q >> 2) * 12 + (q & 3);
+                    d[0] = src[0]; d[4] = src[1]; d[8] = src[2];
+                    if (intensity_out) intensity_out[q] = src[3];
+                }
+            }
+            close(fd);
         });
         if (bad >= 0) { if (bad_index) *bad_index = bad; return CM3D_RD_ERR_IO; }
         return CM3D_RD_OK;
@@ -1015,6 +1101,21 @@ extern "C" int cm3d_manifest_load_sweeps(cm3d_reader *r, const cm3d_manifest *m,
         std::vector<const char *> paths((size_t)n);
         for (int i = 0; i < n; ++i) paths[i] = m->sweep_paths.data() + m->sweep_path_off[i];
         return cm3d_reader_load_sweeps(r, paths.data(), n, stride, raw_out, cap_rows, sweep_row_off, bad_index);
+    } catch (...) {
+        return CM3D_RD_ERR_IO;
+    }
+}
+
+extern "C" int cm3d_manifest_load_sweeps_quads(cm3d_reader *r, const cm3d_manifest *m, int32_t file_stride, float *quads_out, float *intensity_out,
+                                               int64_t cap_rows, int32_t *sweep_row_off, int32_t *frame_rows, int32_t *bad_index)
+{
+    if (!r || !m || m->bad_frame >= 0) return CM3D_RD_ERR_ARG;
+    try {
+        const int n = (int)m->sweep_path_off.size() - 1;
+        std::vector<const char *> paths((size_t)n);
+        for (int i = 0; i < n; ++i) paths[i] = m->sweep_paths.data() + m->sweep_path_off[i];
+        return cm3d_reader_load_sweeps_quads(r, paths.data(), n, file_stride, m->frame_sweep_off.data(), (int)m->frame_sweep_off.size() - 1, quads_out,
+                                             intensity_out, cap_rows, sweep_row_off, frame_rows, bad_index);
     } catch (...) {
         return CM3D_RD_ERR_IO;
     }

@@ -190,7 +190,7 @@ def default_layout():
 
 
 def pack_frames(frames: Sequence, lane_tables: Sequence[np.ndarray], frame_lane: Sequence[int],
-                classes: Optional[ClassTable] = None, layout: Optional[str] = None) -> HostBatch:
+                classes: Optional[ClassTable] = None, layout: Optional[str] = None, keep_intensity: bool = True) -> HostBatch:
     """frames: objects with the attributes of cm3d_amd.synthetic.Frame.  layout: "rows" (the sweeps as they are) or
     "quads" (rows_to_quads); None = default_layout()."""
     classes = classes or ClassTable.nuscenes()
@@ -251,7 +251,7 @@ def pack_frames(frames: Sequence, lane_tables: Sequence[np.ndarray], frame_lane:
     intensity = frame_rows = None
     row_off = i32(row_off)
     if layout == "quads":
-        raw, intensity, row_off, frame_rows = rows_to_quads(raw, row_off, fso)
+        raw, intensity, row_off, frame_rows = rows_to_quads(raw, row_off, fso, keep_intensity)
         stride = _lib.RAW_QUADS
     return HostBatch(
         raw=raw, raw_stride=stride, intensity=intensity, frame_rows=frame_rows,
@@ -284,8 +284,13 @@ def pack_manifest(man, lane_tables, frame_lane, classes: Optional[ClassTable], r
     W, H = int(wh[0, 0]), int(wh[0, 1])
     if np.any(wh[:, 0] != W) or np.any(wh[:, 1] != H):
         raise ValueError("all frames of a batch must share mask size and camera count")
-    raw, row_off = rd.load_sweeps([p for m in man for p in m.sweep_paths], stride, alloc)
     fso = np.concatenate([[0], np.cumsum([len(m.sweep_paths) for m in man])]).astype(np.int32)
+    intensity = frame_rows = None
+    if default_layout() == "quads":     # the files' rows go straight into the quad layout (no intensity plane: no output holds it)
+        raw, intensity, row_off, frame_rows = rd.load_sweeps_quads([p for m in man for p in m.sweep_paths], fso, stride, False, alloc)
+        stride = _lib.RAW_QUADS
+    else:
+        raw, row_off = rd.load_sweeps([p for m in man for p in m.sweep_paths], stride, alloc)
     n_cams = man[0].cams.shape[0]
     mask_cam, mask_frame, class_id, score = [], [], [], []
     for fi, m in enumerate(man):
@@ -306,7 +311,8 @@ def pack_manifest(man, lane_tables, frame_lane, classes: Optional[ClassTable], r
     lane_off = np.concatenate([[0], np.cumsum([t.shape[0] for t in lane32])]).astype(np.int32)
     i32 = lambda a: np.asarray(a, np.int32)
     hb = HostBatch(
-        raw=raw, raw_stride=stride, sweep_row_off=row_off, sweep_xf=np.concatenate([np.asarray(m.sweep_xf, np.float32).reshape(-1, _lib.SWEEP_XF_STRIDE) for m in man], 0),
+        raw=raw, raw_stride=stride, intensity=intensity, frame_rows=frame_rows, sweep_row_off=row_off,
+        sweep_xf=np.concatenate([np.asarray(m.sweep_xf, np.float32).reshape(-1, _lib.SWEEP_XF_STRIDE) for m in man], 0),
         frame_sweep_off=fso, max_rows_per_sweep=max(1, int(np.diff(row_off).max())), cams=np.stack([np.asarray(m.cams, np.float32) for m in man]),
         n_cams=n_cams, mask_off=fmo.astype(np.int32), mask_cam=i32(mask_cam), mask_frame=i32(mask_frame), rle_counts=counts, rle_off=rle_off,
         class_id=i32(class_id), score=np.asarray(score, np.float64), lane=np.concatenate(lane32, 0), lane_off=lane_off,

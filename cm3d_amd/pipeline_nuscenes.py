@@ -126,7 +126,7 @@ def prepare_scene_batch(task):
     # one engine call per mask size (all cameras of nuScenes share one)
     for (W, H) in sorted({(frames[i].width, frames[i].height) for i in live}):
         sel = [i for i in live if (frames[i].width, frames[i].height) == (W, H)]
-        batches.append(lifting.pack_frames([frames[i] for i in sel], lanes, [frame_lane[i] for i in sel], classes, layout="rows"))
+        batches.append(lifting.pack_frames([frames[i] for i in sel], lanes, [frame_lane[i] for i in sel], classes))
     if through_shm:                         # reader process: the sweeps (nearly all of the bytes) go through shared memory
         from multiprocessing import shared_memory
         for hb in batches:
@@ -317,11 +317,19 @@ def _native_batch_tail(nt, head, sub=None, rd=None):
     a Python statement per frame.  Returns (HostBatch, rows of its frames in sample.json)."""
     man, counts, rle_off, fmo, n_per, (W, H), lanes, frame_lane, locs = head
     t0 = time.perf_counter()
-    raw, row_off = man.load_sweeps(5, rd)
+    # the sweeps go straight into the batch's layout: quads (12 of a row's 20 bytes reach the page-locked buffer and the GPU; the
+    # intensity is not uploaded -- no output of the entry point holds it) unless CM3D_RAW_LAYOUT=rows asks for the files' rows
+    intensity = frame_rows = None
+    if lifting.default_layout() == "quads":
+        raw, intensity, row_off, frame_rows = man.load_sweeps_quads(5, rd)
+        stride = lifting._lib.RAW_QUADS
+    else:
+        raw, row_off = man.load_sweeps(5, rd)
+        stride = 5
     t1 = time.perf_counter()
     F = man.n_frames
     hb = lifting.HostBatch(
-        raw=raw, raw_stride=5, sweep_row_off=row_off, sweep_xf=man.sweep_xf, frame_sweep_off=man.frame_sweep_off,
+        raw=raw, raw_stride=stride, intensity=intensity, frame_rows=frame_rows, sweep_row_off=row_off, sweep_xf=man.sweep_xf, frame_sweep_off=man.frame_sweep_off,
         max_rows_per_sweep=max(1, int(np.diff(row_off).max())), cams=man.cams, n_cams=6, mask_off=fmo.astype(np.int32), mask_cam=man.mask_cam,
         mask_frame=np.repeat(np.arange(F, dtype=np.int32), n_per), rle_counts=counts, rle_off=rle_off, class_id=man.class_id, score=man.score,
         lane=np.concatenate(lanes, 0), lane_off=np.concatenate([[0], np.cumsum([t_.shape[0] for t_ in lanes])]).astype(np.int32),

@@ -35,6 +35,7 @@ def lib():
         h.cm3d_reader_close.restype, h.cm3d_reader_close.argtypes = None, [p]
         h.cm3d_reader_threads.restype, h.cm3d_reader_threads.argtypes = i32, [p]
         h.cm3d_reader_load_sweeps.restype, h.cm3d_reader_load_sweeps.argtypes = C.c_int, [p, p, i32, i32, p, i64, p, p]
+        h.cm3d_reader_load_sweeps_quads.restype, h.cm3d_reader_load_sweeps_quads.argtypes = C.c_int, [p, p, i32, i32, p, i32, p, p, i64, p, p, p]
         h.cm3d_reader_load_masks.restype, h.cm3d_reader_load_masks.argtypes = C.c_int, [p, p, i32, p, i64, p, p, p, i32, p, p]
         h.cm3d_rle_string_to_counts.restype, h.cm3d_rle_string_to_counts.argtypes = i64, [C.c_char_p, i64, p, i64]
         # tables / manifests / writer
@@ -51,6 +52,7 @@ def lib():
         h.cm3d_manifest_bad_label.restype, h.cm3d_manifest_bad_label.argtypes = C.c_char_p, [p]
         h.cm3d_manifest_copy.restype, h.cm3d_manifest_copy.argtypes = C.c_int, [p] + [p] * 13
         h.cm3d_manifest_load_sweeps.restype, h.cm3d_manifest_load_sweeps.argtypes = C.c_int, [p, p, i32, p, i64, p, p]
+        h.cm3d_manifest_load_sweeps_quads.restype, h.cm3d_manifest_load_sweeps_quads.argtypes = C.c_int, [p, p, i32, p, p, i64, p, p, p]
         h.cm3d_manifest_load_masks.restype, h.cm3d_manifest_load_masks.argtypes = C.c_int, [p, p, p, i64, p, p, p, i32, p, p]
         h.cm3d_write_results_json.restype = i64
         h.cm3d_write_results_json.argtypes = [p, i64, C.c_char_p, i32, p, p, p, i32, C.c_char_p, p, i64]
@@ -160,6 +162,40 @@ class Reader:
             # pinning 200 MB afresh)
             out = _Owned(out, owner)
         return out, off
+
+    def load_sweeps_quads(self, paths, frame_sweep_off, file_stride=5, intensity=False, alloc=None):
+        """The same files straight into the quad layout of include/cm3d_hip.h (x, y, z of four rows side by side, frames padded to
+        whole quads): -> (quads (R/4, 3, 4) float32, intensity (R,) float32 or None, sweep_row_off (n+1,) int32 in the padded
+        numbering, frame_rows (F,) int32).  12 of a row's bytes reach the batch (16 with intensity=True) instead of 4 * file_stride.
+        alloc(n_floats) as in load_sweeps (the quads only)."""
+        L, n = lib(), len(paths)
+        arr = _paths(paths)
+        fso = np.ascontiguousarray(frame_sweep_off, np.int32)
+        F = len(fso) - 1
+        off, frows = np.zeros(n + 1, np.int32), np.zeros(max(F, 1), np.int32)
+        bad = C.c_int32(-1)
+        rc = L.cm3d_reader_load_sweeps_quads(self.h, arr, n, file_stride, fso.ctypes.data, F, None, None, 0, off.ctypes.data, frows.ctypes.data, C.byref(bad))
+        if rc not in (OK, ERR_CAPACITY):
+            raise ReaderError(rc, "cm3d_reader_load_sweeps_quads", bad.value)
+        rows = int(off[-1])
+        if alloc is not None:
+            raw, owner = np.asarray(alloc(max(rows * 3, 4))).reshape(-1), None
+        else:
+            raw, owner = _staging(max(rows * 3, 4), np.float32, self.pinned)
+        inten, iowner = (_staging(max(rows, 1), np.float32, self.pinned) if intensity else (None, None))
+        if rows:
+            rc = L.cm3d_reader_load_sweeps_quads(self.h, arr, n, file_stride, fso.ctypes.data, F, raw.ctypes.data, inten.ctypes.data if intensity else None,
+                                                 rows, off.ctypes.data, frows.ctypes.data, C.byref(bad))
+            if rc != OK:
+                raise ReaderError(rc, "cm3d_reader_load_sweeps_quads", bad.value)
+        out = raw[:rows * 3].reshape(rows // 4, 3, 4)
+        iout = inten[:rows] if intensity else None
+        if owner is not None:
+            self._keep = [owner, iowner] + self._keep[:2]
+            out = _Owned(out, owner)
+            if iout is not None:
+                iout = _Owned(iout, iowner)
+        return out, iout, off, frows[:F]
 
     def load_masks(self, paths, guess_counts=1 << 20, guess_masks=1 << 12):
         """-> (rle_counts uint32, rle_off int32 (M+1), frame_mask_off int32 (n+1), mask_wh int32 (M,2)).
@@ -341,6 +377,32 @@ class Manifest:
             rd._keep = [owner] + rd._keep[:1]
             out = _Owned(out, owner)
         return out, off
+
+    def load_sweeps_quads(self, file_stride=5, rd=None, intensity=False):
+        """load_sweeps into the quad layout (Reader.load_sweeps_quads): -> (quads, intensity or None, sweep_row_off, frame_rows)."""
+        L, rd = lib(), (rd or self.tables.rd)
+        F = self.n_frames
+        off, frows = np.zeros(self.n_sweeps + 1, np.int32), np.zeros(max(F, 1), np.int32)
+        bad = C.c_int32(-1)
+        rc = L.cm3d_manifest_load_sweeps_quads(rd.h, self.h, file_stride, None, None, 0, off.ctypes.data, frows.ctypes.data, C.byref(bad))
+        if rc not in (OK, ERR_CAPACITY):
+            raise ReaderError(rc, "cm3d_manifest_load_sweeps_quads", bad.value)
+        rows = int(off[-1])
+        raw, owner = _staging(max(rows * 3, 4), np.float32, rd.pinned)
+        inten, iowner = (_staging(max(rows, 1), np.float32, rd.pinned) if intensity else (None, None))
+        if rows:
+            rc = L.cm3d_manifest_load_sweeps_quads(rd.h, self.h, file_stride, raw.ctypes.data, inten.ctypes.data if intensity else None, rows,
+                                                   off.ctypes.data, frows.ctypes.data, C.byref(bad))
+            if rc != OK:
+                raise ReaderError(rc, "cm3d_manifest_load_sweeps_quads", bad.value)
+        out = raw[:rows * 3].reshape(rows // 4, 3, 4)
+        iout = inten[:rows] if intensity else None
+        if owner is not None:
+            rd._keep = [owner, iowner] + rd._keep[:2]
+            out = _Owned(out, owner)
+            if iout is not None:
+                iout = _Owned(iout, iowner)
+        return out, iout, off, frows[:F]
 
     def load_masks(self, guess_counts=1 << 20):
         """-> (rle_counts uint32, rle_off int32 (M+1), frame_mask_off int32 (F+1), mask_wh int32 (M,2))"""

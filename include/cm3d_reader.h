@@ -41,6 +41,19 @@ int32_t cm3d_reader_threads(const cm3d_reader *r);
 int cm3d_reader_load_sweeps(cm3d_reader *r, const char *const *paths, int32_t n_files, int32_t stride, float *raw_out,
                             int64_t cap_rows, int32_t *sweep_row_off, int32_t *bad_index);
 
+/* The same files into the QUAD layout of include/cm3d_hip.h (cm3d_sweep_prep; replaces the column strip of utils/pcd.py:250-257 on the way):
+ * x, y, z of batch rows 4q..4q+3 side by side, every frame padded to a multiple of 4 rows with NaN rows that belong to its last sweep.
+ *  file_stride     floats per row in the files (5 for nuScenes)
+ *  frame_sweep_off int32[n_frames+1]        which files make up which frame (frame_sweep_off[n_frames] = n_files)
+ *  quads_out       float[cap_rows/4][3][4]  OUT, 16-byte aligned
+ *  intensity_out   float[cap_rows] or NULL  OUT the rows' fourth column (NULL: not wanted)
+ *  sweep_row_off   int32[n_files+1]         OUT row offsets in the padded numbering
+ *  frame_rows      int32[n_frames]          OUT rows of each frame without its padding
+ * Returns CM3D_RD_ERR_CAPACITY (offsets filled in, nothing read) when the padded total exceeds cap_rows. */
+int cm3d_reader_load_sweeps_quads(cm3d_reader *r, const char *const *paths, int32_t n_files, int32_t file_stride,
+                                  const int32_t *frame_sweep_off, int32_t n_frames, float *quads_out, float *intensity_out,
+                                  int64_t cap_rows, int32_t *sweep_row_off, int32_t *frame_rows, int32_t *bad_index);
+
 /* All mask files of a batch (one per frame; a NULL or empty path = a frame without masks).
  *  counts_out     uint32[cap_counts]       OUT run lengths of all masks back to back (alternating 0-run, 1-run, ...)
  *  rle_off        int32[cap_masks+1]       OUT run-length offsets per mask
@@ -100,6 +113,8 @@ int cm3d_manifest_copy(const cm3d_manifest *m, int32_t *sample_index, int32_t *f
 /* cm3d_reader_load_sweeps / cm3d_reader_load_masks on the manifest's own file lists */
 int cm3d_manifest_load_sweeps(cm3d_reader *r, const cm3d_manifest *m, int32_t stride, float *raw_out, int64_t cap_rows,
                               int32_t *sweep_row_off, int32_t *bad_index);
+int cm3d_manifest_load_sweeps_quads(cm3d_reader *r, const cm3d_manifest *m, int32_t file_stride, float *quads_out, float *intensity_out,
+                                    int64_t cap_rows, int32_t *sweep_row_off, int32_t *frame_rows, int32_t *bad_index);
 int cm3d_manifest_load_masks(cm3d_reader *r, const cm3d_manifest *m, uint32_t *counts_out, int64_t cap_counts, int32_t *rle_off,
                              int32_t *frame_mask_off, int32_t *mask_wh, int32_t cap_masks, int64_t *needed, int32_t *bad_index);
 

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_reader_library_exports_every_declared_symbol(tmp_path):
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "cm3d_reader.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(cm3d_[a-z0-9_]+)\s*\(", src)))
-    assert len(names) == 20 and "cm3d_tables_manifest" in names and "cm3d_write_results_json" in names
+    assert len(names) == 22 and "cm3d_reader_load_sweeps_quads" in names and "cm3d_tables_manifest" in names and "cm3d_write_results_json" in names
     h = ctypes.CDLL(reader.LIB_PATH)
     for n in names:
         assert hasattr(h, n), n
@@ -102,10 +102,12 @@ def test_native_batches_equal_the_python_reader(tmp_path):
     x, y = a[1][0], b[1][0]
     assert x.n_frames == 4
     for k in ("raw", "sweep_row_off", "sweep_xf", "frame_sweep_off", "cams", "mask_off", "mask_cam", "mask_frame", "rle_counts", "rle_off",
-              "class_id", "score", "lane", "lane_off", "frame_lane", "ego_xyz"):
-        assert np.array_equal(getattr(x, k), getattr(y, k)), k
+              "class_id", "score", "lane", "lane_off", "frame_lane", "ego_xyz", "frame_rows"):
+        assert np.array_equal(getattr(x, k), getattr(y, k), equal_nan=(k == "raw")), k      # (a frame's padding rows are NaN)
     assert (x.width, x.height, x.n_cams, x.raw_stride, x.max_rows_per_sweep, x.tokens, x.labels, x.ego_box) == \
            (y.width, y.height, y.n_cams, y.raw_stride, y.max_rows_per_sweep, y.tokens, y.labels, y.ego_box)
+    # the product's layout: quads -- 12 of a row's 20 bytes leave the page cache; the native reader leaves the intensity behind
+    assert x.quads and x.raw.shape[1:] == (3, 4) and y.intensity is None and x.intensity is not None
 
 
 def test_integration_md_reader_binding_runs_as_written(tmp_path):
@@ -311,3 +313,31 @@ def test_integration_md_tables_binding_runs_as_written(tmp_path):
     assert np.array_equal(got["sweep_xf"].view(np.uint32), np.concatenate([m.sweep_xf for m in pman]).astype(np.float32).view(np.uint32))
     assert np.array_equal(got["score"], np.concatenate([np.asarray(m.scores, np.float64) for m in pman]))
     assert np.array_equal(got["mask_cam"], np.concatenate([m.cam_nums for m in pman])) and got["class_id"].size == got["score"].size
+
+
+def test_native_quads_equal_the_numpy_packing(tmp_path):
+    """cm3d_reader_load_sweeps_quads (files -> quad layout, frames padded to whole quads) against lifting.rows_to_quads on the rows
+    the plain loader returns: ragged sweeps (a sweep that starts inside a quad), an empty sweep, a frame of one row, both
+    intensity settings -- and the rows layout of the same files stays what it was."""
+    from cm3d_amd import lifting
+    rng = np.random.default_rng(11)
+    sizes = [7, 0, 13, 1, 256, 5, 4, 3]
+    fso = np.array([0, 3, 4, 6, 8], np.int32)                   # frames of 3, 1, 2, 2 sweeps
+    paths = []
+    for i, n in enumerate(sizes):
+        a = rng.normal(0, 30, (n, 5)).astype(np.float32)
+        p = tmp_path / f"s{i}.bin"
+        a.tofile(p)
+        paths.append(str(p))
+    rd = reader.Reader(3, pinned=False)
+    rows, off = rd.load_sweeps(paths, 5)
+    want_q, want_i, want_off, want_rows = lifting.rows_to_quads(np.asarray(rows), off, fso)
+    for intensity in (False, True):
+        q, it, o, fr = rd.load_sweeps_quads(paths, fso, 5, intensity)
+        assert np.array_equal(np.asarray(q), want_q, equal_nan=True) and np.array_equal(o, want_off) and np.array_equal(fr, want_rows)
+        assert (it is None) == (not intensity)
+        if intensity:
+            assert np.array_equal(np.asarray(it), want_i)
+    assert int(want_off[-1]) % 4 == 0 and np.all(want_off[fso[:-1]] % 4 == 0) and want_rows.tolist() == [20, 1, 261, 7]
+    with pytest.raises(reader.ReaderError):
+        rd.load_sweeps_quads(paths, np.array([0, 3, 9], np.int32), 5)          # frames that do not cover the files
