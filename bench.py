@@ -238,8 +238,10 @@ def rehearse_launch(args):
     return 0
 
 
-def end_to_end_bench(args):
-    """`--end-to-end N`: what a user of the drop-in script pays -- files on disk -> pseudolabels_minival.json, through
+def end_to_end_bench(args, quick=False):
+    """quick=True: the leg of the DEFAULT bench line -- dataset of args.end_to_end frames, one warm-up run over two scenes, one timed run
+    of the entry point with the native reader on threads; returns a dict instead of printing.
+    `--end-to-end N`: what a user of the drop-in script pays -- files on disk -> pseudolabels_minival.json, through
     cm3d_amd.pipeline_nuscenes (src/nuscenes/2d_to_3d.py) on a synthetic nuScenes-layout dataset of N frames shaped like
     --config (C2 by default): table walk, <f>_data.json, mask pickles + RLE strings, sweep files, H2D, the GPU pass,
     the record gather, the JSON writer.  Timed three ways: the native loader (libcm3d_reader.so) on threads of this process,
@@ -288,6 +290,13 @@ def end_to_end_bench(args):
         run("warm", names[:2], 0, 0)                                      # first-use costs (library loads, allocator) stay out
         nproc = max(2, min(cores // 2, 16))
         dt_t, res_t, timer_t = run("threads", names, int(os.environ.get("CM3D_E2E_READER_THREADS", "0")), 0)
+        if quick:
+            return {"frames_per_s": round(n_frames / dt_t, 1), "seconds": round(dt_t, 3), "frames": n_frames, "timer": timer_t,
+                    "boxes": sum(len(v) for v in res_t["results"].values()), "sweep_file_MB": round(sweep_bytes / 1e6, 1),
+                    "usable_cores": cores, "frames_per_gpu_batch": args.frames, "dataset_write_seconds": round(t_write, 1),
+                    "what": "files of a synthetic nuScenes-layout dataset (tables, .bin sweeps, _masks.pkl, _data.json) in the page cache -> "
+                            "pseudolabels_minival.json through src/nuscenes/2d_to_3d.py's entry point (cm3d_amd.pipeline_nuscenes.main), "
+                            "wall time of the call; the full comparison (reader processes, Python reader): bench.py --end-to-end N"}
         dt_p, res_p, timer_p = run("procs", names, max(1, cores // nproc), nproc)
         sub = names[:max(2, 128 // per_scene)]
         dt_py, res_py, _ = run("python", sub, -1, 0)
@@ -341,6 +350,8 @@ def main(argv=None):
     ap.add_argument("--fusion", type=int, default=0, metavar="SAMPLES",
                     help="time the SAM3D fusion matching (SURVEY 8 f4) on this many samples instead of the lifting path")
     ap.add_argument("--rehearse-launch", action="store_true", help="launch, rendezvous and the record exchange only (no GPU needed)")
+    ap.add_argument("--e2e-frames", type=int, default=int(os.environ.get("CM3D_BENCH_E2E_FRAMES", "2048")), metavar="FRAMES",
+                    help="frames of the end-to-end leg of the default line (files -> labels through the entry point; 0 = skip)")
     ap.add_argument("--end-to-end", type=int, default=0, metavar="FRAMES",
                     help="time the entry point instead: files of a synthetic dataset of this many frames -> pseudolabels json")
     args = ap.parse_args(argv)
@@ -383,7 +394,8 @@ def main(argv=None):
     cache_dir = os.environ.get("CM3D_BENCH_CACHE")     # experiments: packed batches kept between runs of one GPU call (generation takes
     for slot in range(depth):                          # longer than the measurement); only without the CPU legs, which need the frames
         import pickle
-        cache = cache_dir and args.cpu_sample == 0 and os.path.join(
+        # (rank 0 needs the frames themselves for the CPU legs; every other rank only the packed batch)
+        cache = cache_dir and (args.cpu_sample == 0 or rank != 0) and os.path.join(
             cache_dir, f"bench_{args.config}_{args.frames}_{rank * depth + slot}_{args.lane_points}_{'_'.join(sorted(args.set))}.pkl")
         if cache and os.path.exists(cache):
             batches.append((None, pickle.load(open(cache, "rb"))))
@@ -480,6 +492,57 @@ def main(argv=None):
             torch.distributed.all_gather(every, mine)
             per_rank_dt = [float(t.item()) for t in every]
             dt = max(per_rank_dt)                        # the job's time is its slowest rank's
+        # how far a K-step region can be off: the same K passes five more times, and one region of >= 0.5 s
+        spread, long_rate = None, None
+        if mode == modes[0]:
+            def region(n_steps):
+                barrier()
+                torch.cuda.synchronize()
+                t_r = time.perf_counter()
+                for step in range(n_steps):
+                    pipe.rerun(step % depth, masks=mode)
+                torch.cuda.synchronize()
+                barrier()
+                torch.cuda.synchronize()
+                d = time.perf_counter() - t_r
+                if world > 1:
+                    mine_r = torch.tensor([d], dtype=torch.float64, device=dev)
+                    every_r = [torch.zeros_like(mine_r) for _ in range(world)]
+                    torch.distributed.all_gather(every_r, mine_r)
+                    d = max(float(t.item()) for t in every_r)
+                return d
+            reps = [args.frames * world * args.steps / region(args.steps) for _ in range(5)]
+            spread = {"min": round(min(reps), 1), "median": round(float(np.median(reps)), 1), "max": round(max(reps), 1), "repeats": 5}
+            n_long = int(max(args.steps, min(20000, np.ceil(0.5 / max(dt / args.steps, 1e-6)))))
+            long_rate = {"value": round(args.frames * world * n_long / region(n_long), 1), "steps": n_long}
+            # what the timed loop amortises and a job of ever-new batches does not: the lane index is built once for the
+            # resident tables, and the medoid stage runs on the hint of the pass before.  The same K passes with the index rebuilt
+            # in EVERY pass (each slot on an index of its own: a rebuild must not touch what another slot's pass is reading) and
+            # without the hint:
+            for e in pipe.engines:
+                ln = dict(e._lane)
+                ln["grid"] = e._lane["grid"].clone()
+                ln["built_event"] = torch.cuda.Event()
+                e._lane, e.b.grid = ln, ln["grid"]
+            hints = [e._md_hint for e in pipe.engines]
+
+            def region_unamortised(n_steps):
+                barrier()
+                torch.cuda.synchronize()
+                t_r = time.perf_counter()
+                for step in range(n_steps):
+                    e = pipe.engines[step % depth]
+                    e.rebuild_lane_grid()
+                    e._md_hint = False
+                    pipe.rerun(step % depth, masks=mode)
+                torch.cuda.synchronize()
+                barrier()
+                torch.cuda.synchronize()
+                return time.perf_counter() - t_r
+            region_unamortised(depth)
+            unamortised = round(args.frames * world * args.steps / region_unamortised(args.steps), 1)
+            for e, h in zip(pipe.engines, hints):
+                e._md_hint = h
         # per-stage breakdown: a separate, untimed pass over ONE batch alone, with events around every stage
         alone = []
         with torch.cuda.stream(pipe.streams[0]):
@@ -514,7 +577,7 @@ def main(argv=None):
                              sum_pairs_long=int((eng.b.hit_count.to(torch.int64) ** 2)[(eng.b.hit_count > 512) & (eng.b.hit_count < 100000)].sum().item()),
                              n_boxes=int((eng.b.flags == 3).sum().item()), max_hits=int(eng.b.hit_count.max().item()),
                              rect_bytes=packed_rect_bytes(eng.b.bbox.cpu().numpy(), eng.b.Wp),
-                             n_gathered=None if gathered is None else int(sum(g.shape[0] for g in gathered)))
+                             n_gathered=None if gathered is None else int(sum(g.shape[0] for g in gathered)), spread=spread, long_rate=long_rate, unamortised=unamortised if mode == modes[0] else None)
 
     if rank != 0:
         if world > 1:
@@ -645,6 +708,12 @@ def main(argv=None):
                    "mask_size": [cfg.width, cfg.height], "lane_points": args.lane_points, "mask_input": main_mode,
                    "batches_in_flight": depth, "distinct_batches": 1 if args.reuse_batch else depth, "cloud_materialised": cloud_stored,
                    "parallelism": f"frame-sharded x{world}, {depth} independent batches in flight per GPU, one RCCL gather of box records"},
+        # the timed K steps are short (a few ms at the driver's --steps): the same region five more times, and one of >= 0.5 s
+        "value_spread": r["spread"], "value_long": None if r["long_rate"] is None else r["long_rate"]["value"],
+        "value_long_steps": None if r["long_rate"] is None else r["long_rate"]["steps"],
+        # the same K passes with the lane index rebuilt in every pass and the medoid stage without the previous pass's hint: what a
+        # job pays whose every batch brings new lane tables (the timed loop replays resident batches: index built once, hint warm)
+        "value_unamortised": r["unamortised"],
         "ranks_in_group": torch.distributed.get_world_size() if world > 1 else 1,
         "per_rank_ms_per_step": [round(t / args.steps * 1e3, 4) for t in r["per_rank_dt"]],
         "roofline": roofline,
@@ -680,6 +749,17 @@ def main(argv=None):
                 out["cpu_baseline_all_cores"] = {"error": repr(exc)}
     else:
         out["cpu_baseline"] = None
+    # what a user of the drop-in script gets: files on disk -> labels, timed here so that the driver's run carries it
+    if world == 1 and args.e2e_frames > 0 and args.cpu_sample > 0:
+        try:
+            del pipe, eng, batches
+            torch.cuda.empty_cache()
+            import copy
+            e_args = copy.copy(args)
+            e_args.end_to_end = args.e2e_frames
+            out["end_to_end"] = end_to_end_bench(e_args, quick=True)
+        except Exception as exc:            # a reported extra: never let it break the bench line
+            out["end_to_end"] = {"error": repr(exc)}
     print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -687,4 +767,8 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    try:
+        sys.exit(main())
+    except cdist.GatherError as exc:        # a rank missing / a timeout in the one exchange: say so and leave with a code of its own
+        print(f"error: {exc}", file=sys.stderr, flush=True)
+        os._exit(3)                         # (not sys.exit: a half-dead process group can hang interpreter shutdown)

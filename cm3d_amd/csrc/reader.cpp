@@ -13,6 +13,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
@@ -481,6 +482,23 @@ extern "C" int cm3d_reader_load_sweeps_quads(cm3d_reader *r, const char *const *
             const int fd = open(paths[i], O_RDONLY);
             struct stat st;
             if (fd < 0 || fstat(fd, &st) != 0 || st.st_size != n * row_bytes) { bad = i; if (fd >= 0) close(fd); return; }
+            auto scatter = [&](const float *src, int64_t r0, int64_t m) {
+                int64_t q = a + r0;
+                for (int64_t k = 0; k < m; ++k, ++q, src += file_stride) {
+                    float *d = quads_out + (q >> 2) * 12 + (q & 3);
+                    d[0] = src[0]; d[4] = src[1]; d[8] = src[2];
+                    if (intensity_out) intensity_out[q] = src[3];
+                }
+            };
+            // the file's pages mapped (they are in the page cache when the job is hot: one pass, page cache -> batch, no copy into
+            // a buffer of ours first); a file system that cannot map falls back to reads in pieces
+            void *mp = mmap(nullptr, (size_t)(n * row_bytes), PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (mp != MAP_FAILED) {
+                scatter((const float *)mp, 0, n);
+                munmap(mp, (size_t)(n * row_bytes));
+                close(fd);
+                return;
+            }
             std::vector<float> buf((size_t)(PIECE * file_stride));
             for (int64_t r0 = 0; r0 < n; r0 += PIECE) {
                 const int64_t m = std::min(PIECE, n - r0);
@@ -491,13 +509,7 @@ extern "C" int cm3d_reader_load_sweeps_quads(cm3d_reader *r, const char *const *
                     if (got <= 0) { bad = i; close(fd); return; }
                     off += (size_t)got;
                 }
-                const float *src = buf.data();
-                int64_t q = a + r0;
-                for (int64_t k = 0; k < m; ++k, ++q, src += file_stride) {
-                    float *d = quads_out + (q >> 2) * 12 + (q & 3);
-                    d[0] = src[0]; d[4] = src[1]; d[8] = src[2];
-                    if (intensity_out) intensity_out[q] = src[3];
-                }
+                scatter(buf.data(), r0, m);
             }
             close(fd);
         });

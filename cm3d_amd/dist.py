@@ -25,10 +25,25 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
             backend = os.environ.get("CM3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        import datetime
+        # a rank that never arrives (a crashed neighbour, a wrong WORLD_SIZE) must end the job with an error, not hang it: every
+        # collective of this job is small, so a short timeout is safe (CM3D_DIST_TIMEOUT_S overrides)
+        timeout = datetime.timedelta(seconds=float(os.environ.get("CM3D_DIST_TIMEOUT_S", "300")))
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # device_id: RCCL binds to this rank's GPU and builds its communicator here, eagerly, instead of inside the first
+            # collective (which for this job would be the end-of-run gather, inside the timed region of bench.py)
+            kw["device_id"] = torch.device(f"cuda:{local_rank}")
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout, **kw)
+        except TypeError:               # a torch whose init_process_group knows no device_id
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local_rank
+
+
+class GatherError(RuntimeError):
+    """The end-of-job exchange failed (a rank missing, a timeout): the job's result is incomplete."""
 
 
 def shard_range(n_items: int, rank: int, world: int):
@@ -64,20 +79,25 @@ def gather_records(records: torch.Tensor, dst: int = 0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [records]
     world, rank = dist.get_world_size(), dist.get_rank()
-    k = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
-    counts = [torch.zeros_like(k) for _ in range(world)]
-    dist.all_gather(counts, k)
-    counts = [int(c.item()) for c in counts]
-    kmax = max(counts)
-    padded = records
-    if records.shape[0] < kmax:
-        pad = torch.zeros(kmax - records.shape[0], records.shape[1], dtype=records.dtype, device=records.device)
-        padded = torch.cat([records, pad], 0)
-    padded = padded.contiguous()
-    # all_gather rather than gather: the same single exchange (5120 x 80 B per rank on the C2 batch), and the collective
-    # every backend of torch.distributed implements for device tensors
-    bufs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(bufs, padded)
+    try:
+        k = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
+        counts = [torch.zeros_like(k) for _ in range(world)]
+        dist.all_gather(counts, k)
+        counts = [int(c.item()) for c in counts]
+        kmax = max(counts)
+        padded = records
+        if records.shape[0] < kmax:
+            pad = torch.zeros(kmax - records.shape[0], records.shape[1], dtype=records.dtype, device=records.device)
+            padded = torch.cat([records, pad], 0)
+        padded = padded.contiguous()
+        # all_gather rather than gather: the same single exchange (5120 x 80 B per rank on the C2 batch), and the collective
+        # every backend of torch.distributed implements for device tensors
+        bufs = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(bufs, padded)
+        if padded.is_cuda:
+            torch.cuda.synchronize(padded.device)       # an asynchronous RCCL error or timeout surfaces here, not later
+    except Exception as exc:                             # (DistBackendError, a timeout, a peer that left)
+        raise GatherError(f"rank {rank} of {world}: the end-of-job gather of the box records failed: {exc!r}") from exc
     if rank != dst:
         return None
     return [b[:c] for b, c in zip(bufs, counts)]

@@ -352,7 +352,7 @@ class LiftEngine:
     All launches go to torch's current HIP stream and never synchronise."""
 
     def __init__(self, device="cuda:0", classes: Optional[ClassTable] = None, min_dist=MIN_DIST,
-                 hits_per_point=4.0, keep_colsum=False, keep_cloud=None):
+                 hits_per_point=4.0, keep_colsum=False, keep_cloud=None, lane_cache=None):
         """keep_cloud: also materialise the transformed cloud (`points`, the reference's aggregated `pc`).  The path
         itself does not need it -- the in-mask points are re-derived from the raw rows (hit_xyz) -- so the default is
         off (CM3D_KEEP_CLOUD=1 turns it on); tests and callers that want the cloud back ask for it."""
@@ -369,9 +369,9 @@ class LiftEngine:
         _verify_matrix_pipe(self.lib, self.dev)
         self.b = None
         self._lane = None                                    # the lane tables on the device and their spatial index (upload)
+        self._lane_cache = lane_cache if lane_cache is not None else {}      # table set -> tables + index; a LiftPipeline hands its engines one
         d = self.dev
         self.side = torch.cuda.Stream(device=d)              # lane-grid build overlaps the point/mask stages
-        self.grid_done = torch.cuda.Event()
         self.fused_sweeps = os.environ.get("CM3D_FUSED_SWEEPS", "1") == "1"    # 0: separate sweep and projection launches
         # the medoid stage's feedback word (stage_medoid): starts at 1 = "expect long lists"
         self._md_hint = os.environ.get("CM3D_MD_HINT", "1") == "1"
@@ -411,7 +411,7 @@ class LiftEngine:
         b.pose_rt = t(hb.pose_rt) if hb.pose_rt is not None else None
         b.pose_inv = t(hb.pose_inv) if hb.pose_inv is not None else None
         b.halfw = self.halfw if hb.ego_box else 0.0
-        b.lane = t(hb.lane); b.lane_off = t(hb.lane_off); b.frame_lane = t(hb.frame_lane); b.ego_xyz = t(hb.ego_xyz)
+        b.frame_lane = t(hb.frame_lane); b.ego_xyz = t(hb.ego_xyz)
         b.pt_cap = hb.n_raw_rows
         b.max_pts = int(max(hb.sweep_row_off[hb.frame_sweep_off[1:]] - hb.sweep_row_off[hb.frame_sweep_off[:-1]]))
         b.planes = (nm_max + 31) // 32
@@ -454,12 +454,28 @@ class LiftEngine:
         # 2d_to_3d.py:406, and looks every frame of the scene up in them): it is built once per distinct set of tables and kept
         # across passes and uploads -- consecutive batches of a scene, and every pass over a resident batch, reuse it.
         # (a caller that knows which tables these are says so -- pipeline_nuscenes: the map locations --; else their checksum)
-        key = getattr(hb, "lane_key", None) or (hb.lane.shape, hb.lane_off.tobytes(), zlib.crc32(np.ascontiguousarray(hb.lane).view(np.uint8)))
-        if self._lane is not None and self._lane["key"] == key:
-            b.lane, b.lane_off, b.grid = self._lane["lane"], self._lane["lane_off"], self._lane["grid"]
+        # (the key first: on a hit the tables are neither uploaded -- a pageable, host-blocking copy of megabytes -- nor read for a
+        # checksum; the checksum of a table set is kept on the host batch.  The cache is shared by the engines of a LiftPipeline:
+        # consecutive batches of a job alternate between them.)
+        key = getattr(hb, "lane_key", None)
+        if key is None:
+            key = getattr(hb, "_lane_crc", None)
+            if key is None:
+                key = hb._lane_crc = (hb.lane.shape, hb.lane_off.tobytes(), zlib.crc32(np.ascontiguousarray(hb.lane).view(np.uint8)))
+        hit = self._lane_cache.get(key)
+        if hit is not None:
+            self._lane = hit
+            b.lane, b.lane_off, b.grid = hit["lane"], hit["lane_off"], hit["grid"]
         else:
+            b.lane = t(hb.lane); b.lane_off = t(hb.lane_off)
             b.grid = torch.empty(b.grid_bytes, dtype=torch.uint8, device=d)
-            self._lane = {"key": key, "lane": b.lane, "lane_off": b.lane_off, "grid": b.grid, "built": False}
+            up = torch.cuda.Event()
+            up.record(torch.cuda.current_stream(d))         # whichever engine builds the index waits for the tables' copies (its streams are not this one)
+            self._lane = {"key": key, "lane": b.lane, "lane_off": b.lane_off, "grid": b.grid, "built": False, "tables_uploaded": up,
+                          "built_event": torch.cuda.Event()}
+            if len(self._lane_cache) >= 8:                  # a handful of cities per job: keep the cache small
+                self._lane_cache.pop(next(iter(self._lane_cache)))
+            self._lane_cache[key] = self._lane
         b.dense = dense_masks
         # The bulk data LAST: sweeps and run lengths come from page-locked staging buffers (cm3d_amd.reader) and copy
         # asynchronously; the small arrays above are pageable, their copies block the host until everything queued before them on
@@ -490,16 +506,17 @@ class LiftEngine:
             return                           # same lane tables as the last build: the index is still valid
         main = torch.cuda.current_stream(self.dev)
         self.side.wait_stream(main)          # the uploads of the tables have been issued before this point
+        self.side.wait_event(self._lane["tables_uploaded"])     # (by another engine of the pipeline, on its stream, when the entry is shared)
         with torch.cuda.stream(self.side):
             self.stage_lane_grid(self.side.cuda_stream)
-            self.grid_done.record(self.side)
+            self._lane["built_event"].record(self.side)
         self._lane["built"], self._lane["done"], self._lane["passes_since_build"] = True, False, 0
 
     def wait_lane_grid(self):
-        """Orders the current stream behind the last build of the lane index (nothing to do once the host has seen a pass
-        that followed the build complete: check_status / download / capture_graph note that)."""
+        """Orders the current stream behind the build of the lane index (by whichever engine of the pipeline built it; nothing to do
+        once the host has seen a pass that followed the build complete: check_status / download / capture_graph note that)."""
         if not self._lane.get("done"):
-            torch.cuda.current_stream(self.dev).wait_event(self.grid_done)
+            torch.cuda.current_stream(self.dev).wait_event(self._lane["built_event"])
 
     def rebuild_lane_grid(self):
         """Forgets the cached lane index: the next pass builds it again (benchmarks that want the build inside a pass)."""
@@ -744,7 +761,8 @@ class LiftPipeline:
         if depth < 1:
             raise ValueError("depth >= 1")
         self.dev = torch.device(device)
-        self.engines = [LiftEngine(device, **engine_kw) for _ in range(depth)]
+        shared = {}                                          # one cache of lane tables + indices for all slots
+        self.engines = [LiftEngine(device, lane_cache=shared, **engine_kw) for _ in range(depth)]
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(depth)]
         self.masks = [None] * depth
         self.uploaded = [torch.cuda.Event() for _ in range(depth)]      # recorded behind a slot's H2D copies (submit)

@@ -269,14 +269,18 @@ REFERENCE_BUCKETS = ("io", "points in mask", "medoid", "drivable", "closest lane
 
 def _native_batch_lanes(nt, names, lane_cache):
     """The scenes' lane tables (one per map location, cached) and the table every frame of the batch uses."""
-    lanes, frame_lane, locs = [], [], []
-    for k, name in enumerate(names):
-        loc = nt.location(name)
+    # one table per distinct LOCATION of the batch (ADVICE r3: four scenes of one city used to upload and index that city's table
+    # four times), in sorted order so that batches with the same set of cities carry the same tables -- the engines' shared cache
+    # of lane indices (lifting.LiftEngine) is keyed by that set
+    scene_loc = [nt.location(name) for name in names]
+    locs = sorted(set(scene_loc))
+    for loc in locs:
         if loc not in lane_cache:
             lane_cache[loc] = np.asarray(nusc_io.load_lane_points(nt.dataroot, loc), np.float64).astype(np.float32).reshape(-1, 3)   # torch.Tensor(...) at :278
-        lanes.append(lane_cache[loc])
-        locs.append(loc)
-        frame_lane.extend([k] * nt.scene_samples(name))
+    lanes = [lane_cache[loc] for loc in locs]
+    frame_lane = []
+    for name, loc in zip(names, scene_loc):
+        frame_lane.extend([locs.index(loc)] * nt.scene_samples(name))
     return lanes, frame_lane, locs
 
 

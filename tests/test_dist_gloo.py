@@ -131,3 +131,34 @@ def test_gather_records_eight_ranks_c3_shape():
         assert fr.size == 0 or (fr.min() >= a and fr.max() < b)          # scene-aligned: only frames of the rank's own scenes
     per_rank = [int(first[b] - first[a]) for a, b in bounds]
     assert max(per_rank) - min(per_rank) <= 2 * 40                       # balanced to within a scene at either end
+
+
+def _worker_missing_peer(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      CM3D_DIST_TIMEOUT_S="5")
+    from cm3d_amd import dist as cdist
+    r, w, _ = cdist.init_from_env(backend="gloo")
+    if r == 1:
+        os._exit(0)                              # this rank dies before the exchange
+    try:
+        cdist.gather_records(torch.zeros(3, 10, dtype=torch.float64), dst=0)
+        q.put("no error")
+    except cdist.GatherError as exc:
+        q.put("GatherError: " + str(exc)[:60])
+    os._exit(0)
+
+
+def test_a_missing_rank_ends_the_gather_with_an_error_not_a_hang():
+    """The one exchange has a timeout and a clear error: rank 1 leaves before it, rank 0 must get GatherError within
+    the timeout (5 s here) instead of waiting for ever."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_missing_peer, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=90)
+    for p in procs:
+        p.join(timeout=60)
+    assert got.startswith("GatherError"), got

@@ -20,7 +20,7 @@ def _run(*args):
 
 def test_lifting_bench_line():
     d = _run("--config", "tiny", "--frames", "8", "--steps", "6", "--warmup", "2", "--cpu-sample", "2", "--cpu-workers", "2",
-             "--lane-points", "2000")
+             "--lane-points", "2000", "--e2e-frames", "64")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -31,11 +31,19 @@ def test_lifting_bench_line():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "traffic" in rf
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
-    # bytes = what must move: every raw row (20 B) + a hit word (4 B) for the rows of 256-row blocks that hold an in-mask point -- the
-    # only hit words the launch writes; nothing the kernel skips is counted; no fraction anywhere above 1
+    # bytes = what must move: every raw row (12 B in the quad layout the bench packs) + a hit word (4 B) for the rows of 256-row blocks
+    # that hold an in-mask point -- the only hit words the launch writes; nothing the kernel skips is counted; no fraction anywhere above 1
     rows, nbytes = rf["rows_per_launch"], rf["bytes_per_launch"]
-    assert (nbytes - 20 * rows) % 4 == 0 and 0 < (nbytes - 20 * rows) // 4 <= rows
-    assert abs(rf["bytes_per_row"] - nbytes / rows) < 0.01 and 20 < rf["bytes_per_row"] <= 24
+    assert (nbytes - 12 * rows) % 4 == 0 and 0 < (nbytes - 12 * rows) // 4 <= rows
+    assert abs(rf["bytes_per_row"] - nbytes / rows) < 0.01 and 12 < rf["bytes_per_row"] <= 16
+    # the K timed steps against five more regions of the same K steps and one long region: the line's value must be
+    # one of that family (30 % slack on either side: six passes over eight tiny frames are a few hundred microseconds)
+    sp = d["value_spread"]
+    assert sp["repeats"] == 5 and sp["min"] <= sp["median"] <= sp["max"] and 0.7 * sp["min"] <= d["value"] <= 1.3 * sp["max"]
+    assert d["value_long"] > 0 and d["value_long_steps"] >= 6
+    # files -> labels through the entry point, timed inside the default line
+    e2e = d["end_to_end"]
+    assert "error" not in e2e and e2e["frames"] == 64 and e2e["frames_per_s"] > 0 and e2e["boxes"] > 0 and e2e["timer"]["total"] > 0
     md = d["kernels"]["medoid"]
     assert md["bound"] == "valu" and 0 < md["frac"] < 1 and 3.5 <= md["algorithmic_slots_per_pair"] <= 11.0
     assert d["config"]["cloud_materialised"] is False and d["ranks_in_group"] == 1
