@@ -8,6 +8,7 @@
 #include <atomic>
 #include <limits>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
 #include <functional>
@@ -490,9 +491,11 @@ extern "C" int cm3d_reader_load_sweeps_quads(cm3d_reader *r, const char *const *
                     if (intensity_out) intensity_out[q] = src[3];
                 }
             };
-            // the file's pages mapped (they are in the page cache when the job is hot: one pass, page cache -> batch, no copy into
-            // a buffer of ours first); a file system that cannot map falls back to reads in pieces
-            void *mp = mmap(nullptr, (size_t)(n * row_bytes), PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            // CM3D_READER_MMAP=1: the file's pages mapped (one pass, page cache -> batch, no copy into a buffer of ours first).  Off by
+            // default: measured on the GPU box (16 cores, 128 reader threads) the map / unmap of every file costs more than the copy it
+            // saves -- sweeps of a 256-frame batch 11.6 ms mapped against 6.9 ms read in pieces (address-space lock, TLB shootdowns)
+            static const bool use_mmap = getenv("CM3D_READER_MMAP") && atoi(getenv("CM3D_READER_MMAP")) != 0;
+            void *mp = use_mmap ? mmap(nullptr, (size_t)(n * row_bytes), PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0) : MAP_FAILED;
             if (mp != MAP_FAILED) {
                 scatter((const float *)mp, 0, n);
                 munmap(mp, (size_t)(n * row_bytes));

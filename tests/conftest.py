@@ -22,7 +22,7 @@ def oracle():
 # The raw rows of a batch exist in two layouts (include/cm3d_hip.h, cm3d_sweep_prep): the files' own rows and the quad layout
 # the product packs by default.  Every GPU parity test that packs frames runs once per layout.
 _LAYOUT_MODULES = {"test_gpu_parity", "test_gpu_magnitude", "test_gpu_campaign"}
-_LAYOUT_GOLDEN_PREFIXES = ("test_g2_", "test_g2b_", "test_g2d_", "test_integration_md")
+_LAYOUT_GOLDEN_PREFIXES = ("test_g2_", "test_g2b_", "test_g2d_", "test_g2e_", "test_g7r_", "test_integration_md")
 
 
 def pytest_generate_tests(metafunc):

@@ -68,3 +68,21 @@ def oracle_results(orc, frames, lane_tables, frame_lane, classes=None):
     exp = oracle_batch(orc, sub, lane_tables, fl, hb)
     out.update(lifting.box_records(hb, exp, classes))
     return out
+
+
+def g7r_scene(tmpdir):
+    """The scene of golden G7r (tests/golden/gen_golden_chain.py): the tiny scene of G7 -- one scene, two frames, written and read
+    back through the on-disk formats -- with the first three detections of every frame listed a second time at a lower score (the
+    same mask, so the same centroid: the per-sample NMS of the reference must drop the copies).  Returns (frames, lane points)."""
+    from cm3d_amd import nusc_io, synthetic as syn
+    tiny = syn.config("tiny")
+    dataroot, mask_dir, names = nusc_io.write_synthetic_dataset(str(tmpdir), tiny, n_scenes=1, frames_per_scene=2)
+    tables = nusc_io.NuscTables("v1.0-synth", dataroot)
+    scene = tables.scene_by_name(names[0])
+    frames = nusc_io.frames_of_scene(tables, scene, mask_dir, n_sweeps=3, ratio=tiny.ratio)
+    for f in frames:
+        f.rles = list(f.rles) + list(f.rles[:3])
+        f.labels = list(f.labels) + list(f.labels[:3])
+        f.cam_nums = list(f.cam_nums) + list(f.cam_nums[:3])
+        f.scores = list(f.scores) + [0.5 * float(s) for s in f.scores[:3]]
+    return frames, nusc_io.load_lane_points(dataroot, tables.location(scene))

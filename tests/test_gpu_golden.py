@@ -437,3 +437,56 @@ def test_every_form_of_the_rle_kernel_equals_the_oracle(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _RLE_FORM_SCRIPT.format(root=root)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FORM OK" in r.stdout, r.stderr[-3000:]
+
+
+def test_g2e_sweep_loop_of_the_reference():
+    """G2e on the device: raw sweeps -> fused sweep preparation + projection + compaction against what the REFERENCE'S OWN sweep
+    loop (from_file, ego-box filter, rotate / translate twice, hstack; gen_golden_chain.py) and its loop body produced -- the
+    cloud bit for bit (sha256), the dropped rows, the index lists and the listed points' coordinates, at 0 m / 1.7 km / 4 km."""
+    import hashlib
+    import torch
+    from cm3d_amd import lifting, synthetic as syn
+    from tests.test_oracle_golden import _g2e_cases
+    for c in _g2e_cases():
+        f = c["f"]
+        hb = lifting.pack_frames([f], [syn.make_lane_table(f.ego_xyz[:2], 2000, seed=1)], [0])
+        eng = lifting.LiftEngine(keep_cloud=True)
+        eng.upload(hb)
+        eng.run(masks="rle")
+        torch.cuda.synchronize()
+        got = eng.download()
+        assert got["points"].shape[0] == c["n"] and hashlib.sha256(np.ascontiguousarray(got["points"]).tobytes()).hexdigest() == c["sha"], c["mag"]
+        # the rows the device marked as dropped = the rows the reference's filter removed (sweep by sweep, in frame-local numbering)
+        removed = eng.removed_rows()
+        first = np.concatenate([[0], np.cumsum([np.asarray(r).shape[0] for r in f.sweeps_raw])])
+        want = np.concatenate([c["dropped"][c["dropped_off"][s]:c["dropped_off"][s + 1]] + first[s] for s in range(len(f.sweeps_raw))])
+        assert np.array_equal(np.flatnonzero(removed[:first[-1]]), want), c["mag"]
+        assert np.array_equal(got["hit_off"], c["idx_off"]) and np.array_equal(got["hit_idx"], c["idx"]), c["mag"]
+        assert np.array_equal(got["hit_xyz"].view(np.uint32), got["points"][c["idx"]].view(np.uint32))
+
+
+def test_g7r_scene_chained_through_the_reference_functions(tmp_path):
+    """G7r on the device: the scene the reference's own functions were chained over (stage 1, lane search, priors, push_centroid,
+    per-sample NMS with the reference's driver loops; gen_golden_chain.py) through the lifting engine: the same boxes in the same
+    order, centre and rotation within 1e-4 (north_star), here ~1e-6 (the device's float32 cos / sin of the lane yaw)."""
+    import json
+    import torch
+    from cm3d_amd import lifting
+    from tests.helpers import g7r_scene
+    frames, lane = g7r_scene(tmp_path)
+    want = json.load(open(os.path.join(G, "g7r_tiny_scene.json")))["results"]
+    hb = lifting.pack_frames(frames, [lane], [0] * len(frames))
+    eng = lifting.LiftEngine()
+    eng.upload(hb)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    got = lifting.box_records(hb, eng.download(full=False))
+    assert set(got) == set(want)
+    worst = 0.0
+    for tok, boxes in want.items():
+        assert [(b["detection_name"], b["detection_score"], b["size"], b["attribute_name"]) for b in got[tok]] == \
+               [(b["detection_name"], b["detection_score"], b["size"], b["attribute_name"]) for b in boxes], tok
+        for a, b in zip(got[tok], boxes):
+            worst = max(worst, float(np.abs(np.array(a["translation"]) - np.array(b["translation"])).max()),
+                        float(np.abs(np.array(a["rotation"]) - np.array(b["rotation"])).max()))
+    assert sum(len(v) for v in want.values()) == 12 and worst < 1e-4

@@ -265,3 +265,52 @@ def test_g7_tiny_scene_fixture_is_reproducible(oracle, tmp_path):
     res = oracle_results(oracle, frames, [nusc_io.load_lane_points(dataroot, tables.location(scene))], [0] * len(frames))
     want = json.load(open(os.path.join(G, "g7_tiny_scene.json")))
     assert json.loads(json.dumps(res)) == want["results"]
+
+
+def _g2e_cases():
+    """The frames tests/golden/gen_golden_chain.py ran the reference's SWEEP LOOP on (2d_to_3d.py:437-465 on the imported
+    LidarPointCloud.from_file / rotate / translate, ego pose 0 m / 1.7 km / 4 km from the map origin): per case the frame, the
+    fixture's cloud checksum, the rows the reference's filter dropped (per sweep), sampled points and the index lists."""
+    from cm3d_amd import synthetic as syn
+    g = np.load(os.path.join(G, "g2e_sweep_loop.npz"))
+    out = []
+    for k in range(3):
+        spec = json.loads(str(g[f"m{k}_spec"]))
+        f = syn.make_frame(syn.config(spec["config"], **spec["over"]), spec["index"])
+        out.append(dict(mag=spec["over"]["ego_magnitude"], f=f, sha=str(g[f"m{k}_sha256"]), n=int(g[f"m{k}_n_points"]), dropped=g[f"m{k}_dropped"],
+                        dropped_off=g[f"m{k}_dropped_off"], sample=g[f"m{k}_sample"], idx=g[f"m{k}_idx"], idx_off=g[f"m{k}_idx_off"]))
+    return out
+
+
+def test_g2e_the_reference_sweep_loop(oracle):
+    """G2e: files -> aggregated cloud through the REFERENCE'S OWN sweep loop (from_file, the ego-box filter of :442-445, rotate /
+    translate twice, hstack) = the oracle's sweep_prep, bit for bit (sha256 over the whole cloud), with the same rows dropped; and
+    the reference's loop body on that cloud = the oracle's index lists."""
+    import hashlib
+    from cm3d_amd import rle
+    for c in _g2e_cases():
+        f = c["f"]
+        P = np.concatenate([oracle.sweep_prep(r, x[0:9], x[9:12], x[12:21], x[21:24]) for r, x in zip(f.sweeps_raw, f.sweep_xf)], 0)
+        assert P.shape[0] == c["n"] and hashlib.sha256(P.tobytes()).hexdigest() == c["sha"], c["mag"]
+        assert np.array_equal(P[::97].view(np.uint32), c["sample"].view(np.uint32))
+        for s, r in enumerate(f.sweeps_raw):                 # the filter, from the raw rows: float32 |x| < f32(sqrt(2.3)) and the same for y
+            r = np.asarray(r, np.float32)
+            drop = np.flatnonzero((np.abs(r[:, 0]) < oracle.EGO_HALFW_F32) & (np.abs(r[:, 1]) < oracle.EGO_HALFW_F32))
+            assert np.array_equal(drop, c["dropped"][c["dropped_off"][s]:c["dropped_off"][s + 1]]), (c["mag"], s)
+        lists = [oracle.points_in_mask(P, f.cams[cam], oracle.erode3x3(rle.counts_to_dense(rle.string_to_counts(m["counts"]), f.width, f.height)))
+                 for m, cam in zip(f.rles, f.cam_nums)]
+        assert np.array_equal(np.concatenate(lists), c["idx"]) and np.array_equal(np.cumsum([0] + [l.size for l in lists]), c["idx_off"])
+        assert c["idx"].size > 5000 and c["dropped"].size > 100
+
+
+def test_g7r_scene_chained_through_the_reference_functions(oracle, tmp_path):
+    """G7r: one scene through the reference's get_medoid -> lane_yaws_distances_and_coords -> get_detection_name -> get_shape_prior ->
+    push_centroid -> circle_nms with the reference's driver code between them (the running mask counter, the per-sample NMS loop;
+    gen_golden_chain.py) = the oracle pipeline: the same boxes in the same order, every number equal (the generating run
+    measured a largest difference of exactly 0)."""
+    from tests.helpers import g7r_scene, oracle_results
+    frames, lane = g7r_scene(tmp_path)
+    want = json.load(open(os.path.join(G, "g7r_tiny_scene.json")))
+    assert want["masks_in_scene"] == sum(len(f.rles) for f in frames) == 22 and want["masks_with_points"] == 17
+    res = json.loads(json.dumps(oracle_results(oracle, frames, [lane], [0] * len(frames))))
+    assert sum(len(v) for v in res.values()) == 12 and res == want["results"]          # NMS dropped the five listed-twice detections
