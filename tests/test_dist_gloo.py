@@ -146,6 +146,8 @@ def _worker_missing_peer(rank, world, port, q):
         q.put("no error")
     except cdist.GatherError as exc:
         q.put("GatherError: " + str(exc)[:60])
+    q.close()
+    q.join_thread()                              # (the queue's feeder thread must have written the item before the process ends)
     os._exit(0)
 
 
