@@ -23,43 +23,55 @@ static __device__ __forceinline__ int cm3d_mbcnt(uint64_t m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// ---- wave-wide reductions and the scan, on the DATA-PARALLEL-PRIMITIVE path of the vector ALU (r04).
+// __shfl_xor / __shfl_up compile to ds_bpermute_b32: a trip through the LDS crossbar and an s_waitcnt per step, six dependent steps
+// per reduction -- several hundred cycles in kernels that are chains of dependent steps already (the RLE scan, the compaction's
+// offsets, the frame tables).  A DPP operand costs nothing beyond its instruction: four steps inside each row of 16 lanes
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four rows' values through v_readlane.
+// Every lane (and the scalar unit) gets the result.
+#define CM3D_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+template <typename Op>
+static __device__ __forceinline__ int cm3d_wave_reduce(int v, Op op)
+{
+    v = op(v, CM3D_DPP(v, 0xB1));          // quad_perm [1,0,3,2]
+    v = op(v, CM3D_DPP(v, 0x4E));          // quad_perm [2,3,0,1]
+    v = op(v, CM3D_DPP(v, 0x141));         // row_half_mirror
+    v = op(v, CM3D_DPP(v, 0x140));         // row_mirror: every lane of a row holds the row's value
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16), r2 = __builtin_amdgcn_readlane(v, 32),
+              r3 = __builtin_amdgcn_readlane(v, 48);
+    return op(op(r0, r1), op(r2, r3));
+}
+
 static __device__ __forceinline__ uint32_t cm3d_wave_or(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o, 64);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    return (uint32_t)cm3d_wave_reduce((int)v, [](int a, int b) { return a | b; });
 }
 
 static __device__ __forceinline__ int cm3d_wave_sum(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return cm3d_wave_reduce(v, [](int a, int b) { return a + b; });
 }
 
 static __device__ __forceinline__ int cm3d_wave_min(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+    return cm3d_wave_reduce(v, [](int a, int b) { return a < b ? a : b; });
 }
 
 static __device__ __forceinline__ int cm3d_wave_max(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
+    return cm3d_wave_reduce(v, [](int a, int b) { return a > b ? a : b; });
 }
 
-// inclusive scan across one wave
+// inclusive scan across one wave: row_shr 1, 2, 4, 8 inside each row of 16 (zeros shift in), then the last lane of row 0 / 2 onto
+// row 1 / 3 (row_bcast:15) and lane 31 onto rows 2 and 3 (row_bcast:31)
 static __device__ __forceinline__ int cm3d_wave_incl_scan(int v)
 {
-    const int lane = cm3d_lane();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
+    v += CM3D_DPP(v, 0x111);
+    v += CM3D_DPP(v, 0x112);
+    v += CM3D_DPP(v, 0x114);
+    v += CM3D_DPP(v, 0x118);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);       // row_bcast:15, rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);       // row_bcast:31, rows 2 and 3
     return v;
 }
 

@@ -594,7 +594,7 @@ __global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uin
     const int bandr = (my1 - my0 + nb) / nb;
     const int ry0 = my0 + band * bandr, ry1 = min(my1, ry0 + bandr - 1);
     const int xw0 = xlo >> 5, wc = (min(xhi, W - 1) >> 5) - xw0 + 1, lw = wc + 2;
-    rect_x = xw0; rect_y = my0; rect_w = wc; rect_h = my1 - my0 + 1;
+    rect_x = xw0; rect_y = my0; rect_w = max(wc, 0); rect_h = max(my1 - my0 + 1, 0);     // (never negative: run lengths that overshoot W*H must not poison the table entries)
     int br = lds_words / lw - 2;                // output rows per tile
     br = min(br, ry1 - ry0 + 1);
     const uint32_t pad = (W & 31) ? ~((1u << (W & 31)) - 1u) : 0u;

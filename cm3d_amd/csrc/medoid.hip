@@ -207,7 +207,7 @@ static __device__ __forceinline__ f2 md_pk_add_clamp01(f2 a, f2 b)
 }
 
 // SCALED (with SAFE): rows and column are scaled by 2^-16 (norms by 2^-32) and every squared distance is below 1 -- the caller has
-// checked the norms (mda_norm_ok) --, so clamp_min_(0) rides on the last addition and the 8 v_max_f32 of a step are gone; s is in
+// checked the norms (mda_point_ok) --, so clamp_min_(0) rides on the last addition and the 8 v_max_f32 of a step are gone; s is in
 // scaled units.
 template <bool DIRECT, bool APPROX = false, bool SAFE = false, bool SCALED = false>
 static __device__ __forceinline__ float md_rows(const float4 *s4, int cnt, float qx, float qy, float qz, float qn, float s)
@@ -360,7 +360,13 @@ static __device__ __forceinline__ float md_vsqrt_clamp01(float x)
 #define MDA_S2 2.3283064365386963e-10f
 #define MDA_N_MAX 1.0e9f
 #define MDA_N_MIN 1.0e-10f
-static __device__ __forceinline__ bool mda_norm_ok(float n) { return n == 0.0f || (n >= MDA_N_MIN && n < MDA_N_MAX); }
+// ... of a POINT: a squared norm of zero only counts when the point IS the origin.  Coordinates of 1e-23 m square to zero as well, but
+// their products with other points' coordinates do not vanish, and the scaled chain would carry denormal values into the root's
+// sequence outside the domain it is checked on; such points take the unscaled, tested routes.
+static __device__ __forceinline__ bool mda_point_ok(float x, float y, float z, float n)
+{
+    return n == 0.0f ? (x == 0.0f && y == 0.0f && z == 0.0f) : (n >= MDA_N_MIN && n < MDA_N_MAX);
+}
 
 template <typename Fetch>
 static __device__ __forceinline__ void md_approx_tile(Fetch fetch, float *s_rows, int off, int M, int jt, float *__restrict__ approx_out)
@@ -376,7 +382,7 @@ static __device__ __forceinline__ void md_approx_tile(Fetch fetch, float *s_rows
         float qx = 0.f, qy = 0.f, qz = 0.f;
         if (j < M) { const float4 q = fetch(off + j); qx = q.x; qy = q.y; qz = q.z; }
         const float qn = (qx * qx + qy * qy) + qz * qz;
-        cols_ok &= mda_norm_ok(qn);
+        cols_ok &= mda_point_ok(qx, qy, qz, qn);
         b1[g] = (lo ? qx : qy) * MDA_S; b2[g] = lo ? qz * MDA_S : 1.0f; b3[g] = lo ? qn * MDA_S2 : 0.0f;
     }
     cols_ok = !__ballot(!cols_ok);                            // (uniform)
@@ -395,7 +401,7 @@ static __device__ __forceinline__ void md_approx_tile(Fetch fetch, float *s_rows
             if (i0 + c * 64 + lane < M) {
                 const float4 p = g4[c];
                 rr[c] = make_float4(-2.0f * p.x, -2.0f * p.z, -2.0f * p.y, (p.x * p.x + p.y * p.y) + p.z * p.z);
-                rows_ok &= mda_norm_ok(rr[c].w);
+                rows_ok &= mda_point_ok(p.x, p.y, p.z, rr[c].w);
             }
         }
         const bool scaled = MD_SCALED_ROUTES && cols_ok && !__ballot(!rows_ok);   // (uniform) this chunk of rows in the scaled form
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
         }
         float s = 0.f;
         const bool col_safe = !__ballot(act && !md_col_safe(qn));
-        const bool col_scal = !__ballot(act && !mda_norm_ok(qn));           // the column side of the scaled form (md_rows<.., SCALED>)
+        const bool col_scal = !__ballot(act && !mda_point_ok(qx, qy, qz, qn));           // the column side of the scaled form (md_rows<.., SCALED>)
         const bool direct = M <= 25;
         const bool approx = approx_opt != nullptr && md_two_pass(M);      // long list: approximate sums (k_medoid_approx), k_medoid_long later
         if (WITH_LONG && approx && MD_APPROX_MFMA) {
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
                     float4 r = g[c];
                     r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
                     rows_safe &= md_row_safe(r.w);
-                    rows_scal &= mda_norm_ok(r.w);
+                    rows_scal &= mda_point_ok(r.x, r.y, r.z, r.w);
                     // the expansion branch only ever needs -2x, -2y, -2z of a row (exact products)
                     if (!direct) { r.x = -2.0f * r.x; r.y = -2.0f * r.y; r.z = -2.0f * r.z; }
                     g[c] = r;

@@ -857,7 +857,7 @@ extern "C" int32_t cm3d_tables_scene_samples(const cm3d_tables *t, const char *s
     auto it = t->scene_by_name.find(scene_name);
     if (it == t->scene_by_name.end()) return CM3D_RD_ERR_ARG;
     int n = 0;
-    for (int s = t->scenes[it->second].first; s >= 0; s = t->samples[s].next) ++n;
+    for (int s = t->scenes[it->second].first; s >= 0 && n <= (int)t->samples.size(); s = t->samples[s].next) ++n;   // (bounded: a cycle of `next` ends here)
     return n;
 }
 
@@ -896,7 +896,9 @@ extern "C" int64_t cm3d_tables_job_tokens(const cm3d_tables *t, const char *cons
     for (int i = 0; i < n_scenes; ++i) {
         auto it = t->scene_by_name.find(scene_names[i] ? scene_names[i] : "");
         if (it == t->scene_by_name.end()) return CM3D_RD_ERR_ARG;
+        int64_t walked = 0;                                      // a cycle of `next` in sample.json ends the walk with an error, not the process
         for (int s = t->scenes[it->second].first; s >= 0; s = t->samples[s].next) {
+            if (++walked > (int64_t)t->samples.size()) return CM3D_RD_ERR_FORMAT;
             const std::string &tok = t->samples[s].token;
             need += (int64_t)tok.size() + 1;
             if (out && need <= cap) { memcpy(p, tok.c_str(), tok.size() + 1); p += tok.size() + 1; }
@@ -974,7 +976,8 @@ extern "C" cm3d_manifest *cm3d_tables_manifest(const cm3d_tables *t, cm3d_reader
             auto it = t->scene_by_name.find(scene_names[k] ? scene_names[k] : "");
             if (it == t->scene_by_name.end()) return fail(CM3D_RD_ERR_ARG);
             int num = 0;
-            for (int s = t->scenes[it->second].first; s >= 0; s = t->samples[s].next) frames.push_back({&t->scenes[it->second].name, num++, s});
+            for (int s = t->scenes[it->second].first; s >= 0 && num <= (int)t->samples.size(); s = t->samples[s].next)
+                frames.push_back({&t->scenes[it->second].name, num++, s});
         }
         const int F = (int)frames.size();
         m->n_frames = F;
@@ -1210,8 +1213,10 @@ extern "C" int64_t cm3d_write_results_json(const double *records, int64_t n, con
         // stable bucket by sample
         std::vector<int64_t> first((size_t)n_tokens + 1, 0), order((size_t)n);
         for (int64_t i = 0; i < n; ++i) {
-            const int64_t ti = (int64_t)records[10 * i + 5];
-            if (ti < 0 || ti >= n_tokens || (int)records[10 * i + 8] < 0 || (int)records[10 * i + 8] >= n_classes) return 0;
+            // (range first, cast after: a NaN or an infinite column must not reach an integer conversion)
+            const double td = records[10 * i + 5], cd = records[10 * i + 8];
+            if (!(td >= 0.0 && td < (double)n_tokens) || !(cd >= 0.0 && cd < (double)n_classes)) return 0;
+            const int64_t ti = (int64_t)td;
             ++first[ti + 1];
         }
         for (int i = 0; i < n_tokens; ++i) first[i + 1] += first[i];

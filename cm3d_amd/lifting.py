@@ -343,7 +343,7 @@ def _verify_matrix_pipe(lib, dev):
         n_bad = int(bad.item())
     if n_bad:
         raise Cm3dError(f"matrix-pipe self-test failed on {key}: {n_bad} of {2048 * 24 * 1024} squared distances differ from the "
-                        "vector fma chain; rebuild with -DMD_APPROX_MFMA=0")
+                        "vector fma chain or an output clamp is not honoured; rebuild with -DMD_APPROX_MFMA=0 -DMD_SCALED_ROUTES=0")
     _MFMA_VERIFIED[key] = True
 
 
