@@ -50,11 +50,8 @@ __global__ __launch_bounds__(LG_BUILD_THREADS) void k_lane_grid_build(const floa
         const float x = lane[(size_t)(lo + i) * 3], y = lane[(size_t)(lo + i) * 3 + 1];
         if (x == x && y == y) { mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y); }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
-        mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
-    }
+    mnx = cm3d_wave_reduce_t(mnx, [](float a, float b) { return fminf(a, b); }); mny = cm3d_wave_reduce_t(mny, [](float a, float b) { return fminf(a, b); });
+    mxx = cm3d_wave_reduce_t(mxx, [](float a, float b) { return fmaxf(a, b); }); mxy = cm3d_wave_reduce_t(mxy, [](float a, float b) { return fmaxf(a, b); });
     const int wave = threadIdx.x >> 6;
     if (cm3d_lane() == 0) { s_red[0][wave] = mnx; s_red[1][wave] = mny; s_red[2][wave] = mxx; s_red[3][wave] = mxy; }
     __syncthreads();
@@ -210,9 +207,7 @@ __global__ __launch_bounds__(256) void k_lane_nn_grid(const float *__restrict__ 
             }
             r_done = r_hi;
             // wave-wide best distance so far
-            double wb = sbest;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) wb = fmin(wb, __shfl_xor(wb, o, 64));
+            const double wb = cm3d_wave_reduce_t(sbest, [](double a, double b) { return fmin(a, b); });
             // every unvisited point is at least r_done * h - margin away
             if (wb < (double)r_done * (double)g.h - (double)g.margin) { resolved = true; break; }
             if (qi - r_done <= 0 && qi + r_done >= g.gw - 1 && qj - r_done <= 0 && qj + r_done >= g.gh - 1) { resolved = true; break; }   // whole grid seen
@@ -240,11 +235,9 @@ __global__ __launch_bounds__(256) void k_lane_nn_grid(const float *__restrict__ 
         }
     }
     // lexicographic (distance, index) minimum over the lanes
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double os = __shfl_xor(sbest, o, 64);
-        const int oj = __shfl_xor(jbest, o, 64);
-        if (os < sbest || (os == sbest && oj < jbest)) { sbest = os; jbest = oj; }
+    {
+        const Cm3dDistIdx best = cm3d_wave_argmin(sbest, jbest);
+        sbest = best.s; jbest = best.j;
     }
     if (lane == 0) {
         if (jbest == 0x7FFFFFFF) jbest = 0;      // empty table / NaN centroid: np.argmin of an all-inf/NaN row

@@ -42,6 +42,54 @@ static __device__ __forceinline__ int cm3d_wave_reduce(int v, Op op)
     return op(op(r0, r1), op(r2, r3));
 }
 
+// the same for any value made of 32-bit words (doubles, (distance, index) pairs): every word moves with the same DPP control
+template <int CTRL, typename T>
+static __device__ __forceinline__ T cm3d_dpp_t(T v)
+{
+    static_assert(sizeof(T) % 4 == 0, "whole 32-bit words");
+    int w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = __builtin_amdgcn_update_dpp(0, w[i], CTRL, 0xF, 0xF, true);
+    T o;
+    __builtin_memcpy(&o, w, sizeof(T));
+    return o;
+}
+template <typename T>
+static __device__ __forceinline__ T cm3d_readlane_t(T v, int l)
+{
+    int w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = __builtin_amdgcn_readlane(w[i], l);
+    T o;
+    __builtin_memcpy(&o, w, sizeof(T));
+    return o;
+}
+// op must be associative and commutative (min, max, a lexicographic minimum, ...): every lane gets the wave's value
+template <typename T, typename Op>
+static __device__ __forceinline__ T cm3d_wave_reduce_t(T v, Op op)
+{
+    v = op(v, cm3d_dpp_t<0xB1>(v));
+    v = op(v, cm3d_dpp_t<0x4E>(v));
+    v = op(v, cm3d_dpp_t<0x141>(v));
+    v = op(v, cm3d_dpp_t<0x140>(v));
+    const T r0 = cm3d_readlane_t(v, 0), r1 = cm3d_readlane_t(v, 16), r2 = cm3d_readlane_t(v, 32), r3 = cm3d_readlane_t(v, 48);
+    return op(op(r0, r1), op(r2, r3));
+}
+struct Cm3dDistIdx { double s; int j; int pad; };          // (distance, index): lexicographic minimum = np.argmin's first minimum
+static __device__ __forceinline__ Cm3dDistIdx cm3d_wave_argmin(double s, int j)
+{
+    Cm3dDistIdx v = {s, j, 0};
+    return cm3d_wave_reduce_t(v, [](Cm3dDistIdx a, Cm3dDistIdx b) { return (b.s < a.s || (b.s == a.s && b.j < a.j)) ? b : a; });
+}
+struct Cm3dValIdx { float s; int j; };
+static __device__ __forceinline__ Cm3dValIdx cm3d_wave_argmin_f(float s, int j)
+{
+    Cm3dValIdx v = {s, j};
+    return cm3d_wave_reduce_t(v, [](Cm3dValIdx a, Cm3dValIdx b) { return (b.s < a.s || (b.s == a.s && b.j < a.j)) ? b : a; });
+}
+
 static __device__ __forceinline__ uint32_t cm3d_wave_or(uint32_t v)
 {
     return (uint32_t)cm3d_wave_reduce((int)v, [](int a, int b) { return a | b; });

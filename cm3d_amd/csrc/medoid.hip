@@ -595,11 +595,9 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
             if (!n1 && s1 != s2) return s1 < s2;
             return j1 < j2;
         };
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float os = __shfl_xor(bs, o, 64);
-            const int oj = __shfl_xor(bj, o, 64);
-            if (better(os, oj, bs, bj)) { bs = os; bj = oj; }
+        {   // (DPP moves instead of ds_bpermute round trips: common.h)
+            const Cm3dValIdx red = cm3d_wave_reduce_t(Cm3dValIdx{bs, bj}, [&](Cm3dValIdx a_, Cm3dValIdx b_) { return better(b_.s, b_.j, a_.s, a_.j) ? b_ : a_; });
+            bs = red.s; bj = red.j;
         }
         if (lane == 0) { tile_best[d.t].s = bs; tile_best[d.t].j = bj; }
 #ifdef CM3D_DIAG
@@ -750,8 +748,7 @@ __global__ __launch_bounds__(64 * MDL_WAVES, 2) void k_medoid_long(const float4 
         if (!(a >= 0.0 && a < 1e300)) all = true;
         thr = fmin(thr, a + (a * rel + abs_e));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) thr = fmin(thr, __shfl_xor(thr, o, 64));
+    thr = cm3d_wave_reduce_t(thr, [](double a_, double b_) { return fmin(a_, b_); });
     if (lane == 0) s_thr[wave] = thr;
     if (__ballot(all) && lane == 0) atomicOr(&s_all, 1);
     __syncthreads();
@@ -780,11 +777,9 @@ __global__ __launch_bounds__(64 * MDL_WAVES, 2) void k_medoid_long(const float4 
         if (wave != 0) continue;
         float bs = lane < C ? s_sum[lane] : INFINITY;
         int bj = lane < C ? s_list[lane] : 0x7FFFFFFF;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float os = __shfl_xor(bs, o, 64);
-            const int oj = __shfl_xor(bj, o, 64);
-            if (better(os, oj, bs, bj)) { bs = os; bj = oj; }
+        {   // (DPP moves instead of ds_bpermute round trips: common.h)
+            const Cm3dValIdx red = cm3d_wave_reduce_t(Cm3dValIdx{bs, bj}, [&](Cm3dValIdx a_, Cm3dValIdx b_) { return better(b_.s, b_.j, a_.s, a_.j) ? b_ : a_; });
+            bs = red.s; bj = red.j;
         }
         best_s = bs; best_j = bj;
     } else {
@@ -837,11 +832,9 @@ __global__ __launch_bounds__(64 * MDL_WAVES, 2) void k_medoid_long(const float4 
                 }
                 float bs = act ? s : INFINITY;
                 int bj = act ? cj : 0x7FFFFFFF;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float os = __shfl_xor(bs, o, 64);
-                    const int oj = __shfl_xor(bj, o, 64);
-                    if (better(os, oj, bs, bj)) { bs = os; bj = oj; }
+                {   // (DPP moves instead of ds_bpermute round trips: common.h)
+                    const Cm3dValIdx red = cm3d_wave_reduce_t(Cm3dValIdx{bs, bj}, [&](Cm3dValIdx a_, Cm3dValIdx b_) { return better(b_.s, b_.j, a_.s, a_.j) ? b_ : a_; });
+                    bs = red.s; bj = red.j;
                 }
                 if (bj != 0x7FFFFFFF && (best_j == 0x7FFFFFFF || better(bs, bj, best_s, best_j))) { best_s = bs; best_j = bj; }
                 nc = 0;
