@@ -33,17 +33,29 @@ struct PqArgs {
 #define PQ_MIN_BLOCKS 3                           // waves per SIMD the register budget is held to (168 registers): what the launch fills anyway
 #endif
 
-static __device__ __forceinline__ float pq_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-
-// sensor -> ego -> global for the lane's four rows with the sweep's coefficients as scalar operands (c[k] = lane k of `vxf`):
-// the k-sequential fma chains of k_sweep_xform / ph_xform, row by row
-static __device__ __forceinline__ void pq_xform4(float vxf, const float (&q)[12], float (&o)[12])
+// sensor -> ego -> global for the lane's four rows, two rows per packed instruction: the k-sequential fma chains of k_sweep_xform /
+// ph_xform element by element (same bits).  xf = the sweep's 24 coefficients in the wave's LDS slice: they come as VECTOR registers
+// (six broadcast ds_read_b128, no vector-ALU time) -- measured on this chip (tools/ubench/valu_wall.hip, profiles/r04_valu_wall.txt): a
+// packed fma with register operands occupies the SIMD 4.6 cycles for two rows, an fma with a SCALAR operand 4.5 for one, and every
+// v_readlane that brings a coefficient into a scalar register 8.8 more.
+static __device__ __forceinline__ void pq_xform4(const float *xf, const float (&q)[12], float (&o)[12])
 {
     float c[CM3D_SWEEP_XF_STRIDE];
 #pragma unroll
-    for (int k = 0; k < CM3D_SWEEP_XF_STRIDE; ++k) c[k] = pq_readlane_f(vxf, k);
+    for (int k = 0; k < CM3D_SWEEP_XF_STRIDE / 4; ++k) {
+        const float4 t = reinterpret_cast<const float4 *>(xf)[k];
+        c[4 * k] = t.x; c[4 * k + 1] = t.y; c[4 * k + 2] = t.z; c[4 * k + 3] = t.w;
+    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ph_xform(c, q[j], q[4 + j], q[8 + j], o[j], o[4 + j], o[8 + j]);
+    for (int h = 0; h < 2; ++h) {
+        const f2 x = {q[2 * h], q[2 * h + 1]}, y = {q[4 + 2 * h], q[5 + 2 * h]}, z = {q[8 + 2 * h], q[9 + 2 * h]};
+        f2 ax, ay, az, bx, by, bz;
+        rot3_2(c, x, y, z, ax, ay, az);                             // sensor -> ego (rotate then translate), ego -> global (2d_to_3d.py:450-457)
+        ax = ax + c[9]; ay = ay + c[10]; az = az + c[11];
+        rot3_2(c + 12, ax, ay, az, bx, by, bz);
+        bx = bx + c[21]; by = by + c[22]; bz = bz + c[23];
+        o[2 * h] = bx.x; o[2 * h + 1] = bx.y; o[4 + 2 * h] = by.x; o[5 + 2 * h] = by.y; o[8 + 2 * h] = bz.x; o[9 + 2 * h] = bz.y;
+    }
 }
 
 #ifdef CM3D_DIAG
@@ -72,6 +84,8 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
     const int lane = cm3d_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     __shared__ __align__(16) float s_cam_all[PHK_WAVES][CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
     __shared__ __align__(16) float s_tab_all[PHK_WAVES][FT_WORDS - FT_WEDGE];
+    __shared__ __align__(16) float s_xf_all[PHK_WAVES][2][CM3D_SWEEP_XF_STRIDE];     // the current sweep's coefficients, and a second set for a chunk with a sweep boundary
+    float *const s_xf = s_xf_all[wave][0], *const s_xf2 = s_xf_all[wave][1];
     float *const s_cam = s_cam_all[wave];
     float(*const s_wedge)[8] = reinterpret_cast<float(*)[8]>(s_tab_all[wave]);
     float(*const s_apx)[16] = reinterpret_cast<float(*)[16]>(s_tab_all[wave] + (FT_APX - FT_WEDGE));
@@ -175,13 +189,13 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
     int c_nxt = chunk_of(draw2_v, slot);
     PQ_STAMP(0);                                                    // start-up
 
-    // the sweep whose coefficients `vxf` holds (lane k = coefficient k); -1: none yet
-    float vxf = 0.f;
+    // the sweep whose coefficients the wave's LDS slice holds; -1: none yet
     int vxf_sweep = -1;
-    auto load_xf = [&](int sw) {                                    // sw: sweep inside the frame
-        float v = 0.f;
-        if (lane < CM3D_SWEEP_XF_STRIDE) v = a.sweep_xf[(size_t)(sa + sw) * CM3D_SWEEP_XF_STRIDE + lane];
-        return v;
+    auto load_xf = [&](int sw, float *dst) {                        // sw: sweep inside the frame; lane k fetches coefficient k
+        if (lane < CM3D_SWEEP_XF_STRIDE) dst[lane] = a.sweep_xf[(size_t)(sa + sw) * CM3D_SWEEP_XF_STRIDE + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     const int32_t *srow = ft + FT_SROW;
 
@@ -250,18 +264,18 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
         // ---- sweep preparation (reference :437-465): ego-box drop on the raw coordinates, sensor -> ego -> global
         int sw_lo = 0, sw_hi = 0;
         if (ns > 1) { sw_lo = ph_sweep_of(srow, ns, cb); sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1); }
-        if (sw_lo != vxf_sweep) { vxf = load_xf(sw_lo); vxf_sweep = sw_lo; }
+        if (sw_lo != vxf_sweep) { load_xf(sw_lo, s_xf); vxf_sweep = sw_lo; }
         float g[12];
-        if ((a.stage & 255) >= 1) pq_xform4(vxf, cur.q, g);
+        if ((a.stage & 255) >= 1) pq_xform4(s_xf, cur.q, g);
         else {
 #pragma unroll
             for (int k = 0; k < 12; ++k) g[k] = cur.q[k];
         }
         if (sw_hi > sw_lo) {                                        // a sweep boundary inside the chunk: once more per further sweep, rows selected
             for (int sw = sw_lo + 1; sw <= sw_hi; ++sw) {
-                const float vx2 = load_xf(sw);
+                load_xf(sw, s_xf2);
                 float g2[12];
-                pq_xform4(vx2, cur.q, g2);
+                pq_xform4(s_xf2, cur.q, g2);
                 const int first = srow[sw];                         // frame-local first row of sweep sw
 #pragma unroll
                 for (int j = 0; j < PH_PT; ++j)
@@ -269,13 +283,25 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
             }
         }
         uint32_t nib = 0;
+        // Nearly every chunk is full and holds no row inside the ego box: eight compares say so, and nothing is selected at all.
+        // (A v_cndmask on VCC occupies the SIMD for 23 cycles on this chip -- tools/ubench/valu_wall.hip -- and the general path below
+        // needs three per row.)
+        bool boxed = false;
 #pragma unroll
-        for (int j = 0; j < PH_PT; ++j) {
-            const bool live = 4 * lane + j < nvalid;
-            const bool drop = live && fabsf(cur.q[j]) < halfw && fabsf(cur.q[4 + j]) < halfw;       // :442-445
-            if (!live || drop) { g[j] = qnan; g[4 + j] = qnan; g[8 + j] = qnan; }
-            nib |= (drop ? 1u : 0u) << j;
-            if (KEEP && live) a.points_out[(size_t)p0 + cb + 4 * lane + j] = make_float4(g[j], g[4 + j], g[8 + j], cur.w[KEEP ? j : 0]);
+        for (int j = 0; j < PH_PT; ++j) boxed |= fabsf(cur.q[j]) < halfw && fabsf(cur.q[4 + j]) < halfw;
+        if (nvalid < PH_WC || __ballot(boxed)) {
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j) {
+                const bool live = 4 * lane + j < nvalid;
+                const bool drop = live && fabsf(cur.q[j]) < halfw && fabsf(cur.q[4 + j]) < halfw;       // :442-445
+                if (!live || drop) { g[j] = qnan; g[4 + j] = qnan; g[8 + j] = qnan; }
+                nib |= (drop ? 1u : 0u) << j;
+            }
+        }
+        if (KEEP) {
+#pragma unroll
+            for (int j = 0; j < PH_PT; ++j)
+                if (4 * lane + j < nvalid) a.points_out[(size_t)p0 + cb + 4 * lane + j] = make_float4(g[j], g[4 + j], g[8 + j], cur.w[KEEP ? j : 0]);
         }
         f2 X[PH_NP], Y[PH_NP], Z[PH_NP];
 #pragma unroll
@@ -368,7 +394,11 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int iu = (int)__builtin_amdgcn_fmed3f(ua[q], 0.f, 32001.f), iv = (int)__builtin_amdgcn_fmed3f(va[q], 0.f, 32001.f);
-                        pa[2 * h + q] = zc[q] > zmin ? ((iv << 16) | iu) : -1;
+                        // code, or -1 unless zc > zmin: the sign of zmin - zc spread over the word and inverted (integer operations at
+                        // full rate instead of a compare and a select on VCC; a NaN depth keeps a positive sign here -- it comes from the
+                        // NaN of a dead row -- and is killed like a small one; if it were not, the exact chain would reject the point)
+                        const int keep = __float_as_int(zmin - zc[q]) >> 31;          // all ones: zc > zmin
+                        pa[2 * h + q] = ((iv << 16) | iu) | ~keep;
                     }
                 }
             }
