@@ -603,7 +603,7 @@ def main(argv=None):
     # inside the timed region -- i.e. while the other batches in flight share the GPU with it
     rows = hb.n_raw_rows
     per_row_in = (hb.bytes_per_row if r["fused"] else 16) + (16 if (r["fused"] and cloud_stored) else 0)
-    roofline = roof("k_project_hits", r["stage_ms"]["project"], "k_project_hits<ONE_PLANE, FUSED, STRIDE>" if r["fused"] else "k_project_hits",
+    roofline = roof("k_project_hits", r["stage_ms"]["project"], ("k_project_q<NPL, KEEP> (quad layout)" if hb.quads else "k_project_hits<ONE_PLANE, FUSED, STRIDE>") if r["fused"] else "k_project_hits",
                     f"bytes that must cross HBM per launch = {per_row_in} B/row x {rows} rows: "
                     + (f"raw sweep rows read ({hb.bytes_per_row} B/row, layout {'quads: x,y,z of four rows side by side, the unused columns stay on the host' if hb.quads else 'rows as in the .bin files'})" if r["fused"] else "prepared cloud read (16 B/row)")
                     + (" + transformed cloud written (16 B/row)" if (r["fused"] and cloud_stored) else "")
@@ -642,7 +642,7 @@ def main(argv=None):
             # the PMC passes were taken on the default workload; a different batch gets no traffic figure
             if args.frames == int(tr.get("frames_per_gpu", 256)) and not args.set and not args.keep_cloud:
                 per_kernel = tr.get(f"{args.config}_{main_mode}", {})
-                roofline["traffic"] = per_kernel.get("k_project_hits")
+                roofline["traffic"] = per_kernel.get("k_project_q" if hb.quads else "k_project_hits")
                 if roofline["traffic"] and roofline.get("measured_copy_GBs", 0) > 0:      # measured HBM bytes of the launch over its time alone
                     roofline["traffic_frac_alone_vs_measured_copy"] = round(rate(roofline["traffic"], r["project_alone_ms"]) / roofline["measured_copy_GBs"], 4)
         except (OSError, ValueError):

@@ -13,7 +13,7 @@ import os
 import shutil
 import sys
 
-STREAM_READERS = {"k_project_hits", "k_erode_pack", "k_compact_hits"}        # 16-byte-per-lane loads
+STREAM_READERS = {"k_project_hits", "k_project_q", "k_erode_pack", "k_compact_hits"}        # 16-byte-per-lane loads
 
 
 def kname(full):
