@@ -1499,7 +1499,9 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
     // the quad layout has its own kernel (project_q.h) for frames of up to 96 masks; CM3D_PQ=0: k_project_hits reads the quads
     static int pq_on = -1;
     if (pq_on < 0) { const char *e = getenv("CM3D_PQ"); pq_on = e ? atoi(e) : 1; }
-    const bool pq = pq_on && (which == 7 || which == 8) && planes_cap <= 3;
+    // (one hit-word plane only: with 80 masks per frame -- three planes in registers, 13 entries per camera -- k_project_q<3> takes
+    //  418 us per 64 frames of the 10-sweep configuration where k_project_hits with its planes in LDS takes 344: CM3D_PQ=3 to compare)
+    const bool pq = pq_on && (which == 7 || which == 8) && planes_cap <= (pq_on >= 3 ? 3 : 1);
     if (pq) fn = one ? (keep ? (const void *)k_project_q<1, true> : (const void *)k_project_q<1, false>)
                      : (keep ? (const void *)k_project_q<3, true> : (const void *)k_project_q<3, false>);
     size_t lds = (one || pq) ? 0 : (size_t)PHK_WAVES * ((size_t)planes_cap * PH_WC * sizeof(uint32_t) + (size_t)nm_cap * sizeof(int));
