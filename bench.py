@@ -643,6 +643,15 @@ def main(argv=None):
             if args.frames == int(tr.get("frames_per_gpu", 256)) and not args.set and not args.keep_cloud:
                 per_kernel = tr.get(f"{args.config}_{main_mode}", {})
                 roofline["traffic"] = per_kernel.get("k_project_q" if hb.quads else "k_project_hits")
+                # The launch is bound by the vector pipe, not by HBM: SQ_INSTS_VALU of the launch (its own PMC pass,
+                # profiles/traffic.json) x 4 cycles -- what SQ_ACTIVE_INST_VALU charges a vector instruction of this kernel's mix, and what
+                # tools/ubench/valu_wall.hip measures for its packed / compare / min / max / DPP instructions -- over the cycles 1024 SIMDs
+                # have in the launch's time alone at the nominal 2.4 GHz (the clock under load is lower: the true share is higher)
+                pv = per_kernel.get(("k_project_q" if hb.quads else "k_project_hits") + "_insts_valu")
+                if pv:
+                    roofline["valu_pipe"] = {"vector_instructions_per_launch": int(pv), "cycles_per_instruction": 4.0,
+                                             "frac_alone_at_2.4GHz": round(pv * 4.0 / (1024 * r["project_alone_ms"] * 1e-3 * 2.4e9), 4),
+                                             "note": "share of the SIMDs' vector-pipe cycles the launch's instructions occupy while it runs alone"}
                 if roofline["traffic"] and roofline.get("measured_copy_GBs", 0) > 0:      # measured HBM bytes of the launch over its time alone
                     roofline["traffic_frac_alone_vs_measured_copy"] = round(rate(roofline["traffic"], r["project_alone_ms"]) / roofline["measured_copy_GBs"], 4)
         except (OSError, ValueError):

@@ -63,6 +63,9 @@ def main(tag):
         # second pass) summed, divided by the number of passes (= dispatches of the reduction kernel)
         passes = max(1, len(agg.get("k_medoid_reduce", [])))
         traffic["c2_rle"]["k_medoid_insts_valu"] = int(sum(sum(v) for k, v in agg.items() if k.startswith("k_medoid")) / passes)
+        for k in ("k_project_q", "k_project_hits"):          # the projection launch's own count (bench.py: roofline.valu_pipe)
+            if k in per:
+                traffic["c2_rle"][k + "_insts_valu"] = int(per[k])
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
     for label, fn in (("three batches in flight (default)", f"profiles/{tag}_c2_rle_kernel_stats.csv"),
                       ("one batch at a time", f"profiles/{tag}_c2_rle_one_batch_kernel_stats.csv")):
