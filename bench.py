@@ -574,7 +574,8 @@ def main(argv=None):
         results[mode] = dict(dt=dt, per_rank_dt=per_rank_dt, stage_ms=stage_ms, project_alone_ms=project_alone_ms, fused=fused, sum_hits=int(status[2]),
                              hit_rows=eng.hit_chunk_rows(),
                              n_points=int(status[1]), sum_pairs=int((eng.b.hit_count.to(torch.int64) ** 2).sum().item()),
-                             sum_pairs_long=int((eng.b.hit_count.to(torch.int64) ** 2)[(eng.b.hit_count > 512) & (eng.b.hit_count < 100000)].sum().item()),
+                             sum_pairs_long=int((eng.b.hit_count.to(torch.int64) ** 2)[(eng.b.hit_count > 256) & (eng.b.hit_count < 100000)].sum().item())
+                             if int(eng.b.hit_count.max().item()) > 384 else 0,      # (csrc/medoid.hip: MD_LONG_MIN in a batch with a list beyond MD_BATCH_LONG)
                              n_boxes=int((eng.b.flags == 3).sum().item()), max_hits=int(eng.b.hit_count.max().item()),
                              rect_bytes=packed_rect_bytes(eng.b.bbox.cpu().numpy(), eng.b.Wp),
                              n_gathered=None if gathered is None else int(sum(g.shape[0] for g in gathered)), spread=spread, long_rate=long_rate, unamortised=unamortised if mode == modes[0] else None)
@@ -680,10 +681,13 @@ def main(argv=None):
     # 'vector-instruction ISSUE cost': 4 cycles per wave instruction, packed float32 included, 8 for v_rsq / v_sqrt): a SIMD issues
     # 2.4e9 / 4 slots a second, 1024 SIMDs 614 G, each slot serves 64 lanes.  ALGORITHMIC slots per pair, i.e. what the
     # reference's float32 arithmetic costs in this instruction set with nothing wasted:
-    #   exact route (lists up to 512 points, csrc/medoid.hip md_rows): 5 packed operations per two pairs for the cdist expansion
-    #     (2.5), clamp_min_ (1), v_rsq (2), its cap for zeros (1), 7 packed operations per two pairs for the correctly rounded
-    #     root (3.5), the ordered sum (1)                                                                           = 11 slots
-    #   first pass of the long lists (md_approx_tile; distances on the matrix pipe): clamp (1), v_sqrt (2), sum (0.5) = 3.5 slots
+    #   exact route (lists up to 256 points, or of a batch without a list beyond 384: csrc/medoid.hip md_rows): 5 packed operations
+    #     per two pairs for the cdist expansion (2.5), clamp_min_ (1), v_rsq (2), its cap for zeros (1), 7 packed operations per two
+    #     pairs for the correctly rounded root (3.5), the ordered sum (1)                                           = 11 slots
+    #   first pass of the long lists (md_approx_tile): five v_mfma_f32_32x32x1_2b_f32 per 2048 pairs, 64 cycles each ON THE SAME PIPE --
+    #     float32 matrix instructions and vector instructions do not overlap on this chip (tools/ubench/mfma_sqrt.hip,
+    #     profiles/r04_mfma_sqrt.txt) -- (2.5), v_sqrt with the output clamp (2), the packed sum (0.5)              = 5 slots
+    #     (r03 priced 3.5: it took the matrix pipe for free and charged the clamp)
     # frac = slots the pairs need / slots the stage's time offers; issued_slots_per_pair (PMC SQ_INSTS_VALU of the same launch,
     # idle lanes of partly filled tiles, staging, tails and the second pass of the long lists included) says how far the
     # kernel's own instruction stream is from the algorithmic one.
@@ -691,7 +695,7 @@ def main(argv=None):
     md_ms = r["stage_ms"]["medoid"]
     insts = per_kernel.get("k_medoid_insts_valu")
     pairs_long = r.get("sum_pairs_long", 0)
-    alg_slots = 11.0 * (r["sum_pairs"] - pairs_long) + 3.5 * pairs_long
+    alg_slots = 11.0 * (r["sum_pairs"] - pairs_long) + 5.0 * pairs_long
     offered = VALU_ISSUE_SLOTS * 64.0 * md_ms * 1e-3
     kernels["medoid"] = {"kernel": "k_medoid_tiles + k_medoid_reduce + k_medoid_long", "bound": "valu", "pairs_per_launch": r["sum_pairs"],
                          "pairs_in_long_lists": pairs_long, "stage_ms_alone": round(md_ms, 4),

@@ -28,10 +28,23 @@
 #endif
 
 #ifndef MD_LONG_MIN
-#define MD_LONG_MIN 512                  // lists longer than this (> 8 tiles) take the two-pass route (k_medoid_long)
+// Lists longer than this take the two-pass route (matrix-pipe first pass, k_medoid_long) -- in a batch that holds a list of more than
+// MD_BATCH_LONG points; a batch without one runs the light instantiation of the tile kernel and nothing else.  r04 (first pass a sixth
+// cheaper, second pass one wave per list): 512 / 384 / 256 / 128 give C4 790 / 826 / 847 / 843 k frames/s and C1 566 / 571 / 576 / 580 k;
+// the headline shape (longest list 358 points) is untouched by anything >= 384 as a batch limit, while a batch limit of 256 costs its
+// medoid stage 10 us alone (the heavy instantiation and the second pass for a handful of lists).
+#define MD_LONG_MIN 256
+#endif
+#ifndef MD_BATCH_LONG
+#define MD_BATCH_LONG 384
 #endif
 #define MD_LONG_MAX 100000               // ... and shorter than this (the error bound of the first pass is derived for M < 10^5)
 static __device__ __forceinline__ bool md_two_pass(int M) { return M > MD_LONG_MIN && M < MD_LONG_MAX; }
+// The work list is ordered by class, most tiles first, and classes up to MD_UNI tiles hold exactly one tile count: its FIRST descriptor
+// belongs to a list of more than MD_BATCH_LONG points if any list of the batch is that long.
+static_assert(MD_BATCH_LONG >= MD_LONG_MIN && MD_BATCH_LONG <= CM3D_MEDOID_TILE * MD_UNI && MD_BATCH_LONG % CM3D_MEDOID_TILE == 0,
+              "the batch limit is a boundary between two of the one-count classes");
+static __device__ __forceinline__ bool md_batch_long(const TileDesc *desc, int ntiles) { return ntiles > 0 && __builtin_amdgcn_readfirstlane(desc[0].M) > MD_BATCH_LONG; }
 
 #ifndef MD_APPROX_MFMA
 // First pass over long lists on the matrix pipe (md_approx_tile); 0: on the vector pipe (md_rows<false, true>).  The error bound
@@ -46,6 +59,7 @@ static __device__ __forceinline__ bool md_two_pass(int M) { return M > MD_LONG_M
 #endif
 typedef float f2 __attribute__((ext_vector_type(2)));      // two rows side by side: v_pk_{add,mul,fma}_f32
 typedef float f16v __attribute__((ext_vector_type(16)));   // accumulator of v_mfma_f32_32x32x2_f32
+typedef float f32v __attribute__((ext_vector_type(32)));   // ... of v_mfma_f32_32x32x1_2b_f32 (two 32x32 blocks)
 typedef int i2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 #define PK_FMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
@@ -338,9 +352,10 @@ static __device__ __forceinline__ float md_vsqrt(float x) { return __builtin_amd
 // in every kernel of this library) -- clamp_min_(0) and the root in ONE instruction for values known to be <= 1
 static __device__ __forceinline__ float md_vsqrt_clamp01(float x)
 {
-    float r;
-    asm("v_sqrt_f32_e64 %0, %1 clamp" : "=v"(r) : "v"(x));
-    return r;
+    // (the compiler folds the median into the root's output modifier -- v_sqrt_f32_e64 ... clamp --; written as inline assembly the
+    // instruction was invisible to its hazard recogniser, which is what places the wait states between a matrix instruction and the
+    // first vector instruction that reads its result)
+    return __builtin_amdgcn_fmed3f(__builtin_amdgcn_sqrtf(x), 0.0f, 1.0f);
 }
 // Scaled form of the first pass.  Coordinates times s = 2^-16 scale every product, every sum and every rounding of the chain by
 // exactly s^2 = 2^-32 and its root by exactly s (powers of four in, powers of two out: no rounding changes as long as nothing
@@ -368,31 +383,64 @@ static __device__ __forceinline__ bool mda_point_ok(float x, float y, float z, f
     return n == 0.0f ? (x == 0.0f && y == 0.0f && z == 0.0f) : (n >= MDA_N_MIN && n < MDA_N_MAX);
 }
 
+// One step of the first pass: 32 staged rows (r0 ..) against the wave's 64 columns.  v_mfma_f32_32x32x1_2b_f32 takes ONE k per
+// instruction and computes two 32x32 blocks -- block lane / 32 pairs the rows (A: row lane % 32, the same in both halves) with the
+// columns of that half (B: this lane's column) --, so the five terms of the expansion are five instructions for 2048 pairs: the
+// 32x32x2 shape needs six (its sixth k slot multiplies 0 by 0).  Float32 matrix instructions and vector instructions do NOT overlap
+// on this chip -- tools/ubench/mfma_sqrt.hip: 211 (169 in this shape) + 167 cycles per 1024 pairs alone, 377 (344) together,
+// whatever the number of waves and however the two are interleaved --, so every instruction saved on either side counts.
+// Accumulator registers 0-15 = block 0 (column lane % 32), 16-31 = block 1 (column 32 + lane % 32), rows 8 (q / 4) + 4 (lane / 32) + q % 4.
+template <bool SCALED>
+static __device__ __forceinline__ f2 md_approx_step(const float *s_rows, int r0, float a5, float bx, float by, float bz, float bn, f2 s)
+{
+    const int lane = cm3d_lane();
+    const float4 a = *reinterpret_cast<const float4 *>(s_rows + 4 * (r0 + (lane & 31)));       // (-2x, -2y, -2z, n) of row r0 + lane % 32
+    f32v c;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) c[q] = 0.0f;
+    c = __builtin_amdgcn_mfma_f32_32x32x1f32(a.x, bx, c, 0, 0, 0);            // (-2 x_i) x_j
+    c = __builtin_amdgcn_mfma_f32_32x32x1f32(a.y, by, c, 0, 0, 0);            // fma(-2 y_i, y_j, .)
+    c = __builtin_amdgcn_mfma_f32_32x32x1f32(a.z, bz, c, 0, 0, 0);            // fma(-2 z_i, z_j, .)
+    c = __builtin_amdgcn_mfma_f32_32x32x1f32(a.w, 1.0f, c, 0, 0, 0);          // fma(n_i, 1, .)
+    c = __builtin_amdgcn_mfma_f32_32x32x1f32(a5, bn, c, 0, 0, 0);             // fma(1, n_j, .); a5 = 0 for a row past the end (all its terms are 0)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (SCALED)     // clamp_min_(0) and the root in one (md_vsqrt_clamp01), this lane's rows of its two columns
+            s += (f2){md_vsqrt_clamp01(c[q]), md_vsqrt_clamp01(c[16 + q])};
+        else            // clamp_min_(0) as a signed-integer maximum on the bits (negative values and -0 -> +0), the root brought to the sums' scale
+            s += (f2){md_vsqrt(__int_as_float(max(__float_as_int(c[q]), 0))), md_vsqrt(__int_as_float(max(__float_as_int(c[16 + q]), 0)))} * MDA_S;
+    }
+    return s;
+}
+
 template <typename Fetch>
 static __device__ __forceinline__ void md_approx_tile(Fetch fetch, float *s_rows, int off, int M, int jt, float *__restrict__ approx_out)
 {
     const int lane = cm3d_lane();
-    const bool lo = lane < 32;
-    // column operands of the two 32-column groups, SCALED: lanes 0-31 carry (x s, z s, n s^2), lanes 32-63 (y s, 1, 0)
-    float b1[2], b2[2], b3[2];
-    bool cols_ok = true;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int j = jt * 64 + g * 32 + (lane & 31);
-        float qx = 0.f, qy = 0.f, qz = 0.f;
-        if (j < M) { const float4 q = fetch(off + j); qx = q.x; qy = q.y; qz = q.z; }
-        const float qn = (qx * qx + qy * qy) + qz * qz;
-        cols_ok &= mda_point_ok(qx, qy, qz, qn);
-        b1[g] = (lo ? qx : qy) * MDA_S; b2[g] = lo ? qz * MDA_S : 1.0f; b3[g] = lo ? qn * MDA_S2 : 0.0f;
+    // this lane's column, SCALED: (x s, y s, z s, n s^2)
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    {   // (the load is unconditional -- of the list's last point for a lane past its end: a load inside a divergent branch is waited for on the spot)
+        const int j = jt * 64 + lane;
+        const float4 q = fetch(off + min(j, M - 1));
+        if (j < M) { qx = q.x; qy = q.y; qz = q.z; }
     }
-    cols_ok = !__ballot(!cols_ok);                            // (uniform)
-    float s[2] = {0.f, 0.f};                                  // in units of s
-    for (int i0 = 0; i0 < M; i0 += MDA_STAGE) {
-        __builtin_amdgcn_wave_barrier();                      // the previous rows' readers are done
-        float4 g4[MDA_STAGE / 64];
+    // the first stage's rows: in flight under the column's arithmetic; every later stage's are fetched under the stage before
+    float4 g4[MDA_STAGE / 64];
 #pragma unroll
-        for (int c = 0; c < MDA_STAGE / 64; ++c)
-            if (i0 + c * 64 + lane < M) g4[c] = fetch(off + i0 + c * 64 + lane);
+    for (int c = 0; c < MDA_STAGE / 64; ++c) g4[c] = fetch(off + min(c * 64 + lane, M - 1));
+    const float qn = (qx * qx + qy * qy) + qz * qz;
+    const bool cols_ok = !__ballot(!mda_point_ok(qx, qy, qz, qn));           // (uniform)
+    const float bx = qx * MDA_S, by = qy * MDA_S, bz = qz * MDA_S, bn = qn * MDA_S2;
+    f2 s = {0.f, 0.f};                                        // in units of s: columns lane % 32 and 32 + lane % 32, this half's rows
+    bool scaled = false;                                      // (uniform) the staged rows are in the scaled form
+#ifdef CM3D_DIAG
+    const int ab = __builtin_amdgcn_readfirstlane(g_md_diag);  // ablation (results wrong by construction; tools/md_long_ablate.py): 128 rows staged once per tile
+#endif
+    for (int i0 = 0; i0 < M; i0 += MDA_STAGE) {
+#ifdef CM3D_DIAG
+        if (!((ab & 128) && i0 > 0)) {
+#endif
+        __builtin_amdgcn_wave_barrier();                      // the previous rows' readers are done
         float4 rr[MDA_STAGE / 64];
         bool rows_ok = true;
 #pragma unroll
@@ -400,62 +448,45 @@ static __device__ __forceinline__ void md_approx_tile(Fetch fetch, float *s_rows
             rr[c] = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past the end: all zeros, and their k = 4 factor is 0 too
             if (i0 + c * 64 + lane < M) {
                 const float4 p = g4[c];
-                rr[c] = make_float4(-2.0f * p.x, -2.0f * p.z, -2.0f * p.y, (p.x * p.x + p.y * p.y) + p.z * p.z);
+                rr[c] = make_float4(-2.0f * p.x, -2.0f * p.y, -2.0f * p.z, (p.x * p.x + p.y * p.y) + p.z * p.z);
                 rows_ok &= mda_point_ok(p.x, p.y, p.z, rr[c].w);
             }
         }
-        const bool scaled = MD_SCALED_ROUTES && cols_ok && !__ballot(!rows_ok);   // (uniform) this chunk of rows in the scaled form
+#pragma unroll
+        for (int c = 0; c < MDA_STAGE / 64; ++c) g4[c] = fetch(off + min(i0 + MDA_STAGE + c * 64 + lane, M - 1));      // the next stage's (past the end: the last row, unused)
+        const bool scaled_now = MD_SCALED_ROUTES && cols_ok && !__ballot(!rows_ok);   // (uniform) this chunk of rows in the scaled form
 #pragma unroll
         for (int c = 0; c < MDA_STAGE / 64; ++c) {
             float4 r = rr[c];
-            if (scaled) r = make_float4(r.x * MDA_S, r.y * MDA_S, r.z * MDA_S, r.w * MDA_S2);
+            if (scaled_now) r = make_float4(r.x * MDA_S, r.y * MDA_S, r.z * MDA_S, r.w * MDA_S2);
             *reinterpret_cast<float4 *>(s_rows + 4 * (c * 64 + lane)) = r;
         }
+        scaled = scaled_now;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int cnt = min(MDA_STAGE, M - i0);
+#ifdef CM3D_DIAG
+        }
+#endif
+        const int cnt = min(MDA_STAGE, M - i0), full = cnt & ~31;
+        const float a5 = full + (lane & 31) < cnt ? 1.0f : 0.0f;            // the last, partial step's rows
         if (scaled) {
-            for (int r0 = 0; r0 < cnt; r0 += 32) {
-                const int row = r0 + (lane & 31);
-                const float2 a = *reinterpret_cast<const float2 *>(s_rows + 4 * row + (lo ? 0 : 2));
-                const float a3 = (lo && row < cnt) ? 1.0f : 0.0f;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[g], c, 0, 0, 0);        // k = 0, 1
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b2[g], c, 0, 0, 0);        // k = 2, 3
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3[g], c, 0, 0, 0);         // k = 4, (5: 0 * 0)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) s[g] += md_vsqrt_clamp01(c[q]);             // clamp_min_(0) and root in one, this lane's rows
-                }
-            }
+            for (int r0 = 0; r0 < full; r0 += 32) s = md_approx_step<true>(s_rows, r0, 1.0f, bx, by, bz, bn, s);
+            if (cnt & 31) s = md_approx_step<true>(s_rows, full, a5, bx, by, bz, bn, s);
         } else {
             // the unscaled form (rare): operands back to their own scale (exact unless a coordinate underflowed when it was scaled: such
-            // a column has a norm below MDA_N_MIN), clamp_min_(0) as a signed-integer maximum on the bits (negative values and -0 -> +0;
-            // fmaxf() on a matrix-pipe result costs two instructions, it is canonicalised first), the root brought to the sums' scale
-            for (int r0 = 0; r0 < cnt; r0 += 32) {
-                const int row = r0 + (lane & 31);
-                const float2 a = *reinterpret_cast<const float2 *>(s_rows + 4 * row + (lo ? 0 : 2));
-                const float a3 = (lo && row < cnt) ? 1.0f : 0.0f;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const float u1 = b1[g] * 65536.0f, u2 = lo ? b2[g] * 65536.0f : 1.0f, u3 = b3[g] * 4294967296.0f;
-                    f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, u1, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, u2, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, u3, c, 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) s[g] += md_vsqrt(__int_as_float(max(__float_as_int(c[q]), 0))) * MDA_S;
-                }
-            }
+            // a column has a norm below MDA_N_MIN)
+            const float ux = bx * 65536.0f, uy = by * 65536.0f, uz = bz * 65536.0f, un = bn * 4294967296.0f;
+            for (int r0 = 0; r0 < full; r0 += 32) s = md_approx_step<false>(s_rows, r0, 1.0f, ux, uy, uz, un, s);
+            if (cnt & 31) s = md_approx_step<false>(s_rows, full, a5, ux, uy, uz, un, s);
         }
     }
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const float tot = (s[g] + __shfl_xor(s[g], 32, 64)) * 65536.0f;     // the two halves of the rows of column lane & 31; back to metres
-        const int j = jt * 64 + g * 32 + lane;
-        if (lo && j < M) approx_out[off + j] = tot;
+    // the two halves of the rows of a column meet; back to metres
+    const float t0 = (s.x + __shfl_xor(s.x, 32, 64)) * 65536.0f, t1 = (s.y + __shfl_xor(s.y, 32, 64)) * 65536.0f;
+    if (lane < 32) {
+        const int j = jt * 64 + lane;
+        if (j < M) approx_out[off + j] = t0;
+        if (j + 32 < M) approx_out[off + j + 32] = t1;
     }
 }
 
@@ -467,7 +498,7 @@ static __device__ __forceinline__ void md_approx_tile(Fetch fetch, float *s_rows
 // ordered longest lists first, so its first descriptor says whether the batch can hold a long list at all (more than MD_UNI
 // tiles: conservative inside the class that holds MD_LONG_MIN); the instantiation that is not needed leaves after that one load.
 // On the headline shape (no list beyond 358 points) the light one runs; three batches in flight: 0.174 -> 0.166 ms per pass.
-template <bool WITH_LONG>
+template <bool WITH_LONG, bool INDEXED>
 __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__restrict__ points,
                                                               const int32_t *__restrict__ pt_off,
                                                               const int32_t *__restrict__ mask_frame, int n_masks,
@@ -483,7 +514,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
         long_list[0] = 0;                                                         // k_medoid_reduce counts the long masks into it
         // what the caller may use as a hint for the NEXT batch (cm3d_medoid2): does this one hold a list the two-pass route
         // would take?  The work list is ordered longest lists first: its first entry says (conservatively, inside its class).
-        if (feedback) feedback[0] = (min(tile_off[n_masks], tile_cap) > 0 && desc[0].M > CM3D_MEDOID_TILE * MD_UNI) ? 1 : 0;
+        if (feedback) feedback[0] = md_batch_long(desc, min(tile_off[n_masks], tile_cap)) ? 1 : 0;
     }
     const int wave = threadIdx.x >> 6, lane = cm3d_lane();
 #ifdef CM3D_DIAG
@@ -495,11 +526,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
     float4 *s_row = s_row_all[wave];
     const int ntiles = min(tile_off[n_masks], tile_cap);
     if (ntiles <= 0) return;
-    {
-        static_assert(MD_LONG_MIN >= CM3D_MEDOID_TILE * MD_UNI, "a long list must lie above the one-class-per-tile-count classes");
-        const bool maybe_long = approx_opt != nullptr && __builtin_amdgcn_readfirstlane(desc[0].M) > CM3D_MEDOID_TILE * MD_UNI;
-        if (maybe_long != WITH_LONG) return;                                  // the other instantiation's batch
-    }
+    if ((approx_opt != nullptr && md_batch_long(desc, ntiles)) != WITH_LONG) return;       // the other instantiation's batch
     for (int t = blockIdx.x * MD_WAVES + wave; t < ntiles; t += gridDim.x * MD_WAVES) {
         const TileDesc d = desc[t];
         // the descriptor is the same in every lane: keep it in scalar registers so that the loops below are
@@ -507,21 +534,29 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
         const int off = __builtin_amdgcn_readfirstlane(d.off), M = __builtin_amdgcn_readfirstlane(d.M);
         const int jt = __builtin_amdgcn_readfirstlane(d.jt);
         // hit_row == NULL: `points` is the per-hit coordinate array of cm3d_compact_hits, laid out like the index lists
-        const float4 *P = hit_row ? points + pt_off[mask_frame[__builtin_amdgcn_readfirstlane(d.m)]] : points;
-        auto fetch = [&](int q) { return hit_row ? P[hit_row[q]] : P[q]; };
+        // (INDEXED is a template parameter and every load below unconditional -- a lane past the list's end loads its last point --: a
+        // load behind a run-time `hit_row ?` or inside a divergent branch is waited for on the spot, and the four gathers of a 256-row
+        // stage then cost four memory round trips instead of one)
+        const float4 *P = INDEXED ? points + pt_off[mask_frame[__builtin_amdgcn_readfirstlane(d.m)]] : points;
+        auto fetch = [&](int q) { return INDEXED ? P[hit_row[q]] : P[q]; };
         const int j = jt * 64 + lane;
         const bool act = j < M;
         float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
-        if (act) {
-            const float4 q = fetch(off + j);
-            qx = q.x; qy = q.y; qz = q.z;
-            qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
+        {
+            const float4 q = fetch(off + min(j, M - 1));
+            if (act) {
+                qx = q.x; qy = q.y; qz = q.z;
+                qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
+            }
         }
         float s = 0.f;
         const bool col_safe = !__ballot(act && !md_col_safe(qn));
         const bool col_scal = !__ballot(act && !mda_point_ok(qx, qy, qz, qn));           // the column side of the scaled form (md_rows<.., SCALED>)
         const bool direct = M <= 25;
-        const bool approx = approx_opt != nullptr && md_two_pass(M);      // long list: approximate sums (k_medoid_approx), k_medoid_long later
+        const bool approx = WITH_LONG && md_two_pass(M);                  // long list (of a batch with the first pass: this instantiation): approximate sums, k_medoid_long later
+#ifdef CM3D_DIAG
+        if (WITH_LONG && ((g_md_diag & 512) ? !approx : ((g_md_diag & 1024) ? approx : false))) continue;      // 512: first-pass tiles only, 1024: exact tiles only
+#endif
         if (WITH_LONG && approx && MD_APPROX_MFMA) {
             md_approx_tile(fetch, reinterpret_cast<float *>(s_row), off, M, jt, approx_opt);
             continue;
@@ -535,7 +570,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
             bool rows_safe = true, rows_scal = true;
 #pragma unroll
             for (int c = 0; c < MD_STAGE / 64; ++c)
-                if (i0 + c * 64 + lane < M) g[c] = fetch(off + i0 + c * 64 + lane);
+                g[c] = fetch(off + min(i0 + c * 64 + lane, M - 1));
 #pragma unroll
             for (int c = 0; c < MD_STAGE / 64; ++c) {
                 if (i0 + c * 64 + lane < M) {
@@ -617,14 +652,15 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
                                                        const int32_t *__restrict__ tile_off,
                                                        const int32_t *__restrict__ hit_row, int idx_cap,
                                                        const TileBest *__restrict__ tile_best, int tile_cap, int two_pass,
-                                                       int32_t *__restrict__ long_list,
+                                                       const TileDesc *__restrict__ desc, int32_t *__restrict__ long_list,
                                                        int32_t *__restrict__ medoid_pos, float *__restrict__ centroid)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     // k_medoid_long's masks go on its list (long_list[0] = how many, zeroed by the tile kernel; then the mask numbers, in whatever
     // order the atomics make it): its workgroups then share the long masks evenly -- walking ALL masks in strides of the grid gave
     // a workgroup as many long masks as chance would have it (C1: 1.1 on average, 5 or 6 at most, and the launch lasts as long as those)
-    const bool is_long = two_pass && m < n_masks && md_two_pass(hit_off[m + 1] - hit_off[m]);
+    // (the tile kernel's own rule: lists of more than MD_LONG_MIN points, in a batch whose longest has more than MD_BATCH_LONG)
+    const bool is_long = two_pass && md_batch_long(desc, min(tile_off[n_masks], tile_cap)) && m < n_masks && md_two_pass(hit_off[m + 1] - hit_off[m]);
     {
         const uint64_t lm = __ballot(is_long);
         if (lm) {
@@ -662,198 +698,232 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
 // only be the (first) minimum of the exact sums if A_j - E_j <= min_k (A_k + E_k); those few columns -- the points within
 // centimetres of the medoid -- get their exact float32 sums here.  A non-finite A_j makes every column a candidate; lists
 // of 10^5 points and more stay on the one-pass route.
-// One workgroup of 8 waves per long mask.  A handful of candidates (the rule) are settled ROW-parallel, one candidate per
-// wave at a time: the 64 lanes take 64 consecutive rows, compute their distances to the candidate together, and the sum
-// runs over them in ascending row order (v_readlane + v_add, the only serial part) -- the very additions, in the very
-// order, of the column-per-lane loop, at a fraction of its time when few of the 64 columns are wanted.  More than
-// MDL_MAXC candidates (lists full of duplicated points): wave 0 takes them 64 columns at a time, as k_medoid_tiles does.
-#define MDL_WAVES 4                      // (8 waves and 148 VGPRs meant ONE workgroup per CU; four waves let three masks share a CU: the serial sums are latency)
-#define MDL_MAXC 64
+// One WAVE per long mask (r04; a workgroup of four waves per mask before, one candidate per wave at a time, each sum a chain of
+// v_readlane + v_add over all rows: 52 cycles per row and candidate).  The exact float32 sum of a column is M dependent additions in
+// ascending row order whatever the machine; what can be shared is everything around them.  Up to MDL_GC candidates are settled in ONE
+// walk over the rows: the 64 lanes take 64 consecutive rows and compute their exact distances to every candidate (two candidates per
+// packed instruction), the distances are transposed through the wave's LDS slice (row c of `t` = candidate c's 64 terms), and lane c
+// adds candidate c's terms in row order -- the very additions, in the very order, of the column-per-lane loop, for all candidates at
+// once.  Rows past the end contribute +0 (s + 0 = s for the non-negative or NaN sums that occur).  More than MDL_MAXC candidates
+// (lists full of duplicated points): 64 columns at a time, as k_medoid_tiles does.
+#define MDL_WAVES 4                      // waves per workgroup, each with long masks of its own (no workgroup barrier anywhere)
+#define MDL_MAXC 64                      // candidates the row-parallel route takes
+#define MDL_GC 16                        // ... and settles per walk over the rows
+#define MDL_AU 8                         // first-pass sums loaded per lane and round trip
+#define MDL_TS 68                        // floats per candidate in the transposition buffer: 16-byte aligned rows, lanes c and c + 8 share banks
 
-// exact float32 distance of this lane's row to the candidate (qx, qy, qz, qn): md_pair2<false> + the correctly rounded root
-static __device__ __forceinline__ float md_exact_dist(float4 p, float qx, float qy, float qz, float qn)
+struct MdlLds {                          // one wave's slice
+    union {
+        float t[MDL_GC][MDL_TS];         // row-parallel route: t[c][r] = distance of row r of the current 64 to candidate c
+        float4 row[MD_STAGE];            // column loop: staged rows
+    } u;
+    float4 q[MDL_GC];                    // the candidates' points (x, y, z, squared norm)
+    int list[MDL_MAXC];                  // the candidates' columns, ascending
+    int cand[64];                        // column loop: candidates waiting
+};
+static_assert(sizeof(float) * MDL_GC * MDL_TS >= sizeof(float4) * MD_STAGE, "the staged rows of the column loop live in the transposition buffer");
+
+// exact float32 distances of this lane's row (m2 = -2 p, n = |p|^2) to two candidates: md_pair2<false>'s chain + the correctly rounded root
+static __device__ __forceinline__ f2 md_exact_dist2(float m2x, float m2y, float m2z, float n, float4 qa, float4 qb)
 {
-    const float n = (p.x * p.x + p.y * p.y) + p.z * p.z;
-    float acc = (-2.0f * p.x) * qx;
-    acc = fmaf(-2.0f * p.y, qy, acc);
-    acc = fmaf(-2.0f * p.z, qz, acc);
-    acc = acc + n;
-    acc = acc + qn;
-    acc = fmaxf(acc, 0.0f);
-    if (__ballot(!md_sqrt_okz(acc))) return sqrtf(acc);                      // both forms are the correctly rounded root
-    return md_sqrt_core2z((f2){acc, acc}).x;
+    f2 acc = (f2){m2x, m2x} * (f2){qa.x, qb.x};
+    acc = PK_FMA(((f2){m2y, m2y}), ((f2){qa.y, qb.y}), acc);
+    acc = PK_FMA(((f2){m2z, m2z}), ((f2){qa.z, qb.z}), acc);
+    acc = acc + (f2){n, n};
+    acc = acc + (f2){qa.w, qb.w};
+    acc = (f2){fmaxf(acc.x, 0.0f), fmaxf(acc.y, 0.0f)};
+    if (__ballot(!md_sqrt_okz(acc.x) || !md_sqrt_okz(acc.y))) return (f2){sqrtf(acc.x), sqrtf(acc.y)};       // both forms are the correctly rounded root
+    return md_sqrt_core2z(acc);
 }
 
-template <typename Fetch>
-static __device__ __forceinline__ float md_exact_colsum_rows(Fetch fetch, int off, int M, int cj)
-{
-    const int lane = cm3d_lane();
-    const float4 q = fetch(off + cj);                           // uniform
-    const float qx = q.x, qy = q.y, qz = q.z, qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
-    float s = 0.0f;
-    float4 p = lane < M ? fetch(off + lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i0 = 0; i0 < M; i0 += 64) {
-        const float4 pn = i0 + 64 + lane < M ? fetch(off + i0 + 64 + lane) : make_float4(0.f, 0.f, 0.f, 0.f);      // next rows under the chain
-        const float d = i0 + lane < M ? md_exact_dist(p, qx, qy, qz, qn) : 0.0f;
-        const int cnt = min(64, M - i0);
-        if (cnt == 64) {
-#pragma unroll
-            for (int k = 0; k < 64; ++k) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), k));
-        } else {
-            for (int k = 0; k < cnt; ++k) s = s + __shfl(d, k, 64);
-        }
-        p = pn;
-    }
-    return s;
-}
-
-__global__ __launch_bounds__(64 * MDL_WAVES, 2) void k_medoid_long(const float4 *__restrict__ points, const int32_t *__restrict__ pt_off,
+template <bool INDEXED>
+__global__ __launch_bounds__(64 * MDL_WAVES, 3) void k_medoid_long(const float4 *__restrict__ points, const int32_t *__restrict__ pt_off,
                                                                 const int32_t *__restrict__ mask_frame, int n_masks,
                                                                 const int32_t *__restrict__ hit_off, const int32_t *__restrict__ hit_row,
                                                                 int idx_cap, const float *__restrict__ approx, const int32_t *__restrict__ long_list,
                                                                 int32_t *__restrict__ medoid_pos, float *__restrict__ centroid)
 {
-    __shared__ float4 s_row[MD_STAGE];
-    __shared__ int s_cand[64];
-    __shared__ int s_list[MDL_MAXC];
-    __shared__ float s_sum[MDL_MAXC];
-    __shared__ double s_thr[MDL_WAVES];
-    __shared__ int s_n, s_all;
-    const int lane = cm3d_lane(), t = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // a workgroup takes entries blockIdx.x, + gridDim.x, ... of the list of long masks (k_medoid_reduce)
+    __shared__ MdlLds s_lds[MDL_WAVES];
+    const int lane = cm3d_lane();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    MdlLds &L = s_lds[wave];
+    // a wave takes entries blockIdx.x + wave * gridDim.x, + gridDim.x * MDL_WAVES, ... of the list of long masks (k_medoid_reduce): a short list
+    // goes to the first waves of many workgroups, i.e. to many CUs
     const int n_long = min(long_list[0], n_masks);
-    for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
-    const int m = long_list[1 + li];
-    const int off = hit_off[m], M = hit_off[m + 1] - off;
-    if (!md_two_pass(M) || off + M > idx_cap) continue;                    // the whole workgroup
-    __syncthreads();                                                       // the previous long mask's LDS state is done with
-    const float4 *P = hit_row ? points + pt_off[mask_frame[m]] : points;
-    auto fetch = [&](int q) { return hit_row ? P[hit_row[q]] : P[q]; };
-    const float *A = approx + off;
-    const double rel = 1.01 * (double)(M + 2) * 1.1920928955078125e-07, abs_e = (double)M * 2e-14;
+#ifdef CM3D_DIAG
+    if (g_md_diag & 256) return;                                           // ablation: no second pass
+#endif
+    auto wave_sync = [] {                                                  // this wave's LDS writes before its reads (and reads before the next writes)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     auto better = [](float s1, int j1, float s2, int j2) {   // is (s1,j1) ahead of (s2,j2)?  (torch.argmin order)
         const bool n1 = s1 != s1, n2 = s2 != s2;
         if (n1 != n2) return n1;
         if (!n1 && s1 != s2) return s1 < s2;
         return j1 < j2;
     };
-    if (t == 0) { s_n = 0; s_all = 0; }
-    __syncthreads();
-    // threshold = min_k (A_k + E_k); anything non-finite -> every column is a candidate
-    double thr = INFINITY;
-    bool all = false;
-    for (int j = t; j < M; j += 64 * MDL_WAVES) {
-        const double a = (double)A[j];
-        if (!(a >= 0.0 && a < 1e300)) all = true;
-        thr = fmin(thr, a + (a * rel + abs_e));
-    }
-    thr = cm3d_wave_reduce_t(thr, [](double a_, double b_) { return fmin(a_, b_); });
-    if (lane == 0) s_thr[wave] = thr;
-    if (__ballot(all) && lane == 0) atomicOr(&s_all, 1);
-    __syncthreads();
-    thr = s_thr[0];
+    for (int li = blockIdx.x + wave * gridDim.x; li < n_long; li += gridDim.x * MDL_WAVES) {
+        const int m = __builtin_amdgcn_readfirstlane(long_list[1 + li]);
+        const int off = __builtin_amdgcn_readfirstlane(hit_off[m]), M = __builtin_amdgcn_readfirstlane(hit_off[m + 1]) - off;
+        if (!md_two_pass(M) || off + M > idx_cap) continue;
+        const float4 *P = INDEXED ? points + pt_off[mask_frame[m]] : points;
+        auto fetch = [&](int q) { return INDEXED ? P[hit_row[q]] : P[q]; };                  // (loads are unconditional, of a clamped row: see k_medoid_tiles)
+        const float *A = approx + off;
+        const double rel = 1.01 * (double)(M + 2) * 1.1920928955078125e-07, abs_e = (double)M * 2e-14;
+        // threshold = min_k (A_k + E_k); anything non-finite -> every column is a candidate
+        // (eight loads in flight per round, unconditional -- a lane past the end re-reads the last sum --: one load per round trip made
+        // the two walks over A longer than the walk over the rows)
+        double thr = INFINITY;
+        bool all = false;
+        for (int j0 = 0; j0 < M; j0 += 64 * MDL_AU) {
+            float av[MDL_AU];
 #pragma unroll
-    for (int w = 1; w < MDL_WAVES; ++w) thr = fmin(thr, s_thr[w]);
-    all = s_all != 0;
-    // the candidates (in no particular order: the final choice is a total order on (sum, index))
-    for (int j = t; j < M; j += 64 * MDL_WAVES) {
-        const double a = (double)A[j];
-        if (all || (a - (a * rel + abs_e) <= thr)) {
-            const int pos = atomicAdd(&s_n, 1);
-            if (pos < MDL_MAXC) s_list[pos] = j;
-        }
-    }
-    __syncthreads();
-    const int C = s_n;
-    float best_s = INFINITY;
-    int best_j = 0x7FFFFFFF;
-    if (C <= MDL_MAXC) {
-        for (int c = wave; c < C; c += MDL_WAVES) {
-            const float sc = md_exact_colsum_rows(fetch, off, M, s_list[c]);
-            if (lane == 0) s_sum[c] = sc;
-        }
-        __syncthreads();
-        if (wave != 0) continue;
-        float bs = lane < C ? s_sum[lane] : INFINITY;
-        int bj = lane < C ? s_list[lane] : 0x7FFFFFFF;
-        {   // (DPP moves instead of ds_bpermute round trips: common.h)
-            const Cm3dValIdx red = cm3d_wave_reduce_t(Cm3dValIdx{bs, bj}, [&](Cm3dValIdx a_, Cm3dValIdx b_) { return better(b_.s, b_.j, a_.s, a_.j) ? b_ : a_; });
-            bs = red.s; bj = red.j;
-        }
-        best_s = bs; best_j = bj;
-    } else {
-        if (wave != 0) continue;
-        // many candidates: 64 columns at a time, column per lane (the row loop of k_medoid_tiles)
-        int nc = 0;                                   // candidates waiting in s_cand (uniform)
-        for (int j0 = 0; j0 < M + 64; j0 += 64) {     // one extra round flushes the tail
-            const int j = j0 + lane;
-            bool cand = false;
-            if (j < M) {
-                const double a = (double)A[j];
-                cand = all || (a - (a * rel + abs_e) <= thr);
+            for (int k = 0; k < MDL_AU; ++k) av[k] = A[min(j0 + k * 64 + lane, M - 1)];
+#pragma unroll
+            for (int k = 0; k < MDL_AU; ++k) {
+                const double a = (double)av[k];
+                if (!(a >= 0.0 && a < 1e300)) all = true;
+                thr = fmin(thr, a + (a * rel + abs_e));
             }
-            const uint64_t cm = __ballot(cand);
-            const int add = (int)__popcll(cm);
-            const bool last = j0 >= M;
-            if (nc + add > 64 || (last && nc > 0)) {
-                // exact sums of the waiting candidates: lane l owns column s_cand[l]
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const bool act = lane < nc;
-                const int cj = act ? s_cand[lane] : 0;
-                float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
-                if (act) {
-                    const float4 q = fetch(off + cj);
-                    qx = q.x; qy = q.y; qz = q.z;
-                    qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
+        }
+        thr = cm3d_wave_reduce_t(thr, [](double a_, double b_) { return fmin(a_, b_); });
+        all = __ballot(all) != 0;
+        // the candidates, in ascending order (the final choice is a total order on (sum, index): any order would do)
+        int C = 0;
+        wave_sync();                                                       // the mask before is done with `list`
+        for (int j0 = 0; j0 < M; j0 += 64 * MDL_AU) {
+            float av[MDL_AU];
+#pragma unroll
+            for (int k = 0; k < MDL_AU; ++k) av[k] = A[min(j0 + k * 64 + lane, M - 1)];
+#pragma unroll
+            for (int k = 0; k < MDL_AU; ++k) {
+                const int j = j0 + k * 64 + lane;
+                const double a = (double)av[k];
+                const bool cand = j < M && (all || (a - (a * rel + abs_e) <= thr));
+                const uint64_t cm = __ballot(cand);
+                if (cand) {
+                    const int pos = C + cm3d_mbcnt(cm);
+                    if (pos < MDL_MAXC) L.list[pos] = j;
                 }
-                float s = 0.f;
-                for (int i0 = 0; i0 < M; i0 += MD_STAGE) {
-                    __builtin_amdgcn_wave_barrier();
-                    float4 g[MD_STAGE / 64];
+                C += (int)__popcll(cm);
+            }
+        }
+        float best_s = INFINITY;
+        int best_j = 0x7FFFFFFF;
+        if (C <= MDL_MAXC) {
+            for (int g0 = 0; g0 < C; g0 += MDL_GC) {
+                const int Cg = min(MDL_GC, C - g0);
+                wave_sync();
+                if (lane < MDL_GC) {                                       // (a group's unused slots: the origin -- finite terms nobody adds up)
+                    float4 q = fetch(off + L.list[g0 + min(lane, Cg - 1)]);
+                    q.w = (q.x * q.x + q.y * q.y) + q.z * q.z;
+                    if (lane >= Cg) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                    L.q[lane] = q;
+                }
+                wave_sync();
+                float s = 0.0f;                                            // lane c < Cg: the sum of candidate g0 + c
+                float4 p = fetch(off + min(lane, M - 1)), p1 = fetch(off + min(64 + lane, M - 1));
+                for (int i0 = 0; i0 < M; i0 += 64) {
+                    const float4 pn = fetch(off + min(i0 + 128 + lane, M - 1));      // two rounds of rows ahead of the chains (rows past the end: the last row, never used)
+                    const bool valid = i0 + lane < M;
+                    const float n = (p.x * p.x + p.y * p.y) + p.z * p.z;
+                    const float m2x = -2.0f * p.x, m2y = -2.0f * p.y, m2z = -2.0f * p.z;
+                    for (int c = 0; c < Cg; c += 2) {                      // (uniform; c + 1 <= MDL_GC - 1)
+                        const f2 d = md_exact_dist2(m2x, m2y, m2z, n, L.q[c], L.q[c + 1]);
+                        L.u.t[c][lane] = valid ? d.x : 0.0f;
+                        L.u.t[c + 1][lane] = valid ? d.y : 0.0f;
+                    }
+                    wave_sync();
+                    if (lane < MDL_GC) {
+                        const float4 *tr = reinterpret_cast<const float4 *>(&L.u.t[lane][0]);
 #pragma unroll
-                    for (int c = 0; c < MD_STAGE / 64; ++c)
-                        if (i0 + c * 64 + lane < M) g[c] = fetch(off + i0 + c * 64 + lane);
-#pragma unroll
-                    for (int c = 0; c < MD_STAGE / 64; ++c) {
-                        if (i0 + c * 64 + lane < M) {
-                            float4 r = g[c];
-                            r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
-                            r.x = -2.0f * r.x; r.y = -2.0f * r.y; r.z = -2.0f * r.z;
-                            md_stage(s_row, c * 64 + lane, r);
+                        for (int k = 0; k < 16; ++k) {
+                            const float4 v = tr[k];
+                            s = s + v.x; s = s + v.y; s = s + v.z; s = s + v.w;
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    s = md_rows<false>(s_row, min(MD_STAGE, M - i0), qx, qy, qz, qn, s);
+                    wave_sync();
+                    p = p1; p1 = pn;
                 }
-                float bs = act ? s : INFINITY;
-                int bj = act ? cj : 0x7FFFFFFF;
-                {   // (DPP moves instead of ds_bpermute round trips: common.h)
-                    const Cm3dValIdx red = cm3d_wave_reduce_t(Cm3dValIdx{bs, bj}, [&](Cm3dValIdx a_, Cm3dValIdx b_) { return better(b_.s, b_.j, a_.s, a_.j) ? b_ : a_; });
-                    bs = red.s; bj = red.j;
-                }
-                if (bj != 0x7FFFFFFF && (best_j == 0x7FFFFFFF || better(bs, bj, best_s, best_j))) { best_s = bs; best_j = bj; }
-                nc = 0;
-                __builtin_amdgcn_wave_barrier();
+                const float bs = lane < Cg ? s : INFINITY;
+                const int bj = lane < Cg ? L.list[g0 + lane] : 0x7FFFFFFF;
+                // (DPP moves instead of ds_bpermute round trips: common.h)
+                const Cm3dValIdx red = cm3d_wave_reduce_t(Cm3dValIdx{bs, bj}, [&](Cm3dValIdx a_, Cm3dValIdx b_) { return better(b_.s, b_.j, a_.s, a_.j) ? b_ : a_; });
+                if (red.j != 0x7FFFFFFF && (best_j == 0x7FFFFFFF || better(red.s, red.j, best_s, best_j))) { best_s = red.s; best_j = red.j; }
             }
-            if (cand) s_cand[nc + cm3d_mbcnt(cm)] = j;
-            nc += add;
+        } else {
+            // many candidates: 64 columns at a time, column per lane (the row loop of k_medoid_tiles)
+            float4 *s_row = L.u.row;
+            int *s_cand = L.cand;
+            int nc = 0;                                   // candidates waiting in s_cand (uniform)
+            for (int j0 = 0; j0 < M + 64; j0 += 64) {     // one extra round flushes the tail
+                const int j = j0 + lane;
+                bool cand = false;
+                if (j < M) {
+                    const double a = (double)A[j];
+                    cand = all || (a - (a * rel + abs_e) <= thr);
+                }
+                const uint64_t cm = __ballot(cand);
+                const int add = (int)__popcll(cm);
+                const bool last = j0 >= M;
+                if (nc + add > 64 || (last && nc > 0)) {
+                    // exact sums of the waiting candidates: lane l owns column s_cand[l]
+                    wave_sync();
+                    const bool act = lane < nc;
+                    const int cj = act ? s_cand[lane] : 0;
+                    float qx = 0.f, qy = 0.f, qz = 0.f, qn = 0.f;
+                    {
+                        const float4 q = fetch(off + cj);
+                        if (act) {
+                            qx = q.x; qy = q.y; qz = q.z;
+                            qn = (q.x * q.x + q.y * q.y) + q.z * q.z;
+                        }
+                    }
+                    float s = 0.f;
+                    for (int i0 = 0; i0 < M; i0 += MD_STAGE) {
+                        __builtin_amdgcn_wave_barrier();
+                        float4 g[MD_STAGE / 64];
+#pragma unroll
+                        for (int c = 0; c < MD_STAGE / 64; ++c)
+                            g[c] = fetch(off + min(i0 + c * 64 + lane, M - 1));
+#pragma unroll
+                        for (int c = 0; c < MD_STAGE / 64; ++c) {
+                            if (i0 + c * 64 + lane < M) {
+                                float4 r = g[c];
+                                r.w = (r.x * r.x + r.y * r.y) + r.z * r.z;
+                                r.x = -2.0f * r.x; r.y = -2.0f * r.y; r.z = -2.0f * r.z;
+                                md_stage(s_row, c * 64 + lane, r);
+                            }
+                        }
+                        wave_sync();
+                        s = md_rows<false>(s_row, min(MD_STAGE, M - i0), qx, qy, qz, qn, s);
+                    }
+                    const float bs = act ? s : INFINITY;
+                    const int bj = act ? cj : 0x7FFFFFFF;
+                    const Cm3dValIdx red = cm3d_wave_reduce_t(Cm3dValIdx{bs, bj}, [&](Cm3dValIdx a_, Cm3dValIdx b_) { return better(b_.s, b_.j, a_.s, a_.j) ? b_ : a_; });
+                    if (red.j != 0x7FFFFFFF && (best_j == 0x7FFFFFFF || better(red.s, red.j, best_s, best_j))) { best_s = red.s; best_j = red.j; }
+                    nc = 0;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (cand) s_cand[nc + cm3d_mbcnt(cm)] = j;
+                nc += add;
+            }
         }
-    }
-    if (lane == 0) {
-        const int bj = best_j == 0x7FFFFFFF ? -1 : best_j;
-        medoid_pos[m] = bj;
-        float cx = 0.f, cy = 0.f, cz = 0.f;
-        if (bj >= 0) {
-            const float4 p = fetch(off + bj);
-            cx = p.x; cy = p.y; cz = p.z;
+        if (lane == 0) {
+            int bj = best_j == 0x7FFFFFFF ? -1 : best_j;
+#ifdef CM3D_DIAG
+            if (g_md_diag & 2048) bj = C;                                  // diagnostic: the number of candidates in place of the position
+#endif
+            medoid_pos[m] = bj;
+            float cx = 0.f, cy = 0.f, cz = 0.f;
+            if (bj >= 0) {
+                const float4 p = fetch(off + bj);
+                cx = p.x; cy = p.y; cz = p.z;
+            }
+            centroid[3 * m + 0] = cx; centroid[3 * m + 1] = cy; centroid[3 * m + 2] = cz;
         }
-        centroid[3 * m + 0] = cx; centroid[3 * m + 1] = cy; centroid[3 * m + 2] = cz;
-    }
     }
 }
 
@@ -917,19 +987,23 @@ extern "C" int cm3d_medoid2(const float *points, const int32_t *pt_off, const in
     int gmax = n_masks / 2 < 1024 ? 1024 : (n_masks / 2 > 4096 ? 4096 : n_masks / 2);
     if (const char *e = getenv("CM3D_MD_GRID")) gmax = atoi(e);
     if (grid > gmax) grid = gmax;
-    hipLaunchKernelGGL(k_medoid_tiles<false>, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
+    // (hit_row == NULL, the product's call: `points` holds the listed points themselves, cm3d_compact_hits' hit_xyz)
+    auto tiles_light = hit_row ? k_medoid_tiles<false, true> : k_medoid_tiles<false, false>;
+    auto tiles_heavy = hit_row ? k_medoid_tiles<true, true> : k_medoid_tiles<true, false>;
+    auto second_pass = hit_row ? k_medoid_long<true> : k_medoid_long<false>;
+    hipLaunchKernelGGL(tiles_light, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
                        tile_off, hit_row, desc, best, tile_cap, colsum_opt, approx, long_list, feedback);
     CM3D_CHECK_LAUNCH();
     if (approx) {             // (without a first pass -- colsum_opt, CM3D_MD_TWO_PASS=0 -- the light instantiation takes every batch)
-        hipLaunchKernelGGL(k_medoid_tiles<true>, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
+        hipLaunchKernelGGL(tiles_heavy, dim3(grid), dim3(MD_THREADS), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks,
                            tile_off, hit_row, desc, best, tile_cap, colsum_opt, approx, long_list, feedback);
         CM3D_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_medoid_reduce, dim3((n_masks + 255) / 256), dim3(256), 0, st, (const float4 *)points, pt_off, mask_frame,
-                       n_masks, hit_off, tile_off, hit_row, idx_cap, best, tile_cap, approx ? 1 : 0, long_list, medoid_pos, centroid);
+                       n_masks, hit_off, tile_off, hit_row, idx_cap, best, tile_cap, approx ? 1 : 0, desc, long_list, medoid_pos, centroid);
     CM3D_CHECK_LAUNCH();
     if (approx) {
-        hipLaunchKernelGGL(k_medoid_long, dim3(n_masks < 1024 ? n_masks : 1024), dim3(64 * MDL_WAVES), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks, hit_off,
+        hipLaunchKernelGGL(second_pass, dim3(n_masks < 1024 ? n_masks : 1024), dim3(64 * MDL_WAVES), 0, st, (const float4 *)points, pt_off, mask_frame, n_masks, hit_off,
                            hit_row, idx_cap, approx, long_list, medoid_pos, centroid);
         CM3D_CHECK_LAUNCH();
     }
@@ -1001,6 +1075,16 @@ __global__ __launch_bounds__(64) void k_selftest_mfma(uint64_t seed, int tiles_p
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? -2.0f * Rx : -2.0f * Ry, lo ? Qx : Qy, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? -2.0f * Rz : Rn, lo ? Qz : 1.0f, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(lo ? 1.0f : 0.0f, lo ? Qn : 0.0f, c, 0, 0, 0);
+        // md_approx_step's form: one k per v_mfma_f32_32x32x1_2b_f32, block lane / 32 = rows 0-31 against the columns of THAT half --
+        // here lane l's own column point (all 64 lanes hold one), so block 1 pairs rows 0-31 with the points of lanes 32-63
+        f32v c2;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) c2[q] = 0.0f;
+        c2 = __builtin_amdgcn_mfma_f32_32x32x1f32(-2.0f * Rx, qx, c2, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x1f32(-2.0f * Ry, qy, c2, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x1f32(-2.0f * Rz, qz, c2, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x1f32(Rn, 1.0f, c2, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x1f32(1.0f, qn, c2, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);          // C/D map of the 32x32 shapes; column = lane & 31
@@ -1012,6 +1096,16 @@ __global__ __launch_bounds__(64) void k_selftest_mfma(uint64_t seed, int tiles_p
             acc = fmaf(1.0f, Qn, acc);
             // (a first product of -0 would come out of the MFMA as +0: both are clamped to 0 before the root)
             if (__float_as_uint(acc) != __float_as_uint(c[q]) && !(acc == 0.0f && c[q] == 0.0f)) ++bad;
+            if (__float_as_uint(acc) != __float_as_uint(c2[q]) && !(acc == 0.0f && c2[q] == 0.0f)) ++bad;      // block 0: columns of lanes 0-31
+            // block 1: the same rows against the column points of lanes 32-63
+            const float Px = __shfl(qx, 32 + (lane & 31), 64), Py = __shfl(qy, 32 + (lane & 31), 64), Pz = __shfl(qz, 32 + (lane & 31), 64),
+                        Pn = __shfl(qn, 32 + (lane & 31), 64);
+            float acc1 = (-2.0f * ix) * Px;
+            acc1 = fmaf(-2.0f * iy, Py, acc1);
+            acc1 = fmaf(-2.0f * iz, Pz, acc1);
+            acc1 = fmaf(in_, 1.0f, acc1);
+            acc1 = fmaf(1.0f, Pn, acc1);
+            if (__float_as_uint(acc1) != __float_as_uint(c2[16 + q]) && !(acc1 == 0.0f && c2[16 + q] == 0.0f)) ++bad;
         }
     }
     // The scaled routes (md_rows<.., SCALED>, md_approx_tile) rest on two more instruction-level facts, checked here as well: the
@@ -1027,7 +1121,9 @@ __global__ __launch_bounds__(64) void k_selftest_mfma(uint64_t seed, int tiles_p
         if (__float_as_uint(got.x) != __float_as_uint(want) || __float_as_uint(got.y) != __float_as_uint(want)) ++bad;
         const float x = (lane & 1) ? -(float)(lane + 1) * 0.01f : (float)(lane + 1) * 0.015f;        // negative: 0; positive (< 1): the plain root
         const float wr = x < 0.0f ? 0.0f : md_vsqrt(x);
-        if (__float_as_uint(md_vsqrt_clamp01(x)) != __float_as_uint(wr)) ++bad;
+        float got_r;                                                                                 // (the instruction itself, not what the compiler makes of the expression)
+        asm volatile("v_sqrt_f32_e64 %0, %1 clamp" : "=v"(got_r) : "v"(x));
+        if (__float_as_uint(got_r) != __float_as_uint(wr) || __float_as_uint(md_vsqrt_clamp01(x)) != __float_as_uint(wr)) ++bad;
     }
     if (bad) atomicAdd(n_bad, bad);
 }
