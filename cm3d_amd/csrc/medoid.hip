@@ -527,6 +527,9 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
     const int ntiles = min(tile_off[n_masks], tile_cap);
     if (ntiles <= 0) return;
     if ((approx_opt != nullptr && md_batch_long(desc, ntiles)) != WITH_LONG) return;       // the other instantiation's batch
+    // (tiles in strides of the grid, longest lists first.  Handing the heavy instantiation's tiles out from a counter instead -- so that a
+    // wave that walks 2000 rows does not hold its workgroup's slots -- costs more than it balances: 29 k atomics on one address, C1's stage
+    // 269 -> 505 us; profiles/r04_project_experiments.txt)
     for (int t = blockIdx.x * MD_WAVES + wave; t < ntiles; t += gridDim.x * MD_WAVES) {
         const TileDesc d = desc[t];
         // the descriptor is the same in every lane: keep it in scalar registers so that the loops below are
@@ -709,7 +712,7 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
 #define MDL_WAVES 4                      // waves per workgroup, each with long masks of its own (no workgroup barrier anywhere)
 #define MDL_MAXC 64                      // candidates the row-parallel route takes
 #define MDL_GC 16                        // ... and settles per walk over the rows
-#define MDL_AU 8                         // first-pass sums loaded per lane and round trip
+#define MDL_AU 16                        // first-pass sums loaded per lane and round trip
 #define MDL_TS 68                        // floats per candidate in the transposition buffer: 16-byte aligned rows, lanes c and c + 8 share banks
 
 struct MdlLds {                          // one wave's slice
