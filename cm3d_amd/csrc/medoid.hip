@@ -125,7 +125,7 @@ struct TileBest { float s; int j; };
 #ifdef CM3D_DIAG
 // Diagnostic build only (make diag; tools/md_diag.py): s_memtime of every tile's wave at its start, after its first staged
 // chunk and at its end, its placement (XCC_ID << 32 | HW_ID) and its list length.
-#define MD_DIAG_WAVES 16384
+#define MD_DIAG_WAVES 65536
 __device__ int g_md_diag;
 __device__ unsigned long long g_md_wave[5 * MD_DIAG_WAVES];
 __device__ unsigned long long g_md_clock[4];          // s_memtime and the 100 MHz s_memrealtime at the first wave's start and the last wave's end
@@ -560,8 +560,22 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
 #ifdef CM3D_DIAG
         if (WITH_LONG && ((g_md_diag & 512) ? !approx : ((g_md_diag & 1024) ? approx : false))) continue;      // 512: first-pass tiles only, 1024: exact tiles only
 #endif
+#ifdef CM3D_DIAG
+        const unsigned long long t_tile = diag ? md_now() : 0ull;           // (per tile; t_start is the wave's)
+        auto stamp = [&](unsigned long long staged) {
+            if (diag && lane == 0 && t < MD_DIAG_WAVES) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                g_md_wave[5 * t] = t_tile; g_md_wave[5 * t + 1] = staged; g_md_wave[5 * t + 2] = md_now();
+                g_md_wave[5 * t + 3] = ((unsigned long long)xcc << 32) | hw; g_md_wave[5 * t + 4] = (unsigned long long)M;
+                if (t == 0) { g_md_clock[0] = t_start; g_md_clock[1] = w_start; g_md_clock[2] = md_now(); g_md_clock[3] = wall_clock64(); }       // same wave, same XCD as the start stamps
+            }
+        };
+#endif
         if (WITH_LONG && approx && MD_APPROX_MFMA) {
             md_approx_tile(fetch, reinterpret_cast<float *>(s_row), off, M, jt, approx_opt);
+#ifdef CM3D_DIAG
+            stamp(t_tile);
+#endif
             continue;
         }
         // Rows are staged MD_STAGE (256) at a time: all their index loads, then all their point gathers are in
@@ -639,12 +653,7 @@ __global__ __launch_bounds__(MD_THREADS, 4) void k_medoid_tiles(const float4 *__
         }
         if (lane == 0) { tile_best[d.t].s = bs; tile_best[d.t].j = bj; }
 #ifdef CM3D_DIAG
-        if (diag && lane == 0 && t < MD_DIAG_WAVES) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-            g_md_wave[5 * t] = t_start; g_md_wave[5 * t + 1] = t_staged; g_md_wave[5 * t + 2] = md_now();
-            g_md_wave[5 * t + 3] = ((unsigned long long)xcc << 32) | hw; g_md_wave[5 * t + 4] = (unsigned long long)M;
-            if (t == 0) { g_md_clock[0] = t_start; g_md_clock[1] = w_start; g_md_clock[2] = md_now(); g_md_clock[3] = wall_clock64(); }       // same wave, same XCD as the start stamps
-        }
+        stamp(t_staged);
 #endif
     }
 }

@@ -50,7 +50,7 @@ ck = (C.c_ulonglong * 4)()
 L.cm3d_md_diag_read_clock.argtypes = [C.c_void_p]
 L.cm3d_md_diag_read_clock(ck)
 print(f"tile 0's wave: {ck[2] - ck[0]} s_memtime ticks in {(ck[3] - ck[1]) * 10} ns of the 100 MHz clock -> {(ck[2] - ck[0]) / max(1, (ck[3] - ck[1]) * 10):.3f} ticks per ns")
-NW = 16384
+NW = 65536
 wv = (C.c_ulonglong * (5 * NW))()
 L.cm3d_md_diag_read_waves(wv, NW)
 wi = np.array(list(wv), np.uint64).reshape(NW, 5)
@@ -84,3 +84,15 @@ for k in worst:
     sel = key == k
     s0 = t[sel, 0].min()
     print(f"  slow SIMD {k}: " + "; ".join(f"M {m} [{(a0 - s0) * tick:.1f} {(a1 - s0) * tick:.1f} {(a2 - s0) * tick:.1f}]" for m, a0, a1, a2 in zip(M[sel], t[sel, 0], t[sel, 1], t[sel, 2])))
+# how evenly the launch ends: when each SIMD's last tile is done, relative to the first start anywhere, and how many tiles it held on average
+t0 = t[:, 0].min()
+last = np.array([t[key == k, 2].max() - t0 for k in ks]) * tick
+busy = np.array([(t[key == k, 2] - t[key == k, 0]).sum() for k in ks]) * tick
+print(f"launch span {(t[:, 2].max() - t0) * tick:.1f} us; a SIMD's last tile ends at: min {last.min():.1f} p10 {np.percentile(last, 10):.1f} median {np.median(last):.1f} "
+      f"p90 {np.percentile(last, 90):.1f} max {last.max():.1f} us; tiles resident per SIMD (sum of lifetimes / span): median {np.median(busy / ((t[:, 2].max() - t0) * tick)):.2f}")
+longm = M > 256
+for nm, sel in (("first-pass tiles (M > 256)", longm), ("exact tiles", ~longm)):
+    if sel.any():
+        lt = (t[sel, 2] - t[sel, 0]) * tick
+        print(f"  {nm}: {sel.sum()} tiles, {M[sel].sum()} rows; lifetime per row ns: median {np.median(lt / M[sel]) * 1e3:.1f}; starts at us: median {np.median(t[sel, 0] - t0) * tick:.1f} "
+              f"p90 {np.percentile(t[sel, 0] - t0, 90) * tick:.1f} max {(t[sel, 0].max() - t0) * tick:.1f}")
