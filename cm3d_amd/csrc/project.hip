@@ -614,6 +614,13 @@ static __device__ __forceinline__ int ph_sweep_of(const int32_t *srow, int ns, i
     for (int k = 1; k < ns; ++k) k_sw += srow[k] <= i;
     return k_sw;
 }
+// The same from a register: lane k of v_srow = the frame-local first row of sweep k (k < ns <= PH_MAX_SWEEPS), lanes from ns on INT_MAX.
+// One compare and a bit count for a uniform row -- the loop above is a memory round trip per sweep, and in a kernel that stores to
+// global memory the compiler makes them VECTOR loads with a wait for everything in flight (the prefetched rows), twice per chunk.
+static __device__ __forceinline__ int ph_sweep_of_u(int v_srow, int i_uniform)
+{
+    return (int)__popcll(__ballot(cm3d_lane() >= 1 && v_srow <= i_uniform));
+}
 
 // One-dimensional grid of 4-wave workgroups whose waves never synchronise.  Wave number t of the launch holds TICKET t of
 // `tpf` tickets per frame: slot = t / F of frame (t % F + W slot) % F, W = waves per workgroup -- the four waves of a workgroup work on four
@@ -703,6 +710,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
     float4 t_tab = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < (FT_WORDS - FT_WEDGE) / 4) t_tab = reinterpret_cast<const float4 *>(ft + FT_WEDGE)[lane];
     const int t_first = lane <= CM3D_MAX_CAMS ? ft[FT_CAMFIRST + lane] : 0;
+    const int v_srow = lane < min(ft[5], PH_MAX_SWEEPS + 1) ? ft[FT_SROW + lane] : 0x7FFFFFFF;       // (ph_sweep_of_u)
     const int p0 = ft[0], n = ft[1], m0 = ft[2], nm = ft[3], sa = ft[4], ns = ft[5], bits_off = ft[6], nwc = ft[7];
     if (slot >= nwc) return;                                        // more tickets than wave-chunks in this frame
     const int planes = (nm + 31) >> 5;
@@ -820,7 +828,7 @@ __global__ __launch_bounds__(PHK_THREADS, PH_MIN_BLOCKS) void k_project_hits(
             // sweep of the chunk's first and last row: equal for all but the chunks that hold a sweep boundary
             const int32_t *srow = ft + FT_SROW;
             int sw_lo = 0, sw_hi = 0;
-            if (ns > 1) { sw_lo = ph_sweep_of(srow, ns, cb); sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1); }
+            if (ns > 1) { sw_lo = ph_sweep_of_u(v_srow, cb); sw_hi = ph_sweep_of_u(v_srow, cb + nvalid - 1); }
             const float *xf_u = sweep_xf + (size_t)(sa + sw_lo) * CM3D_SWEEP_XF_STRIDE;                    // scalar loads
             uint32_t nib = 0;
             // (scalar float32 per row, the 24 coefficients as scalar operands.  Measured alternatives: the packed form -- half the
@@ -1190,6 +1198,7 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int32_t *srow = ft + FT_SROW;
+    const int v_srow = lane < min(ns, PH_MAX_SWEEPS + 1) ? srow[lane] : 0x7FFFFFFF;                  // (ph_sweep_of_u)
     // Hit words (plane 0) of every wave-chunk of the span that holds a hit: all requested before the first is used.  The
     // array is only ever indexed at [0] and rotated, so it stays in registers without unrolling the loop.
     uint32_t wq[CP_SPAN][PH_PT];
@@ -1238,7 +1247,7 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *
             // sweep of each of this lane's rows (k_hit_xyz re-derives the coordinates of the listed rows from the raw rows)
             int sweep[PH_PT] = {sa, sa, sa, sa};
             if (ns > 1) {
-                const int sw_lo = ph_sweep_of(srow, ns, cb), sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1);
+                const int sw_lo = ph_sweep_of_u(v_srow, cb), sw_hi = ph_sweep_of_u(v_srow, cb + nvalid - 1);
 #pragma unroll
                 for (int jj = 0; jj < PH_PT; ++jj) sweep[jj] = sa + (sw_lo >= sw_hi ? sw_lo : ph_sweep_of(srow, ns, cb + 4 * lane + jj));
             }

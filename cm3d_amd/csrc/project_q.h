@@ -121,6 +121,8 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
     if (lane < (FT_WORDS - FT_WEDGE) / 4) t_tab = reinterpret_cast<const float4 *>(ft + FT_WEDGE)[lane];
     // lane c (<= CM3D_MAX_CAMS): first entry of camera c; read with v_readlane
     const int v_first = lane <= CM3D_MAX_CAMS ? ft[FT_CAMFIRST + lane] : 0;
+    // lane k (< the frame's sweeps): frame-local first row of sweep k; INT_MAX beyond (ph_sweep_of_u)
+    const int v_srow = lane < min(ft[5], PH_MAX_SWEEPS + 1) ? ft[FT_SROW + lane] : 0x7FFFFFFF;
     // the frame's mask entries in register lanes: lane e of set s = entry 64 s + e (k_frame_tables: sorted by camera)
     const int4 *ment = a.ment_all + (size_t)f * a.nm_cap * 2;
     int e_box[NE], e_ext[NE], e_kw[NE], e_off[NE], e_gbox[NE], e_gext[NE];
@@ -197,7 +199,6 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    const int32_t *srow = ft + FT_SROW;
 
     int acc_cnt[NC];
 #pragma unroll
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
         PQ_IV_BEGIN(105);
         // ---- sweep preparation (reference :437-465): ego-box drop on the raw coordinates, sensor -> ego -> global
         int sw_lo = 0, sw_hi = 0;
-        if (ns > 1) { sw_lo = ph_sweep_of(srow, ns, cb); sw_hi = ph_sweep_of(srow, ns, cb + nvalid - 1); }
+        if (ns > 1) { sw_lo = ph_sweep_of_u(v_srow, cb); sw_hi = ph_sweep_of_u(v_srow, cb + nvalid - 1); }
         if (sw_lo != vxf_sweep) { load_xf(sw_lo, s_xf); vxf_sweep = sw_lo; }
         float g[12];
         if ((a.stage & 255) >= 1) pq_xform4(s_xf, cur.q, g);
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
                 load_xf(sw, s_xf2);
                 float g2[12];
                 pq_xform4(s_xf2, cur.q, g2);
-                const int first = srow[sw];                         // frame-local first row of sweep sw
+                const int first = __builtin_amdgcn_readlane(v_srow, sw);          // frame-local first row of sweep sw
 #pragma unroll
                 for (int j = 0; j < PH_PT; ++j)
                     if (cb + 4 * lane + j >= first) { g[j] = g2[j]; g[4 + j] = g2[4 + j]; g[8 + j] = g2[8 + j]; }
