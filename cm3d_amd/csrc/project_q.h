@@ -29,6 +29,22 @@ struct PqArgs {
     int stage;                                    // 99 = everything; the diagnostic build stops the chunk loop's stages earlier (timing only)
 };
 
+// the chunk loop's stage cuts and ablation bits exist in the diagnostic build only: in the product every test of `stage` was a loop-invariant
+// condition the compiler kept as a 64-bit mask in two scalar registers (seven of them, in spill lanes)
+#ifdef CM3D_DIAG
+#define PQ_STAGE(a) ((a).stage)
+#else
+#define PQ_STAGE(a) 99
+#endif
+#ifndef PQ_OPT_LDSV
+#define PQ_OPT_LDSV 1       // LDS slices addressed from a vector register
+#endif
+#ifndef PQ_OPT_SCALV
+#define PQ_OPT_SCALV 1      // uniform operands of vector instructions in vector registers
+#endif
+#ifndef PQ_OPT_PTRV
+#define PQ_OPT_PTRV 0       // per-lane base addresses in vector registers (no fewer spills on top of the other two, 1 % slower in flight)
+#endif
 #ifndef PQ_MIN_BLOCKS
 #define PQ_MIN_BLOCKS 3                           // waves per SIMD the register budget is held to (168 registers): what the launch fills anyway
 #endif
@@ -72,11 +88,16 @@ static __device__ __forceinline__ void pq_xform4(const float *xf, const float (&
 #define PQ_IV_END(which) do { } while (0)
 #endif
 
+#ifdef PQ_NUM_VGPR
+#define PQ_VGPR_ATTR __attribute__((amdgpu_num_vgpr(PQ_NUM_VGPR)))
+#else
+#define PQ_VGPR_ATTR
+#endif
 template <int NPL, bool KEEP>
-__global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const PqArgs a)
+__global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) PQ_VGPR_ATTR void k_project_q(const PqArgs a)
 {
 #ifdef CM3D_DIAG
-    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = (a.stage & 255) >= 100 ? ph_now() : 0ull;
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = (PQ_STAGE(a) & 255) >= 100 ? ph_now() : 0ull;
     const unsigned long long t_prev0 = t_prev;
 #endif
     constexpr int NE = NPL == 1 ? 1 : 2;          // sets of 64 mask entries held in register lanes
@@ -85,10 +106,17 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
     __shared__ __align__(16) float s_cam_all[PHK_WAVES][CM3D_MAX_CAMS * CM3D_CAM_STRIDE];
     __shared__ __align__(16) float s_tab_all[PHK_WAVES][FT_WORDS - FT_WEDGE];
     __shared__ __align__(16) float s_xf_all[PHK_WAVES][2][CM3D_SWEEP_XF_STRIDE];     // the current sweep's coefficients, and a second set for a chunk with a sweep boundary
-    float *const s_xf = s_xf_all[wave][0], *const s_xf2 = s_xf_all[wave][1];
-    float *const s_cam = s_cam_all[wave];
-    float(*const s_wedge)[8] = reinterpret_cast<float(*)[8]>(s_tab_all[wave]);
-    float(*const s_apx)[16] = reinterpret_cast<float(*)[16]>(s_tab_all[wave] + (FT_APX - FT_WEDGE));
+    // (the wave's LDS slices are addressed from a VECTOR register: an LDS instruction takes its address from one anyway, and five base
+    // addresses in scalar registers were five of the 46 this kernel kept in spill lanes, each use a v_mov or a v_readlane)
+#if PQ_OPT_LDSV
+    const int wave_v = (int)(threadIdx.x >> 6);
+#else
+    const int wave_v = wave;
+#endif
+    float *const s_xf = s_xf_all[wave_v][0], *const s_xf2 = s_xf_all[wave_v][1];
+    float *const s_cam = s_cam_all[wave_v];
+    float(*const s_wedge)[8] = reinterpret_cast<float(*)[8]>(s_tab_all[wave_v]);
+    float(*const s_apx)[16] = reinterpret_cast<float(*)[16]>(s_tab_all[wave_v] + (FT_APX - FT_WEDGE));
     const float qnan = __int_as_float(0x7FC00000);
     const int n_frames = a.n_frames, tpf = a.tpf, n_cams = a.n_cams;
 
@@ -104,7 +132,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
     auto draw = [&](int l) {
         int v = 0;
 #ifdef CM3D_DIAG
-        if (a.stage & 512) return l == slot ? static_next++ : (1 << 20);     // timing only: fixed shares, no draws
+        if (PQ_STAGE(a) & 512) return l == slot ? static_next++ : (1 << 20);     // timing only: fixed shares, no draws
 #endif
         if (lane == 0) v = atomicAdd(&taken[l], 1);
         return v;
@@ -153,6 +181,17 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
         }
         return c;
     };
+    // Per-lane base addresses in VECTOR registers (pinned by the empty asm: the compiler would put the uniform part back into scalar
+    // registers) for everything the chunk loop reads or writes with a per-lane address: a 64-bit base in scalar registers costs two of
+    // the 102 the loop does not have (46 lived in spill lanes), here it is one v_lshl_add_u64 with the chunk's offset per use.
+    const float *raw_lane = a.raw + ((size_t)p0 + 4 * lane) * 3;
+    uint32_t *hw_lane = a.hit_words + (size_t)p0 + 4 * lane;
+    uint32_t *rb_lane = a.removed_bits + (size_t)bits_off + (lane >> 3);
+    int32_t *cnt_lane = a.wc_cnt + (size_t)f * a.nwc_max * a.nm_cap + lane;
+    int32_t *grp_lane = a.grp + (size_t)f * a.zstride + lane;
+#if PQ_OPT_PTRV
+    asm volatile("" : "+v"(raw_lane), "+v"(hw_lane), "+v"(rb_lane), "+v"(cnt_lane), "+v"(grp_lane));
+#endif
     // the lane's four rows of a chunk: x0..3 y0..3 z0..3 [+ the four intensities when the cloud is kept]
     struct Rows { float q[12]; float w[KEEP ? 4 : 1]; };
     auto load_rows = [&](Rows &r, int chunk) {
@@ -162,7 +201,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
         if (KEEP) { r.w[0] = 0.f; r.w[KEEP ? 1 : 0] = 0.f; r.w[KEEP ? 2 : 0] = 0.f; r.w[KEEP ? 3 : 0] = 0.f; }
         if (4 * lane < nvalid) {
             const size_t row = (size_t)p0 + cb + 4 * lane;
-            const float4 *p = reinterpret_cast<const float4 *>(a.raw + row * 3);
+            const float4 *p = reinterpret_cast<const float4 *>(raw_lane + (size_t)cb * 3);
             const float4 x = p[0], y = p[1], z = p[2];
             r.q[0] = x.x; r.q[1] = x.y; r.q[2] = x.z; r.q[3] = x.w; r.q[4] = y.x; r.q[5] = y.y; r.q[6] = y.z; r.q[7] = y.w;
             r.q[8] = z.x; r.q[9] = z.y; r.q[10] = z.z; r.q[11] = z.w;
@@ -177,7 +216,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
     {
 #pragma unroll
         for (int q = 0; q < CAM_Q; ++q) reinterpret_cast<float4 *>(s_cam)[lane + 64 * q] = t_cam[q];
-        if (lane < (FT_WORDS - FT_WEDGE) / 4) reinterpret_cast<float4 *>(s_tab_all[wave])[lane] = t_tab;
+        if (lane < (FT_WORDS - FT_WEDGE) / 4) reinterpret_cast<float4 *>(s_tab_all[wave_v])[lane] = t_tab;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -203,7 +242,6 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
     int acc_cnt[NC];
 #pragma unroll
     for (int s = 0; s < NC; ++s) acc_cnt[s] = 0;
-    int32_t *const wc_cnt_f = a.wc_cnt + (size_t)f * a.nwc_max * a.nm_cap;
     int32_t *const wc_info_f = a.wc_info + (size_t)f * a.nwc_max;
     int32_t *const grp_f = a.grp + (size_t)f * a.zstride;
     const int ngrp_max = (a.nwc_max + PH_GRP - 1) / PH_GRP;
@@ -219,10 +257,10 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
     auto flush_results = [&]() {
         if (pend_chunk < 0) return;
 #ifdef CM3D_DIAG
-        if (a.stage & 1024) return;                                 // timing only: no result stores at all
+        if (PQ_STAGE(a) & 1024) return;                                 // timing only: no result stores at all
 #endif
         const int pcb = pend_chunk * PH_WC, pvalid = min(PH_WC, n - pcb);
-        int32_t *cnt_row = wc_cnt_f + pend_chunk * a.nm_cap;
+        int32_t *cnt_row = cnt_lane + pend_chunk * a.nm_cap;              // (this lane's entry)
         bool mine = pend_cnt[0] != 0;
         if (NC == 2) mine |= pend_cnt[NC - 1] != 0;
         const bool any = __ballot(mine) != 0ull;
@@ -230,7 +268,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) {
                 if (pl * 32 >= nm) break;                           // uniform
-                uint32_t *hw = a.hit_words + (size_t)pl * a.n_points_total + p0 + pcb + 4 * lane;
+                uint32_t *hw = hw_lane + (size_t)pl * a.n_points_total + pcb;
                 if (pvalid >= PH_WC) {
                     *reinterpret_cast<u4u *>(hw) = (u4u){pend_bits[pl][0], pend_bits[pl][1], pend_bits[pl][2], pend_bits[pl][3]};
                 } else {
@@ -244,19 +282,25 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
         for (int s = 0; s < NC; ++s) {
             const int k = 64 * s + lane;
             if (k < nm) {
-                cnt_row[k] = pend_cnt[s];
-                if (pend_cnt[s] && !(a.stage & 256)) atomicAdd(&grp_f[(pend_chunk / PH_GRP) * a.nm_cap + k], pend_cnt[s]);
+                cnt_row[64 * s] = pend_cnt[s];
+                if (pend_cnt[s] && !(PQ_STAGE(a) & 256)) atomicAdd(&grp_lane[(pend_chunk / PH_GRP) * a.nm_cap + 64 * s], pend_cnt[s]);
             }
         }
         if (lane == 0) {
             wc_info_f[pend_chunk] = pend_drop | (any ? (int)0x80000000 : 0);
-            if (pend_drop && !(a.stage & 256)) atomicAdd(&grp_f[ngrp_max * a.nm_cap + pend_chunk / PH_GRP], pend_drop);
+            if (pend_drop && !(PQ_STAGE(a) & 256)) atomicAdd(&grp_f[ngrp_max * a.nm_cap + pend_chunk / PH_GRP], pend_drop);
         }
     };
     int draw_from = list;
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): every start-up load has landed (tables, entries, first rows) before the loop
-    const int W = a.W, H = a.H;
-    const float min_dist = a.min_dist, halfw = a.halfw;
+    // Uniform values that are only ever operands of vector instructions live in VECTOR registers (the empty asm hides that they are
+    // uniform): each was a scalar register -- the kernel kept 46 of those in spill lanes, 8.8 cycles per reload --, and a vector
+    // instruction with a scalar operand occupies the SIMD 4.5 cycles instead of 3 (tools/ubench/valu_wall.hip).
+    int W = a.W, H = a.H;
+    float min_dist = a.min_dist, halfw = a.halfw, zmin_v = zmin;
+#if PQ_OPT_SCALV
+    asm volatile("" : "+v"(W), "+v"(H), "+v"(min_dist), "+v"(halfw), "+v"(zmin_v));
+#endif
 #pragma unroll 1
     do {
         const int cb = chunk * PH_WC;
@@ -267,7 +311,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
         if (ns > 1) { sw_lo = ph_sweep_of_u(v_srow, cb); sw_hi = ph_sweep_of_u(v_srow, cb + nvalid - 1); }
         if (sw_lo != vxf_sweep) { load_xf(sw_lo, s_xf); vxf_sweep = sw_lo; }
         float g[12];
-        if ((a.stage & 255) >= 1) pq_xform4(s_xf, cur.q, g);
+        if ((PQ_STAGE(a) & 255) >= 1) pq_xform4(s_xf, cur.q, g);
         else {
 #pragma unroll
             for (int k = 0; k < 12; ++k) g[k] = cur.q[k];
@@ -319,7 +363,9 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
             vv |= __builtin_amdgcn_update_dpp(0, vv, 0xB1, 0xF, 0xF, true);
             vv |= __builtin_amdgcn_update_dpp(0, vv, 0x4E, 0xF, 0xF, true);
             vv |= __builtin_amdgcn_update_dpp(0, vv, 0x104, 0xF, 0xF, true);
-            if ((lane & 7) == 0) a.removed_bits[(size_t)bits_off + 8 * chunk + (lane >> 3)] = (uint32_t)vv;
+            int l7 = lane & 7;
+            asm volatile("" : "+v"(l7));                            // (not a loop invariant: its mask would sit in two scalar registers for a path few chunks take)
+            if (l7 == 0) rb_lane[8 * chunk] = (uint32_t)vv;
         }
         PQ_STAMP(1);                                                // rows arrive, transform, dropped rows
         PQ_IV_END(105);
@@ -350,7 +396,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
         PQ_IV_BEGIN(104);
         uint32_t vis = 0u;
 #pragma unroll 1
-        for (int cgp = 0; cgp < ((a.stage & 255) >= 2 ? n_cams : 0); cgp += PH_CG) {
+        for (int cgp = 0; cgp < ((PQ_STAGE(a) & 255) >= 2 ? n_cams : 0); cgp += PH_CG) {
             if (!((cam_has >> cgp) & ((1u << PH_CG) - 1u))) continue;
             float inside[PH_CG];
 #pragma unroll
@@ -378,7 +424,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
             const int c = __builtin_ctz(vis);
             vis &= vis - 1u;
             const int e0 = __builtin_amdgcn_readlane(v_first, c), e1 = __builtin_amdgcn_readlane(v_first, c + 1);
-            if (e0 >= e1 || (a.stage & 255) < 3) continue;
+            if (e0 >= e1 || (PQ_STAGE(a) & 255) < 3) continue;
             // ---- approximate projection (wedge_setup): pixel codes for the grown boxes
             const bool pretest = (apx_okmask >> c) & 1;
             int pa[PH_PT];
@@ -398,7 +444,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
                         // code, or -1 unless zc > zmin: the sign of zmin - zc spread over the word and inverted (integer operations at
                         // full rate instead of a compare and a select on VCC; a NaN depth keeps a positive sign here -- it comes from the
                         // NaN of a dead row -- and is killed like a small one; if it were not, the exact chain would reject the point)
-                        const int keep = __float_as_int(zmin - zc[q]) >> 31;          // all ones: zc > zmin
+                        const int keep = __float_as_int(zmin_v - zc[q]) >> 31;        // all ones: zc > zmin
                         pa[2 * h + q] = ((iv << 16) | iu) | ~keep;
                     }
                 }
@@ -431,7 +477,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
                     PQ_STAMP(5);                                    // grown-box tests
                     if (!cmask) continue;
                 }
-                if ((a.stage & 255) < 4) break;
+                if ((PQ_STAGE(a) & 255) < 4) break;
                 if (!projected) {
                     projected = true;
                     const int cns = __builtin_amdgcn_readfirstlane((int)s_cam[c * CM3D_CAM_STRIDE + 54]);
@@ -452,7 +498,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
                     }
                 }
                 PQ_STAMP(6);                                        // exact chain
-                uint32_t rem = (a.stage & 255) >= 5 ? cmask : 0u;
+                uint32_t rem = (PQ_STAGE(a) & 255) >= 5 ? cmask : 0u;
                 // candidate masks of the block, up to PH_MB at a time: all their words are requested before the first is used (one
                 // memory round trip per batch).  A batch is straight-line code for its number of masks (mask_batch<NB>): every load
                 // has its use on the same path, so the compiler's s_waitcnt bookkeeping never carries a "pending" word register
@@ -537,7 +583,7 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
             chunk = c_nxt;
             if (c_nxt < nwc) c_nxt = chunk_of(draw_v, draw_from);
 #ifdef CM3D_DIAG
-            if ((a.stage & 255) == 101) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((PQ_STAGE(a) & 255) == 101) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             PQ_IV_END(101);
         }
@@ -554,11 +600,11 @@ __global__ __launch_bounds__(PHK_THREADS, PQ_MIN_BLOCKS) void k_project_q(const 
     tot = cm3d_wave_sum(tot);
     if (lane == 0 && tot) atomicAdd(&a.frame_hits[f], tot);
 #ifdef CM3D_DIAG
-    if ((a.stage & 255) >= 100 && lane == 0) {
+    if ((PQ_STAGE(a) & 255) >= 100 && lane == 0) {
         acc[0] = ph_now() - t_prev0;
         // (per-wave slots, plain stores: thousands of atomics on one address at the end of the early waves held up the draws of the late ones)
         const int wid = (int)blockIdx.x * PHK_WAVES + wave;
-        if ((a.stage & 255) == 100) {
+        if ((PQ_STAGE(a) & 255) == 100) {
             for (int k = 0; k < 8; ++k) atomicAdd(&g_ph_stamp[k], acc[k]);
             atomicAdd(&g_ph_count[0], 1ull);
         } else if (wid < PH_DIAG_WAVES) {
