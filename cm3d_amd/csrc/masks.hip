@@ -536,6 +536,9 @@ __global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uin
                                                                         int n_masks, int W, int H, int Wp, int lds_words,
                                                                         uint32_t *__restrict__ packed, int32_t *__restrict__ bbox, int max_bands, int diag)
 {
+#ifndef CM3D_DIAG
+    diag = 0;                                                   // (the ablation switches exist in the diagnostic build only: each was a loop-invariant mask in scalar registers)
+#endif
     extern __shared__ __align__(16) uint32_t s_all[];
     __shared__ int s_part[RW_WAVES][4];                         // the bands' shares of the bounding box
     const int lane = cm3d_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
