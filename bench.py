@@ -575,7 +575,7 @@ def main(argv=None):
                              hit_rows=eng.hit_chunk_rows(),
                              n_points=int(status[1]), sum_pairs=int((eng.b.hit_count.to(torch.int64) ** 2).sum().item()),
                              sum_pairs_long=int((eng.b.hit_count.to(torch.int64) ** 2)[(eng.b.hit_count > 256) & (eng.b.hit_count < 100000)].sum().item())
-                             if int(eng.b.hit_count.max().item()) > 384 else 0,      # (csrc/medoid.hip: MD_LONG_MIN in a batch with a list beyond MD_BATCH_LONG)
+                             if int(eng.b.hit_count.max().item()) > 448 else 0,      # (csrc/medoid.hip: MD_LONG_MIN in a batch with a list beyond MD_BATCH_LONG)
                              n_boxes=int((eng.b.flags == 3).sum().item()), max_hits=int(eng.b.hit_count.max().item()),
                              rect_bytes=packed_rect_bytes(eng.b.bbox.cpu().numpy(), eng.b.Wp),
                              n_gathered=None if gathered is None else int(sum(g.shape[0] for g in gathered)), spread=spread, long_rate=long_rate, unamortised=unamortised if mode == modes[0] else None)
@@ -681,7 +681,7 @@ def main(argv=None):
     # 'vector-instruction ISSUE cost': 4 cycles per wave instruction, packed float32 included, 8 for v_rsq / v_sqrt): a SIMD issues
     # 2.4e9 / 4 slots a second, 1024 SIMDs 614 G, each slot serves 64 lanes.  ALGORITHMIC slots per pair, i.e. what the
     # reference's float32 arithmetic costs in this instruction set with nothing wasted:
-    #   exact route (lists up to 256 points, or of a batch without a list beyond 384: csrc/medoid.hip md_rows): 5 packed operations
+    #   exact route (lists up to 256 points, or of a batch without a list beyond 448: csrc/medoid.hip md_rows): 5 packed operations
     #     per two pairs for the cdist expansion (2.5), clamp_min_ (1), v_rsq (2), its cap for zeros (1), 7 packed operations per two
     #     pairs for the correctly rounded root (3.5), the ordered sum (1)                                           = 11 slots
     #   first pass of the long lists (md_approx_tile): five v_mfma_f32_32x32x1_2b_f32 per 2048 pairs, 64 cycles each ON THE SAME PIPE --

@@ -31,12 +31,12 @@
 // Lists longer than this take the two-pass route (matrix-pipe first pass, k_medoid_long) -- in a batch that holds a list of more than
 // MD_BATCH_LONG points; a batch without one runs the light instantiation of the tile kernel and nothing else.  r04 (first pass a sixth
 // cheaper, second pass one wave per list): 512 / 384 / 256 / 128 give C4 790 / 826 / 847 / 843 k frames/s and C1 566 / 571 / 576 / 580 k;
-// the headline shape (longest list 358 points) is untouched by anything >= 384 as a batch limit, while a batch limit of 256 costs its
+// the headline shape (longest lists 358-400 points) is untouched by a batch limit of 448, while a batch limit of 256 costs its
 // medoid stage 10 us alone (the heavy instantiation and the second pass for a handful of lists).
 #define MD_LONG_MIN 256
 #endif
 #ifndef MD_BATCH_LONG
-#define MD_BATCH_LONG 384
+#define MD_BATCH_LONG 448                // (384 sent one of the headline shape's three resident batches -- longest list 390-odd points -- down the heavy route: 35 us for that pass)
 #endif
 #define MD_LONG_MAX 100000               // ... and shorter than this (the error bound of the first pass is derived for M < 10^5)
 static __device__ __forceinline__ bool md_two_pass(int M) { return M > MD_LONG_MIN && M < MD_LONG_MAX; }

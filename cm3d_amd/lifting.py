@@ -590,7 +590,7 @@ class LiftEngine:
                                          _ptr(b.pg_ws), b.pg_ws_bytes, st), "cm3d_compact_hits")
 
     def stage_medoid(self, st):
-        """The medoid stage.  In a batch with a list of more than 384 points, lists of more than 256 go a two-pass route that costs two
+        """The medoid stage.  In a batch with a list of more than 448 points, lists of more than 256 go a two-pass route that costs two
         launches even when a batch holds no such list (they find that out on the device: 2-3 % of a pass with three batches in flight).  The first launch leaves word 0
         of `self._md_fb` -- page-locked host memory the device writes directly, no copy -- saying whether THIS batch held one; the next
         pass of this engine reads whatever has arrived by then and, if the last batch it heard of had none, asks for the one-pass

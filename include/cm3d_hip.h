@@ -223,7 +223,7 @@ int64_t cm3d_tile_work_bytes(int32_t n_masks, int32_t idx_cap);
  *  medoid_pos int32[n_masks]    OUT position in the mask's index list (-1 if the list is empty)
  *  centroid   float[n_masks][3] OUT global-frame xyz of the medoid point
  *  colsum_opt float[idx_cap] OUT, optional (may be NULL): every column sum, laid out like hit_idx.  When NULL, lists of
- *             more than 256 points (in a batch whose longest list has more than 384) are settled in two passes (approximate sums for all columns, exact float32 sums only
+ *             more than 256 points (in a batch whose longest list has more than 448) are settled in two passes (approximate sums for all columns, exact float32 sums only
  *             for the columns a proven error bound cannot exclude): the same position, less work
  *  workspace: cm3d_medoid_workspace_bytes(n_masks, idx_cap) */
 int64_t cm3d_medoid_workspace_bytes(int32_t n_masks, int32_t idx_cap);

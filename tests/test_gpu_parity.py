@@ -98,7 +98,7 @@ def test_colsum_bit_exact(oracle):
 
 
 def test_medoid_hint_never_changes_a_result(oracle):
-    """LiftEngine feeds the medoid stage's feedback word (does this batch hold a list of more than 384 points?) back as the next
+    """LiftEngine feeds the medoid stage's feedback word (does this batch hold a list of more than 448 points?) back as the next
     pass's hint (cm3d_medoid2).  A batch without long lists, then -- in the same engine, so with a hint that says "none" -- a batch
     full of them, then the short one again: every pass must give the oracle's results, whatever the hint said."""
     import torch
@@ -118,7 +118,7 @@ def test_medoid_hint_never_changes_a_result(oracle):
             seen.append(int(eng._md_fb_np[0]))
             got = eng.download()
             _compare(hb, got, exp)
-        assert (np.diff(exp["hit_off"]).max() > 384) == bool(seen[-1])          # csrc/medoid.hip MD_BATCH_LONG
+        assert (np.diff(exp["hit_off"]).max() > 448) == bool(seen[-1])          # csrc/medoid.hip MD_BATCH_LONG
     assert seen[:3] == [0, 0, 0] and seen[3:6] == [1, 1, 1] and seen[6:] == [0, 0, 0]
 
 

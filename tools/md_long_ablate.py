@@ -57,7 +57,7 @@ torch.cuda.synchronize()
 pos = eng.b.medoid_pos.cpu().numpy()
 ho = eng.b.hit_off.cpu().numpy()
 Ms = np.diff(ho)[:len(pos)]
-lm = (Ms > 256) & (Ms < 100000) & (Ms.max() > 384)
+lm = (Ms > 256) & (Ms < 100000) & (Ms.max() > 448)
 C = pos[lm]
 print(f"long masks {lm.sum()} of {len(pos)}; M: median {int(np.median(Ms[lm]))} max {Ms[lm].max()}; candidates per long mask: min {C.min()} median {int(np.median(C))} "
       f"mean {C.mean():.1f} p90 {int(np.percentile(C, 90))} max {C.max()}; share with more than 16: {np.mean(C > 16):.3f}, more than 64: {np.mean(C > 64):.3f}; "
