@@ -162,6 +162,38 @@ def get_medoid(points, want_colsum=False, via_rows=False):
     return (j, colsum.cpu().numpy()[:M]) if want_colsum else j
 
 
+def get_medoids(point_lists, via_rows=False, want_colsum=False):
+    """Several lists in ONE call of the medoid stage (one "mask" each; `get_medoid` is the reference's one-list signature): what the
+    lists of a batch do to each other -- the two-pass route is taken by lists of more than 256 points when the batch holds one of
+    more than 448 (csrc/medoid.hip) -- can only be tested this way.  point_lists: arrays (M_k, 3); returns the list of medoid indices
+    (and the exact column sums with want_colsum, which also forces the one-pass route)."""
+    L = _lib.lib()
+    Ms = [int(np.asarray(p).shape[0]) for p in point_lists]
+    n, tot = len(Ms), int(sum(Ms))
+    P4 = np.zeros((max(tot, 1), 4), np.float32)
+    if tot:
+        P4[:tot, :3] = np.concatenate([np.asarray(p, np.float32).reshape(-1, 3) for p in point_lists], 0)
+    hit_off = np.concatenate([[0], np.cumsum(Ms)]).astype(np.int32)
+    tiles = [(m + _lib.MEDOID_TILE - 1) // _lib.MEDOID_TILE for m in Ms]
+    tile_off = np.concatenate([[0], np.cumsum(tiles)]).astype(np.int32)
+    pts = _t(P4)
+    # gather form: every list is the cloud of a frame of its own, its rows listed in order
+    pt_off, mask_frame = _t(hit_off.copy()), _t(np.arange(n, dtype=np.int32))
+    hit_idx = _t(np.concatenate([np.arange(m, dtype=np.int32) for m in Ms]) if tot else np.zeros(1, np.int32))
+    d_hit_off, d_tile_off = _t(hit_off), _t(tile_off)
+    med, cen = _e(n), _e(n, 3, dtype=torch.float32)
+    colsum = _e(max(tot, 1), dtype=torch.float32) if want_colsum else None
+    ws = _ws(L.cm3d_medoid_workspace_bytes(n, max(tot, 1)))
+    check(L.cm3d_medoid(pts.data_ptr(), pt_off.data_ptr() if via_rows else 0, mask_frame.data_ptr() if via_rows else 0, n,
+                        d_hit_off.data_ptr(), d_tile_off.data_ptr(), hit_idx.data_ptr() if via_rows else 0, max(tot, 1), 0, med.data_ptr(),
+                        cen.data_ptr(), colsum.data_ptr() if want_colsum else 0, ws.data_ptr(), ws.numel(), _st()), "cm3d_medoid")
+    out = [int(v) for v in med.cpu().numpy()]
+    if want_colsum:
+        cs = colsum.cpu().numpy()
+        return out, [cs[hit_off[k]:hit_off[k + 1]] for k in range(n)]
+    return out
+
+
 # ----------------------------------------------------------------------------- a10
 def lane_yaws_distances_and_coords(all_centroids, all_lane_pts):
     """Returns (yaws, distances, coords) like the reference; yaws/coords are float32-valued."""

@@ -364,6 +364,35 @@ def test_first_pass_forms_of_the_long_lists(oracle):
         assert got == want, name
 
 
+def test_second_pass_candidate_counts_and_batches_that_mix_the_routes(oracle):
+    """r04's second pass (csrc/medoid.hip k_medoid_long) settles up to 16 candidates per walk over the rows, further groups of 16 up to
+    64, and more than 64 in the column loop; and a list of 257-448 points takes the two-pass route only in a batch that holds a list of
+    more than 448.  Lists whose best point is duplicated K times (K tied candidates, the first of them must win) on both sides of every one of
+    those limits, batches with and without a long list, both pointer forms of the entry point: every position must be the oracle's."""
+    from cm3d_amd import ops
+    rng = np.random.default_rng(11)
+    centre = np.array([612.0, 1634.0, 1.5])
+
+    def tied(M, K):
+        pts = centre + rng.normal(0, [1.2, 0.7, 0.3], (M, 3))
+        best = int(np.argmin(np.linalg.norm(pts - pts.mean(0), axis=1)))
+        where = rng.choice(np.setdiff1d(np.arange(M), [best]), K - 1, replace=False) if K > 1 else []
+        pts[where] = pts[best]
+        return np.ascontiguousarray(pts.astype(np.float32))
+
+    def want(p):
+        return oracle.medoid(np.concatenate([p, np.zeros((len(p), 1), np.float32)], 1), np.arange(len(p)))
+    lists = [tied(M, K) for M in (460, 700, 1500) for K in (1, 2, 15, 16, 17, 33, 64, 65, 130)]
+    lists += [tied(M, K) for M in (257, 300, 448) for K in (1, 17, 70)] + [tied(100, 3), tied(256, 5), tied(64, 1)]
+    exp = [want(p) for p in lists]
+    for via_rows in (False, True):
+        assert ops.get_medoids(lists, via_rows=via_rows) == exp, via_rows                           # one batch: every list beyond 256 in two passes
+        short = [p for p in lists if len(p) <= 448]
+        assert ops.get_medoids(short, via_rows=via_rows) == [want(p) for p in short], via_rows      # no list beyond 448: one pass for all
+    one, _ = ops.get_medoids(lists, want_colsum=True)                                                # the one-pass route for every length
+    assert one == exp
+
+
 def test_every_route_of_the_medoid_root_equals_the_oracle(oracle):
     """k_medoid_tiles takes the root of a step of squared distances on one of four routes (csrc/medoid.hip md_rows): without any
     test when the norms of the list prove every value to be 0 or inside [1e-30, 1e30) (SAFE), packed after a test of the
