@@ -501,6 +501,7 @@ def main(argv=None):
                 t_r = time.perf_counter()
                 for step in range(n_steps):
                     pipe.rerun(step % depth, masks=mode)
+                region.enqueue_s = time.perf_counter() - t_r        # the host is done handing the passes to the streams here
                 torch.cuda.synchronize()
                 barrier()
                 torch.cuda.synchronize()
@@ -515,6 +516,7 @@ def main(argv=None):
             spread = {"min": round(min(reps), 1), "median": round(float(np.median(reps)), 1), "max": round(max(reps), 1), "repeats": 5}
             n_long = int(max(args.steps, min(20000, np.ceil(0.5 / max(dt / args.steps, 1e-6)))))
             long_rate = {"value": round(args.frames * world * n_long / region(n_long), 1), "steps": n_long}
+            long_rate["host_enqueue_ms_per_step"] = round(region.enqueue_s / n_long * 1e3, 4)
             # what the timed loop amortises and a job of ever-new batches does not: the lane index is built once for the
             # resident tables, and the medoid stage runs on the hint of the pass before.  The same K passes with the index rebuilt
             # in EVERY pass (each slot on an index of its own: a rebuild must not touch what another slot's pass is reading) and
@@ -543,7 +545,9 @@ def main(argv=None):
             unamortised = round(args.frames * world * args.steps / region_unamortised(args.steps), 1)
             for e, h in zip(pipe.engines, hints):
                 e._md_hint = h
-        # per-stage breakdown: a separate, untimed pass over ONE batch alone, with events around every stage
+        # per-stage breakdown: a separate, untimed pass over ONE batch alone, with events around every stage -- with the projection launch
+        # as one batch alone gets it (the whole chip; the pipeline above asked for two workgroups per CU: cm3d_project_workgroups_per_cu)
+        wg_hint = eng.lib.cm3d_project_workgroups_per_cu(0)
         alone = []
         with torch.cuda.stream(pipe.streams[0]):
             st = pipe.streams[0].cuda_stream
@@ -565,6 +569,7 @@ def main(argv=None):
                         b.record()
                         ev[s].append((a, b))
         torch.cuda.synchronize()
+        eng.lib.cm3d_project_workgroups_per_cu(wg_hint)
         # (project: the events of the timed region -> mean, it is an average launch duration; the alone-pass stages: medians of a
         # handful of passes, one preempted pass must not stand for the stage)
         stage_ms = {s: float(np.mean([a.elapsed_time(b) for a, b in ev[s]])) if s == "project" else float(np.median([a.elapsed_time(b) for a, b in ev[s]]))
@@ -630,6 +635,7 @@ def main(argv=None):
     roofline["measured_copy_GBs"] = round(5 * 2 * src_buf.numel() * 4 / (time.perf_counter() - t_cp) / 1e9, 1)
     del src_buf, dst_buf
     roofline["batches_in_flight"] = depth
+    roofline["workgroups_per_cu_in_flight"] = wg_hint if wg_hint else "as many as fit minus one (3)"      # cm3d_project_workgroups_per_cu; the alone figures: the whole chip
     roofline["avg_launch_ms_alone"] = round(r["project_alone_ms"], 4)      # the same launch with nothing else on the GPU
     roofline["frac_alone"] = round(rate(by["k_project_hits"], r["project_alone_ms"]) / HBM_PEAK_GBS, 4)
     # the same against what a plain stream gets on THIS box (the device copy above: reads + writes), not the nominal peak
@@ -723,6 +729,9 @@ def main(argv=None):
                    "parallelism": f"frame-sharded x{world}, {depth} independent batches in flight per GPU, one RCCL gather of box records"},
         # the timed K steps are short (a few ms at the driver's --steps): the same region five more times, and one of >= 0.5 s
         "value_spread": r["spread"], "value_long": None if r["long_rate"] is None else r["long_rate"]["value"],
+        # what the HOST needs to hand one pass to its stream (Python + ~12 launches), measured in the long region: the pass is GPU-bound while
+        # this stays below ms_per_step
+        "host_enqueue_ms_per_step": None if r["long_rate"] is None else r["long_rate"].get("host_enqueue_ms_per_step"),
         "value_long_steps": None if r["long_rate"] is None else r["long_rate"]["steps"],
         # the same K passes with the lane index rebuilt in every pass and the medoid stage without the previous pass's hint: what a
         # job pays whose every batch brings new lane tables (the timed loop replays resident batches: index built once, hint warm)

@@ -28,6 +28,7 @@ _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 # name -> (restype, argtypes); mirrors include/cm3d_hip.h one to one
 SIGNATURES = {
     "cm3d_abi_version": (_i32, []),
+    "cm3d_project_workgroups_per_cu": (_i32, [_i32]),
     "cm3d_error_string": (C.c_char_p, [_i32]),
     "cm3d_removed_words": (_i64, [_i32, _i32]),
     "cm3d_batch_begin": (_i32, [_p, _p, _i32, _p, _i64, _p]),

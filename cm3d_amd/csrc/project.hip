@@ -1442,6 +1442,15 @@ extern "C" int cm3d_project_hit_rows(const void *workspace, int64_t workspace_by
     return CM3D_OK;
 }
 
+// cm3d_project_workgroups_per_cu (cm3d_hip.h): 0 = fill the chip
+static int g_ph_wg_per_cu = 0;
+extern "C" int cm3d_project_workgroups_per_cu(int32_t n)
+{
+    const int prev = g_ph_wg_per_cu;
+    g_ph_wg_per_cu = n < 0 ? 0 : n;
+    return prev;
+}
+
 // workgroups of the projection kernel the chip holds at once.  CM3D_PH_BLOCKS overrides (experiments).
 static int ph_target_blocks(const void *kernel, size_t lds)
 {
@@ -1460,6 +1469,9 @@ static int ph_target_blocks(const void *kernel, size_t lds)
     // 64.4 us), and the registers the fourth would hold are what lets the small kernels of the neighbouring batches in flight
     // (masks, compaction, medoid) run beside it instead of behind it (three batches in flight: 0.177 -> 0.174 ms per pass).
     if (per_cu >= 4) --per_cu;
+    // a caller with several batches in flight leaves room beside the launch (cm3d_project_workgroups_per_cu): 768 / 512 / 384 workgroups
+    // give 2.302 / 2.343 / 2.363 M frames/s on C2 with three batches in flight, 609 / 613 / 606 k on C1, 849 / 865 / 850 k on C4
+    if (g_ph_wg_per_cu > 0 && g_ph_wg_per_cu < per_cu) per_cu = g_ph_wg_per_cu;
     return cus * per_cu;
 }
 
@@ -1522,6 +1534,11 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
         }
     }
     static int blocks_one[9 + 4] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // cached for the register-only variants (no dynamic LDS)
+    static int blocks_hint = 0;                                                   // ... under this value of cm3d_project_workgroups_per_cu
+    if (blocks_hint != g_ph_wg_per_cu) {
+        for (int &b : blocks_one) b = 0;
+        blocks_hint = g_ph_wg_per_cu;
+    }
     const int slot_id = pq ? 9 + (one ? 0 : 2) + (keep ? 1 : 0) : which;
     int target = (one || pq) ? blocks_one[slot_id] : 0;
     if (!target) {

@@ -767,6 +767,14 @@ class LiftPipeline:
         self.masks = [None] * depth
         self.uploaded = [torch.cuda.Event() for _ in range(depth)]      # recorded behind a slot's H2D copies (submit)
         self._next = 0
+        # With batches in flight the projection launch leaves a third of the chip to the other batches' kernels (two workgroups per CU
+        # instead of three: cm3d_project_workgroups_per_cu -- process-wide, results unaffected): +1-2 % frames/s at depth 3, while one batch
+        # at a time runs fastest with the launch filling the chip.  CM3D_PIPE_WG_PER_CU overrides (0: never ask).
+        want = int(os.environ.get("CM3D_PIPE_WG_PER_CU", "2"))
+        if depth >= 2 and want > 0:
+            self.engines[0].lib.cm3d_project_workgroups_per_cu(want)
+        elif depth == 1:
+            self.engines[0].lib.cm3d_project_workgroups_per_cu(0)
 
     @property
     def depth(self):

@@ -173,6 +173,13 @@ int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_fram
  * frame_sweep_off) must be <= 16; use the two separate calls otherwise.  Arguments as in cm3d_sweep_prep and
  * cm3d_project_hits.  Rows of 4 or 5 floats (the reference's .bin layouts) and the quad layout have their own instantiations. */
 #define CM3D_MAX_FUSED_SWEEPS 16
+/* How much of the chip one projection launch takes (process-wide; r04).  0 (the default): as many workgroups as fit minus one per
+ * CU -- the fastest launch when nothing else runs.  n >= 1: n workgroups per CU.  A caller that keeps several batches in flight on
+ * streams of their own (cm3d_amd.lifting.LiftPipeline) asks for 2: the launch alone takes 62 instead of 52 us on the headline shape, but
+ * the kernels of the other batches run beside it instead of behind it (three batches in flight: +1-2 % frames/s on C2, C1 and C4).
+ * Returns the previous value.  Results do not depend on it. */
+int cm3d_project_workgroups_per_cu(int32_t n);
+
 int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const float *intensity, const int32_t *sweep_row_off, int32_t n_sweeps,
                             int32_t max_sweeps_per_frame, const float *sweep_xf, const int32_t *frame_sweep_off,
                             float halfw, float *points, int32_t pt_cap, int32_t *pt_off, uint32_t *removed_bits,

@@ -97,6 +97,31 @@ def test_colsum_bit_exact(oracle):
         assert np.array_equal(cs.view(np.uint32), got["colsum"][o:e].view(np.uint32)), f"mask {m} column sums differ"
 
 
+def test_projection_share_of_the_chip_never_changes_a_result(oracle, raw_layout):
+    """cm3d_project_workgroups_per_cu (LiftPipeline asks for 2 per CU with batches in flight) only sizes the projection launch's grid:
+    the work lists hand every wave-chunk to exactly one wave whatever their number.  One batch under 0 (fill the chip), 1, 2 and 7 workgroups
+    per CU: every pass the oracle's results."""
+    import torch
+    from cm3d_amd import lifting
+    cfg = syn.config("c1", n_masks=24)
+    frames = [syn.make_frame(cfg, 40 + i) for i in range(3)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 3000, seed=1)]
+    hb = lifting.pack_frames(frames, lanes, [0] * 3, layout=raw_layout)
+    exp = oracle_batch(oracle, frames, lanes, [0] * 3, hb)
+    eng = lifting.LiftEngine()
+    eng.upload(hb)
+    prev = eng.lib.cm3d_project_workgroups_per_cu(0)
+    try:
+        for per_cu in (0, 1, 2, 7, 0):
+            eng.lib.cm3d_project_workgroups_per_cu(per_cu)
+            eng.run(masks="rle")
+            torch.cuda.synchronize()
+            eng.check_status()
+            _compare(hb, eng.download(), exp)
+    finally:
+        eng.lib.cm3d_project_workgroups_per_cu(prev)
+
+
 def test_medoid_hint_never_changes_a_result(oracle):
     """LiftEngine feeds the medoid stage's feedback word (does this batch hold a list of more than 448 points?) back as the next
     pass's hint (cm3d_medoid2).  A batch without long lists, then -- in the same engine, so with a hint that says "none" -- a batch
