@@ -21,6 +21,10 @@ import platform
 import sys
 import time
 
+# Four batches in flight want four hardware queues of their own and the runtime maps streams onto GPU_MAX_HW_QUEUES of them (4 by default, one
+# of which other work shares): read when the HIP runtime starts, so it is set before anything can start it.  (A value in the environment wins.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -339,8 +343,9 @@ def main(argv=None):
                     help="processes of the all-cores CPU baseline (-1 = every core this job may use; 0 = skip)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override a field of the synthetic config (e.g. --set n_masks=80); for experiments")
-    ap.add_argument("--in-flight", type=int, default=3,
-                    help="independent batches kept in flight per GPU (LiftPipeline depth; 1 = one batch at a time)")
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="independent batches kept in flight per GPU (LiftPipeline depth; 1 = one batch at a time).  r04: 4 with eight hardware "
+                         "queues and the projection launch at one workgroup per CU: 2.46-2.48 M frames/s against 2.29 M with 3 (five and more: worse)")
     ap.add_argument("--keep-cloud", action="store_true", help="also materialise the transformed cloud (16 B/row more HBM traffic)")
     ap.add_argument("--reuse-batch", action="store_true",
                     help="generate ONE synthetic batch and make every slot in flight a resident copy of it (the large shapes: generating "
@@ -442,14 +447,11 @@ def main(argv=None):
         calls = {"sweeps": eng.stage_sweeps, "masks": lambda s: eng.stage_masks(s, mode),
                  "project": eng.stage_sweep_project if fused else eng.stage_project,
                  "compact": eng.stage_compact, "medoid": eng.stage_medoid, "lanes": lanes_after_grid, "boxes": eng.stage_boxes}
-        for k in range(max(args.warmup, depth)):
-            pipe.rerun(k % depth, masks=mode)
-        torch.cuda.synchronize()
+        # Everything that is not a pass happens BEFORE the warm-up steps, so that the timed region follows them with nothing but the barrier
+        # and the synchronize in between: a few milliseconds of host work there (status read-backs, event creation) let the GPU's clocks
+        # drop, and the first region measured 3 % (three batches in flight) to 17 % (four) below every later one.
         if world > 1 and mode == modes[0]:
-            cdist.gather_records(eng.b.box, dst=0)      # untimed: sets up the RCCL channels the final gather uses
-        torch.cuda.synchronize()
-        for e in pipe.engines:
-            e.check_status()
+            cdist.gather_records(eng.b.box, dst=0)      # untimed: sets up the RCCL channels the final gather uses (the records' buffer exists since upload)
         ev_every = 1 if args.steps <= 16 else 8        # an event pair costs ~5 us of stream time: sample every 8th step
         for _ in range(0, args.steps, ev_every):        # created (first record) outside the timed region
             pe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -458,11 +460,16 @@ def main(argv=None):
             ev["project"].append(pe)
         graphs = None
         if args.graph:
+            for k in range(depth):
+                pipe.rerun(k, masks=mode)               # (a capture wants the once-only work of a slot's first pass done)
+            torch.cuda.synchronize()
             graphs = []
             for slot in range(depth):
                 with torch.cuda.stream(pipe.streams[slot]):
                     graphs.append(pipe.engines[slot].capture_graph(masks=mode))
             torch.cuda.synchronize()
+        for k in range(max(args.warmup, depth)):
+            pipe.rerun(k % depth, masks=mode)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -477,14 +484,18 @@ def main(argv=None):
                 pipe.rerun(step % depth, masks=mode, project_events=pe)       # LiftEngine.run() on that batch's stream
         gathered = None
         if mode == modes[0]:
-            # the single end-of-job exchange: fixed-size box records -> rank 0 (RCCL gather)
-            for s in pipe.streams:
-                torch.cuda.current_stream(dev).wait_stream(s)
+            # the single end-of-job exchange: fixed-size box records -> rank 0 (RCCL gather).  With more than one rank the records must be
+            # final first: a host synchronize (cross-stream event waits on the current stream -- wait_stream -- cost 0.4 ms of a 34 ms region
+            # with three batches in flight and 3.7 ms with four); one rank keeps its records, nothing to wait for before the synchronize below.
+            if world > 1:
+                torch.cuda.synchronize()
             gathered = cdist.gather_records(eng.b.box, dst=0)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        for e in pipe.engines:
+            e.check_status()                            # (of the warm-up and the timed passes; raises on any error flag)
         per_rank_dt = [dt]
         if world > 1:
             mine = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -619,7 +630,10 @@ def main(argv=None):
                       "are extra traffic and NOT counted, so `frac` cannot be inflated by bytes the kernel skips; avg_launch_ms = HIP events the "
                       "library records on the launch stream right around the kernel, inside the timed region: with several batches in flight "
                       "it holds the time the launch queues behind and shares the chip with the other batches' kernels (rocprof's execution time "
-                      "of the same launches: profiles/*_kernel_stats.csv); frac_alone = the same launch with nothing else on the GPU")
+                      "of the same launches: profiles/*_kernel_stats.csv) -- and since r04 the pipeline GIVES the launch only a part of the chip while batches are "
+                      "in flight (workgroups_per_cu_in_flight: one workgroup per CU of the three that fit with four batches in flight; the pass is faster "
+                      "for it, this launch slower), so `frac` says what the launch gets of the HBM while sharing, not what the kernel can do; "
+                      "frac_alone = the same launch with nothing else on the GPU and the whole chip, the figure to judge the kernel by")
     per_row = round(by["k_project_hits"] / max(1, rows), 2)
     roofline["rows_per_launch"] = rows
     roofline["bytes_per_row"] = per_row

@@ -767,10 +767,12 @@ class LiftPipeline:
         self.masks = [None] * depth
         self.uploaded = [torch.cuda.Event() for _ in range(depth)]      # recorded behind a slot's H2D copies (submit)
         self._next = 0
-        # With batches in flight the projection launch leaves a third of the chip to the other batches' kernels (two workgroups per CU
-        # instead of three: cm3d_project_workgroups_per_cu -- process-wide, results unaffected): +1-2 % frames/s at depth 3, while one batch
-        # at a time runs fastest with the launch filling the chip.  CM3D_PIPE_WG_PER_CU overrides (0: never ask).
-        want = int(os.environ.get("CM3D_PIPE_WG_PER_CU", "2"))
+        # With batches in flight the projection launch leaves part of the chip to the other batches' kernels (two workgroups per CU
+        # instead of three, one with four batches in flight: cm3d_project_workgroups_per_cu -- process-wide, results unaffected): +1-2 %
+        # frames/s at depth 3, +4 % at depth 4, while one batch at a time runs fastest with the launch filling the chip.
+        # CM3D_PIPE_WG_PER_CU overrides (0: never ask).  Four batches in flight need GPU_MAX_HW_QUEUES >= 8 in the environment before the HIP
+        # runtime starts (bench.py sets it): on the default four hardware queues a fourth stream shares one and the pass gets slower.
+        want = int(os.environ.get("CM3D_PIPE_WG_PER_CU", "1" if depth >= 4 else "2"))       # (four in flight: 2.51 M frames/s at 1, 2.46 at 2, 2.40 at 3)
         if depth >= 2 and want > 0:
             self.engines[0].lib.cm3d_project_workgroups_per_cu(want)
         elif depth == 1:

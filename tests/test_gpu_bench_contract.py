@@ -27,7 +27,7 @@ def test_lifting_bench_line():
     assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert d["value"] > 0 and abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
-    assert "workload" in d["config"] and d["config"]["batches_in_flight"] == 3
+    assert "workload" in d["config"] and d["config"]["batches_in_flight"] == 4
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "traffic" in rf
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
