@@ -67,7 +67,7 @@ def main(tag):
             if k in per:
                 traffic["c2_rle"][k + "_insts_valu"] = int(per[k])
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
-    for label, fn in (("three batches in flight (default)", f"profiles/{tag}_c2_rle_kernel_stats.csv"),
+    for label, fn in (("batches in flight (default: four since the end of r04)", f"profiles/{tag}_c2_rle_kernel_stats.csv"),
                       ("one batch at a time", f"profiles/{tag}_c2_rle_one_batch_kernel_stats.csv")):
         rows = list(csv.DictReader(open(fn)))
         print(label)
