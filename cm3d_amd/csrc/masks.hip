@@ -469,12 +469,19 @@ static __device__ __forceinline__ int rw_chunk_scan(const uint32_t *__restrict__
 {
     const int i0 = base + lane * RW_PER;
     int sum = 0;
-    if (i0 + RW_PER <= n && ((((uintptr_t)(cnts + i0)) & 15) == 0)) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(cnts + i0), b = *reinterpret_cast<const uint4 *>(cnts + i0 + 4);
+    // (r04: the 16-byte loads took only lanes whose runs happen to start on a 16-byte boundary -- a quarter of the masks --, the others eight
+    // loads inside eight divergent branches, which the compiler waits for one after the other.  A whole chunk inside the mask -- uniform --
+    // is two 16-byte loads per lane from a 4-byte-aligned address, the chip's unaligned mode; the mask's last chunk eight loads of a clamped
+    // index, unconditional, so that they are in flight together.)
+    typedef uint32_t rw_u4 __attribute__((ext_vector_type(4), aligned(4)));
+    if (base + RW_CHUNK <= n) {
+        const rw_u4 a = *reinterpret_cast<const rw_u4 *>(cnts + i0), b = *reinterpret_cast<const rw_u4 *>(cnts + i0 + 4);
         v[0] = (int)a.x; v[1] = (int)a.y; v[2] = (int)a.z; v[3] = (int)a.w; v[4] = (int)b.x; v[5] = (int)b.y; v[6] = (int)b.z; v[7] = (int)b.w;
     } else {
 #pragma unroll
-        for (int q = 0; q < RW_PER; ++q) v[q] = i0 + q < n ? (int)cnts[i0 + q] : 0;
+        for (int q = 0; q < RW_PER; ++q) v[q] = (int)cnts[min(i0 + q, n - 1)];
+#pragma unroll
+        for (int q = 0; q < RW_PER; ++q) v[q] = i0 + q < n ? v[q] : 0;
     }
 #pragma unroll
     for (int q = 0; q < RW_PER; ++q) sum += v[q];
