@@ -1164,8 +1164,17 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *
     const int32_t *grp_f = grp + (size_t)f * zstride;
     const int ngrp_max = (nwc_max + PH_GRP - 1) / PH_GRP;
     // ---- everything the offsets are made of is requested at once
+    // (r04: loads in ROUNDS of unconditional, clamped loads whose values are masked afterwards.  A load inside a loop of unknown trip count or a
+    // divergent branch is waited for before the next is issued: the chunks before the wave's inside its group alone were up to 15 dependent
+    // round trips per wave, where the comment above said one.)
     int fsum = 0;                                                      // in-mask points of the frames before this one
-    for (int q = lane; q < f; q += 64) fsum += frame_hits[q];
+    for (int q0 = 0; q0 < f; q0 += 4 * 64) {
+        int t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = frame_hits[min(q0 + u * 64 + lane, f - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fsum += q0 + u * 64 + lane < f ? t[u] : 0;
+    }
     int dsum = 0;                                                      // dropped rows before wave-chunk c0 (fused: counted by the projection)
     if (fused) {
         for (int q = lane; q < g; q += 64) dsum += grp_f[ngrp_max * nm_cap + q];
@@ -1180,13 +1189,20 @@ __global__ __launch_bounds__(PH_THREADS, 4) void k_compact_hits(const uint32_t *
         int cnt = 0, pre = 0;
         if (k < nm) {
             cnt = hit_count[m0 + k];
-            int q = 0;
-            for (; q + 4 <= g; q += 4) {                               // groups before the wave's
-                const int a0 = grp_f[(q + 0) * nm_cap + k], a1 = grp_f[(q + 1) * nm_cap + k], a2 = grp_f[(q + 2) * nm_cap + k], a3 = grp_f[(q + 3) * nm_cap + k];
-                pre += (a0 + a1) + (a2 + a3);
+            for (int q = 0; q < g; q += 8) {                           // groups before the wave's (uniform trip count), eight per round
+                int a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = grp_f[min(q + u, g - 1) * nm_cap + k];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pre += q + u < g ? a[u] : 0;
             }
-            for (; q < g; ++q) pre += grp_f[q * nm_cap + k];
-            for (int c = cg0; c < c0; ++c) pre += cnt_f[(size_t)c * nm_cap + k];         // wave-chunks before it inside its group (< PH_GRP)
+            for (int c = cg0; c < c0; c += 8) {                        // wave-chunks before it inside its group (< PH_GRP: two rounds at most)
+                int a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = cnt_f[(size_t)min(c + u, c0 - 1) * nm_cap + k];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pre += c + u < c0 ? a[u] : 0;
+            }
         }
         const int inc = cm3d_wave_incl_scan(cnt);
         if (k < nm) s_run[k] = carry + inc - cnt + pre;                // + the frame's base, below
