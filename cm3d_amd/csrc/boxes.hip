@@ -140,10 +140,14 @@ __global__ __launch_bounds__(256) void k_lane_nn_grid(const float *__restrict__ 
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = cm3d_lane();
     if (k >= n_masks) return;
-    if (medoid_pos[k] < 0) { if (lane == 0) { lane_idx[k] = -1; lane_dist[k] = INFINITY; } return; }
-    const int tb = frame_lane[mask_frame[k]];
+    // (everything that only needs the mask's number is requested before the first branch: behind `if (medoid_pos[k] < 0) return` the other
+    // loads started a round trip later each)
+    const int mp = medoid_pos[k], mf = mask_frame[k];
+    const float cxf = centroid[3 * k], cyf = centroid[3 * k + 1];
+    if (mp < 0) { if (lane == 0) { lane_idx[k] = -1; lane_dist[k] = INFINITY; } return; }
+    const int tb = frame_lane[mf];
     const LaneGrid g = grids[tb];
-    const double cx = (double)centroid[3 * k], cy = (double)centroid[3 * k + 1];
+    const double cx = (double)cxf, cy = (double)cyf;
     double d2cut = INFINITY, sbest = INFINITY;
     int jbest = 0x7FFFFFFF;
     bool resolved = true;
@@ -211,8 +215,11 @@ __global__ __launch_bounds__(256) void k_lane_nn_grid(const float *__restrict__ 
                     if (m & 1) { c0 = qi + r_lo; c1 = qi + r_hi; } else { c0 = qi - r_hi; c1 = qi - r_lo; }
                 }
                 c0 = max(c0, 0); c1 = min(c1, g.gw - 1);
-                int a = 0, b = 0;
-                if (sg < nseg && row >= 0 && row < g.gh && c0 <= c1) { a = cs[row * g.gw + c0]; b = cs[row * g.gw + c1 + 1]; }
+                // (unconditional loads of clamped cells, masked afterwards: inside the branch the two were waited for one after the other)
+                const bool seg_ok = sg < nseg && row >= 0 && row < g.gh && c0 <= c1;
+                const int rowc = min(max(row, 0), g.gh - 1), c0c = min(c0, g.gw - 1), c1c = max(c1, 0);
+                int a = cs[rowc * g.gw + c0c], b = cs[rowc * g.gw + c1c + 1];
+                if (!seg_ok) { a = 0; b = 0; }
                 visit(a, b);
             }
             r_done = r_hi;
@@ -391,12 +398,20 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
 
     for (int k = lane_id; k < nm; k += 64) {
         const int m = m0 + k;
-        const bool valid = medoid_pos[m] >= 0;
+        // (one wave per frame and a score of lanes at work: the kernel is as long as its chain of dependent loads.  Everything indexed by the mask is
+        // requested up front, the lane point and the class's tables one round trip later; inside `if (valid)` each waited for the one before.)
+        const int mp = medoid_pos[m], li = lane_idx[m];
         int cls = class_id[m];
+        const float c_x = centroid[3 * m], c_y = centroid[3 * m + 1], c_z = centroid[3 * m + 2];
+        const double ld_m = lane_dist[m], score_m = score[m];
+        const bool valid = mp >= 0;
         if (cls < 0 || cls >= n_classes) cls = 0;
+        const float yaw_m = lane[(size_t)(valid ? max(ltab + li, 0) : 0) * 3 + 2];        // (a mask without a medoid: the array's first point, unused)
+        const int veh = is_vehicle[cls], grp_c = nms_group[cls];
+        const double prior_l = prior_wlh[3 * cls + 0], prior_w = prior_wlh[3 * cls + 1];
         double tx = 0.0, ty = 0.0, tz = 0.0, qw = 1.0, qz = 0.0, yaw_out = 0.0, ld = 0.0;
         if (valid) {
-            double cx = (double)centroid[3 * m], cy = (double)centroid[3 * m + 1], cz = (double)centroid[3 * m + 2];
+            double cx = (double)c_x, cy = (double)c_y, cz = (double)c_z;
             if (waymo) {
                 // src/waymo/2d_to_3d.py:812-816: np.dot(inv(float32 pose), [centroid, 1]) in float64
                 const double gx = cx, gy = cy, gz = cz;
@@ -404,10 +419,10 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
                 cy = Pi[4] * gx + Pi[5] * gy + Pi[6] * gz + Pi[7];
                 cz = Pi[8] * gx + Pi[9] * gy + Pi[10] * gz + Pi[11];
             }
-            const float yaw = lane[(size_t)(ltab + lane_idx[m]) * 3 + 2];      // :295, an f32 value
-            yaw_out = (double)yaw; ld = lane_dist[m];
+            const float yaw = yaw_m;                                           // :295, an f32 value
+            yaw_out = (double)yaw; ld = ld_m;
             tx = cx; ty = cy; tz = cz;
-            if (is_vehicle[cls]) {
+            if (veh) {
                 // :788-789 np.cos/np.sin of a float32 give float32
                 const double cs = (double)cosf(yaw), sn = (double)sinf(yaw);
                 // pyquaternion Quaternion(matrix=Rz): trace method on M^T
@@ -424,7 +439,7 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
                 double alpha = atan(fabs(ey) / fabs(ex));
                 if (ex < 0) { if (ey < 0) alpha = -PI + alpha; else alpha = PI - alpha; }
                 else        { if (ey < 0) alpha = -alpha; }
-                const double l = prior_wlh[3 * cls + 0], w = prior_wlh[3 * cls + 1];
+                const double l = prior_l, w = prior_w;
                 const double o1 = fabs(w / (2.0 * sin(theta - alpha)));
                 const double o2 = fabs(l / (2.0 * cos(theta - alpha)));
                 double off = o1 < o2 ? o1 : o2;
@@ -441,8 +456,8 @@ __global__ __launch_bounds__(64) void k_box_nms(const float *__restrict__ centro
             }
         }
         double *b = box + (size_t)m * CM3D_BOX_STRIDE;
-        b[0] = tx; b[1] = ty; b[2] = tz; b[3] = qw; b[4] = qz; b[5] = yaw_out; b[6] = ld; b[7] = score[m]; b[8] = (double)cls;
-        s_x[k] = tx; s_y[k] = ty; s_s[k] = score[m]; s_lab[k] = nms_group[cls];
+        b[0] = tx; b[1] = ty; b[2] = tz; b[3] = qw; b[4] = qz; b[5] = yaw_out; b[6] = ld; b[7] = score_m; b[8] = (double)cls;
+        s_x[k] = tx; s_y[k] = ty; s_s[k] = score_m; s_lab[k] = grp_c;
         s_valid[k] = valid; s_sup[k] = 0; s_keep[k] = 0;
     }
     nms_phase(nm, lane_id, nms_thr, s_x, s_y, s_s, s_lab, s_order, s_valid, s_sup, s_keep);

@@ -686,11 +686,17 @@ __global__ __launch_bounds__(256) void k_medoid_reduce(const float4 *__restrict_
     const int t0 = tile_off[m], t1 = min(tile_off[m + 1], tile_cap);
     int bj = -1;
     float bs = 0.f;
-    for (int t = t0; t < t1; ++t) {
-        const TileBest b = tile_best[t];
-        if (b.j == 0x7FFFFFFF) continue;
-        const bool bn = b.s != b.s, cn = bs != bs;
-        if (bj < 0 || (bn && !cn) || (!bn && !cn && b.s < bs)) { bs = b.s; bj = b.j; }
+    for (int tb = t0; tb < t1; tb += 8) {             // (eight tiles per round trip, unconditional loads of a clamped tile: one load per iteration before)
+        TileBest bb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bb[u] = tile_best[min(tb + u, t1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const TileBest b = bb[u];
+            if (tb + u >= t1 || b.j == 0x7FFFFFFF) continue;
+            const bool bn = b.s != b.s, cn = bs != bs;
+            if (bj < 0 || (bn && !cn) || (!bn && !cn && b.s < bs)) { bs = b.s; bj = b.j; }
+        }
     }
     medoid_pos[m] = bj;
     float cx = 0.f, cy = 0.f, cz = 0.f;
