@@ -1674,8 +1674,11 @@ extern "C" int cm3d_compact_hits(const uint32_t *hit_words, int32_t planes, int3
     const int tile_cap = (int)(tile_cap64 > 0x7FFFFFFF ? 0x7FFFFFFF : tile_cap64);
     PhXyzSrc xs;
     xs.raw = raw; xs.intensity = intensity; xs.raw_stride = raw_stride; xs.sweep_xf = sweep_xf; xs.points = (const float4 *)points;
-    static int span = 0;
-    if (!span) { const char *e = getenv("CM3D_CP_SPAN"); span = e ? atoi(e) : 4; if (span != 2 && span != 8) span = 4; }
+    // wave-chunks per wave: 4; 8 for frames of 150 k points and more (C4: 906 -> 920 k frames/s; C2 2.59 -> 2.55 M with 8, C1 and C5 no difference);
+    // CM3D_CP_SPAN = 2 / 4 / 8 forces one (experiments, tests/test_gpu_golden.py)
+    static int span_forced = -1;
+    if (span_forced < 0) { const char *e = getenv("CM3D_CP_SPAN"); span_forced = e ? atoi(e) : 0; if (span_forced != 2 && span_forced != 4 && span_forced != 8) span_forced = 0; }
+    const int span = span_forced ? span_forced : (nwc_max >= 600 ? 8 : 4);
     // dynamic LDS: a slice of nm_cap ints per wave; the builder row needs MD_FROM_COUNTS_LDS ints
     const size_t cp_lds = sizeof(int) * (size_t)std::max(PH_WAVES * nm_cap, (int)MD_FROM_COUNTS_LDS(PH_THREADS));
 #define CP_LAUNCH(SPAN)                                                                                                          \

@@ -468,6 +468,43 @@ def test_every_form_of_the_rle_kernel_equals_the_oracle(env):
     assert r.returncode == 0 and "FORM OK" in r.stdout, r.stderr[-3000:]
 
 
+_CP_SPAN_SCRIPT = """
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch
+from cm3d_amd import lifting, synthetic as syn
+from oracle import oracle as orc
+from tests.helpers import oracle_batch
+from tests.test_gpu_parity import _compare
+for name, over, n in (("tiny", dict(), 5), ("c1", dict(n_masks=24), 2)):
+    cfg = syn.config(name, **over)
+    frames = [syn.make_frame(cfg, 70 + i) for i in range(n)]
+    lanes = [syn.make_lane_table(frames[0].ego_xyz[:2], 3000, seed=1)]
+    hb = lifting.pack_frames(frames, lanes, [0] * n)
+    exp = oracle_batch(orc, frames, lanes, [0] * n, hb)
+    eng = lifting.LiftEngine()
+    eng.upload(hb)
+    eng.run(masks="rle")
+    torch.cuda.synchronize()
+    eng.check_status()
+    _compare(hb, eng.download(), exp)
+print("SPAN OK")
+"""
+
+
+@pytest.mark.parametrize("span", ["2", "8"])
+def test_every_span_of_the_compaction_equals_the_oracle(span):
+    """cm3d_compact_hits gives a wave 4 wave-chunks (8 for frames of 150 k points and more); CM3D_CP_SPAN forces 2 / 4 / 8 (read once per
+    process, hence the child): the same index lists, coordinates and everything behind them under each."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CP_SPAN_SCRIPT.format(root=root)], env=dict(os.environ, CM3D_CP_SPAN=span), capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0 and "SPAN OK" in r.stdout, r.stderr[-3000:]
+
+
 def test_g2e_sweep_loop_of_the_reference():
     """G2e on the device: raw sweeps -> fused sweep preparation + projection + compaction against what the REFERENCE'S OWN sweep
     loop (from_file, ego-box filter, rotate / translate twice, hstack; gen_golden_chain.py) and its loop body produced -- the
