@@ -1468,7 +1468,7 @@ extern "C" int cm3d_project_workgroups_per_cu(int32_t n)
 }
 
 // workgroups of the projection kernel the chip holds at once.  CM3D_PH_BLOCKS overrides (experiments).
-static int ph_target_blocks(const void *kernel, size_t lds)
+static int ph_target_blocks(const void *kernel, size_t lds, bool share)
 {
     static int forced = -1, cus = 0;
     if (forced < 0) {
@@ -1487,7 +1487,9 @@ static int ph_target_blocks(const void *kernel, size_t lds)
     if (per_cu >= 4) --per_cu;
     // a caller with several batches in flight leaves room beside the launch (cm3d_project_workgroups_per_cu): 768 / 512 / 384 workgroups
     // give 2.302 / 2.343 / 2.363 M frames/s on C2 with three batches in flight, 609 / 613 / 606 k on C1, 849 / 865 / 850 k on C4
-    if (g_ph_wg_per_cu > 0 && g_ph_wg_per_cu < per_cu) per_cu = g_ph_wg_per_cu;
+    // (k_project_q only: the multi-plane kernel of frames with more than 32 masks -- hit words in LDS -- is not what the others wait for on its shapes;
+    // C5, four in flight: 47.9 k frames/s with its full grid, 47.4 k at one workgroup per CU)
+    if (share && g_ph_wg_per_cu > 0 && g_ph_wg_per_cu < per_cu) per_cu = g_ph_wg_per_cu;
     return cus * per_cu;
 }
 
@@ -1558,7 +1560,7 @@ static int ph_launch(const PhSweepIn *fused, const float *points, const int32_t 
     const int slot_id = pq ? 9 + (one ? 0 : 2) + (keep ? 1 : 0) : which;
     int target = (one || pq) ? blocks_one[slot_id] : 0;
     if (!target) {
-        target = ph_target_blocks(fn, lds);
+        target = ph_target_blocks(fn, lds, pq);
         if (one || pq) blocks_one[slot_id] = target;
     }
     // tickets per frame: about PH_OVERSUB times as many waves as the chip holds at once (see the kernel's header), at least

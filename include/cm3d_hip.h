@@ -177,7 +177,8 @@ int cm3d_project_hits(const float *points, const int32_t *pt_off, int32_t n_fram
  * CU -- the fastest launch when nothing else runs.  n >= 1: n workgroups per CU.  A caller that keeps several batches in flight on
  * streams of their own (cm3d_amd.lifting.LiftPipeline) asks for 2: the launch alone takes 62 instead of 52 us on the headline shape, but
  * the kernels of the other batches run beside it instead of behind it (three batches in flight: +1-2 % frames/s on C2, C1 and C4).
- * Returns the previous value.  Results do not depend on it. */
+ * Returns the previous value.  Results do not depend on it.  (Honoured by the launch for frames of up to 32 masks on the quad layout, the one the
+ * other batches' kernels queue behind; the multi-plane launch keeps its grid.) */
 int cm3d_project_workgroups_per_cu(int32_t n);
 
 int cm3d_sweep_project_hits(const float *raw, int32_t raw_stride, const float *intensity, const int32_t *sweep_row_off, int32_t n_sweeps,
