@@ -37,6 +37,7 @@ SIGNATURES = {
     "cm3d_rle_to_dense": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p]),
     "cm3d_erode_pack": (_i32, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "cm3d_rle_erode_pack": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p]),
+    "cm3d_rle_erode_pack_begin": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _p, _i64, _p]),
     "cm3d_project_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "cm3d_project_hit_rows": (_i32, [_p, _i64, _i32, _i32, _i32, _p, _p]),
     "cm3d_project_hits": (_i32, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32,

@@ -539,13 +539,24 @@ extern "C" int cm3d_rw_diag_read_waves(unsigned long long *out_host, int n_waves
 }
 #endif
 
+struct RwBegin { int32_t *status; int32_t *hit_count; uint32_t *removed_bits; long long removed_words; int n_masks; };
+
 __global__ __launch_bounds__(RW_THREADS, 5) void k_rle_erode_pack_wave(const uint32_t *__restrict__ cnts_all, const int32_t *__restrict__ rle_off,
                                                                         int n_masks, int W, int H, int Wp, int lds_words,
-                                                                        uint32_t *__restrict__ packed, int32_t *__restrict__ bbox, int max_bands, int diag)
+                                                                        uint32_t *__restrict__ packed, int32_t *__restrict__ bbox, int max_bands, int diag,
+                                                                        const RwBegin begin)
 {
 #ifndef CM3D_DIAG
     diag = 0;                                                   // (the ablation switches exist in the diagnostic build only: each was a loop-invariant mask in scalar registers)
 #endif
+    // cm3d_rle_erode_pack_begin: the per-pass reset (cm3d_batch_begin's: status word, hit counts, removed-row bits) rides on this launch -- the
+    // first of a pass -- instead of a launch of its own.  Nothing in this kernel reads or writes those arrays; whatever does runs behind it.
+    if (begin.status) {
+        const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+        if (i0 < CM3D_STATUS_WORDS) begin.status[i0] = 0;
+        for (long long i = i0; i < begin.n_masks; i += step) begin.hit_count[i] = 0;
+        for (long long i = i0; i < begin.removed_words; i += step) begin.removed_bits[i] = 0u;
+    }
     extern __shared__ __align__(16) uint32_t s_all[];
     __shared__ int s_part[RW_WAVES][4];                         // the bands' shares of the bounding box
     const int lane = cm3d_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -772,9 +783,12 @@ extern "C" int cm3d_rle_to_dense(const uint32_t *rle_counts, const int32_t *rle_
     return CM3D_OK;
 }
 
-extern "C" int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int32_t n_masks, int32_t total_runs,
-                                   int32_t W, int32_t H, uint32_t *packed, int32_t *bbox, void *workspace,
-                                   int64_t workspace_bytes, cm3d_stream_t stream)
+extern "C" int cm3d_batch_begin(int32_t *status, int32_t *hit_count, int32_t n_masks, uint32_t *removed_bits, int64_t removed_words,
+                                cm3d_stream_t stream);
+
+static int rle_erode_pack_impl(const uint32_t *rle_counts, const int32_t *rle_off, int32_t n_masks, int32_t total_runs,
+                               int32_t W, int32_t H, uint32_t *packed, int32_t *bbox, void *workspace,
+                               int64_t workspace_bytes, const RwBegin begin, cm3d_stream_t stream)
 {
     if (!rle_counts || !rle_off || !packed || !bbox || !workspace) return CM3D_ERR_ARG;
     if (n_masks <= 0 || total_runs <= 0 || n_masks > total_runs || W <= 0 || H <= 0 || W > 32 * EP_MAX_WP || W > 32767 || H > 32767)
@@ -814,11 +828,33 @@ extern "C" int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rl
         if (gcap < 0) { const char *e = getenv("CM3D_RLE_GRID"); gcap = e ? atoi(e) : 0; }
         if (bands == 1 && gcap > 0 && grid > gcap) grid = gcap;
         hipLaunchKernelGGL(k_rle_erode_pack_wave, dim3(grid), dim3(RW_THREADS), lds, st,
-                           rle_counts, rle_off, n_masks, W, H, Wp, lds_wave, packed, bbox, bands, rle_diag);
+                           rle_counts, rle_off, n_masks, W, H, Wp, lds_wave, packed, bbox, bands, rle_diag, begin);
     } else {
+        if (begin.status) {                 // (the workgroup-per-mask form does not carry the reset: a launch of its own, as cm3d_batch_begin makes it)
+            const int rc = cm3d_batch_begin(begin.status, begin.hit_count, begin.n_masks, begin.removed_bits, begin.removed_words, stream);
+            if (rc != CM3D_OK) return rc;
+        }
         hipLaunchKernelGGL(k_rle_erode_pack, dim3(n_masks), dim3(EP_THREADS), (size_t)lds_words * 4, st, rle_counts, rle_off, W, H, Wp,
                            lds_words, packed, bbox);
     }
     CM3D_CHECK_LAUNCH();
     return CM3D_OK;
+}
+
+extern "C" int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int32_t n_masks, int32_t total_runs,
+                                   int32_t W, int32_t H, uint32_t *packed, int32_t *bbox, void *workspace,
+                                   int64_t workspace_bytes, cm3d_stream_t stream)
+{
+    const RwBegin none = {nullptr, nullptr, nullptr, 0, 0};
+    return rle_erode_pack_impl(rle_counts, rle_off, n_masks, total_runs, W, H, packed, bbox, workspace, workspace_bytes, none, stream);
+}
+
+extern "C" int cm3d_rle_erode_pack_begin(const uint32_t *rle_counts, const int32_t *rle_off, int32_t n_masks, int32_t total_runs,
+                                         int32_t W, int32_t H, uint32_t *packed, int32_t *bbox, void *workspace,
+                                         int64_t workspace_bytes, int32_t *status, int32_t *hit_count, int32_t n_count_masks,
+                                         uint32_t *removed_bits, int64_t removed_words, cm3d_stream_t stream)
+{
+    if (!status || !hit_count || n_count_masks < 0 || removed_words < 0 || (removed_words > 0 && !removed_bits)) return CM3D_ERR_ARG;
+    const RwBegin begin = {status, hit_count, removed_bits, (long long)removed_words, n_count_masks};
+    return rle_erode_pack_impl(rle_counts, rle_off, n_masks, total_runs, W, H, packed, bbox, workspace, workspace_bytes, begin, stream);
 }

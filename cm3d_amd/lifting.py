@@ -497,11 +497,14 @@ class LiftEngine:
         return b.dense
 
     # -- the stages, in reference order
-    def stage_begin(self, st):
-        """Resets the per-pass state and starts the lane-grid build on the side stream."""
+    def stage_begin(self, st, defer_reset=False):
+        """Resets the per-pass state and starts the lane-grid build on the side stream.  defer_reset: the reset rides on the mask stage's
+        launch instead (stage_masks(..., reset=True): run() does that for resident run lengths on the fused-sweeps path, one launch less
+        per pass)."""
         b = self.b
-        check(self.lib.cm3d_batch_begin(_ptr(b.status), _ptr(b.hit_count), b.M, _ptr(b.removed_bits), b.removed_words, st),
-              "cm3d_batch_begin")
+        if not defer_reset:
+            check(self.lib.cm3d_batch_begin(_ptr(b.status), _ptr(b.hit_count), b.M, _ptr(b.removed_bits), b.removed_words, st),
+                  "cm3d_batch_begin")
         if self._lane["built"]:
             return                           # same lane tables as the last build: the index is still valid
         main = torch.cuda.current_stream(self.dev)
@@ -529,8 +532,17 @@ class LiftEngine:
                                        _ptr(b.sweep_xf), _ptr(b.frame_sweep_off), b.F, b.halfw, _ptr(b.points), b.pt_cap,
                                        _ptr(b.pt_off), _ptr(b.removed_bits), _ptr(b.status), st), "cm3d_sweep_prep")
 
-    def stage_masks(self, st, masks="dense"):
+    def stage_masks(self, st, masks="dense", reset=False):
+        """reset (run lengths only): this launch also does cm3d_batch_begin's work -- it must then be the first call of the pass."""
         b = self.b
+        if reset:
+            if masks != "rle":
+                raise ValueError("the per-pass reset rides on the run-length mask launch only")
+            check(self.lib.cm3d_rle_erode_pack_begin(_ptr(b.rle_counts), _ptr(b.rle_off), b.M, b.hb.rle_counts.size, b.W, b.H,
+                                                     _ptr(b.packed), _ptr(b.bbox), _ptr(b.rle_ws), b.rle_ws_bytes,
+                                                     _ptr(b.status), _ptr(b.hit_count), b.M, _ptr(b.removed_bits), b.removed_words, st),
+                  "cm3d_rle_erode_pack_begin")
+            return
         if masks == "dense":
             if b.dense is None:
                 raise Cm3dError("dense masks requested but not resident: call decode_masks_dense() or pass dense_masks")
@@ -640,11 +652,14 @@ class LiftEngine:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 stage_events.append(e)
-        self.stage_begin(st)
+        # (resident run lengths on the fused-sweeps path: the mask launch is the pass's first and carries the reset -- one launch and one
+        # launch boundary less per pass; CM3D_FUSED_RESET=0: the reset as a launch of its own)
+        fused_reset = masks == "rle" and self.can_fuse_sweeps() and os.environ.get("CM3D_FUSED_RESET", "1") != "0"
+        self.stage_begin(st, defer_reset=fused_reset)
         mark()
         if not self.can_fuse_sweeps():
             self.stage_sweeps(st)
-        self.stage_masks(st, masks)
+        self.stage_masks(st, masks, reset=fused_reset)
         if not self.can_fuse_sweeps():
             self.stage_project(st, project_events)
         else:

@@ -132,6 +132,14 @@ int cm3d_rle_erode_pack(const uint32_t *rle_counts, const int32_t *rle_off, int3
                         int32_t W, int32_t H, uint32_t *packed, int32_t *bbox, void *workspace,
                         int64_t workspace_bytes, cm3d_stream_t stream);
 
+/* The same launch carrying the per-pass reset of cm3d_batch_begin (status word, hit_count[n_count_masks], removed-row bits): the mask stage is the
+ * first stage of a pass over resident run lengths, and a launch of its own for the reset cost the pass a launch boundary (r04).  Only for passes
+ * whose FIRST call is this one (cm3d_sweep_prep, which writes status and removed bits, must not have run before it in the pass). */
+int cm3d_rle_erode_pack_begin(const uint32_t *rle_counts, const int32_t *rle_off, int32_t n_masks, int32_t total_runs,
+                              int32_t W, int32_t H, uint32_t *packed, int32_t *bbox, void *workspace, int64_t workspace_bytes,
+                              int32_t *status, int32_t *hit_count, int32_t n_count_masks, uint32_t *removed_bits, int64_t removed_words,
+                              cm3d_stream_t stream);
+
 /* ---- a4-a7: projection + in-image + in-mask test ----------------------------
  * Replaces the per-mask block 2d_to_3d.py:553-613 (clone, 2x translate/rotate,
  * view_points, in-image test, floor, mask gather incl. the floor(u)!=0 && floor(v)!=0
